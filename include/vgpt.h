@@ -1,0 +1,184 @@
+/*
+ * vgpt.h — C ABI of libvgpt_hip.so: the MI355X (gfx950) kernels behind the
+ * next-clip diffusion hot path of Video-GPT.
+ *
+ * Every entry point replaces one piece of arithmetic the reference executes
+ * through PyTorch ops; the reference site each one stands in for is cited as
+ * `path:line` relative to the reference checkout (third-party pins:
+ * transformers==4.47.1 Phi3 blocks, diffusers==0.29.0 AutoencoderKL).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless a parameter is named host_*;
+ *   - outputs and workspaces are caller-allocated; nothing here allocates,
+ *     frees or synchronises, so every call is capturable into a hipGraph;
+ *   - `stream` is a hipStream_t passed as void*;
+ *   - return 0 on success, <0 on failure (VGPT_ERR_*); the message of the last
+ *     failure on the calling thread is returned by vgpt_last_error();
+ *   - bf16 tensors are raw 16-bit bfloat16; "row-major" means last dim contiguous.
+ */
+#ifndef VGPT_H
+#define VGPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGPT_OK 0
+#define VGPT_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, misaligned) */
+#define VGPT_ERR_UNSUPPORTED (-2) /* shape outside what the kernel was built for */
+#define VGPT_ERR_HIP (-3)         /* HIP runtime error at launch */
+
+/* activation of the gated MLP (Phi3MLP: down(up * act(gate)); config.hidden_act) */
+#define VGPT_ACT_SILU 0
+#define VGPT_ACT_GELU 1      /* erf form  */
+#define VGPT_ACT_GELU_TANH 2 /* tanh form */
+#define VGPT_ACT_NONE 3
+
+/* epilogues of vgpt_gemm_bf16 */
+#define VGPT_EPI_NONE 0  /* C = A W^T                       */
+#define VGPT_EPI_RESID 1 /* C = A W^T + R   (residual add)  */
+#define VGPT_EPI_BIAS 2  /* C = A W^T + bias[n]             */
+
+/* prediction type of the sampler (LVM/scheduler.py:178) */
+#define VGPT_PRED_V 0
+#define VGPT_PRED_X1 1
+
+const char* vgpt_last_error(void);
+int vgpt_abi_version(void);
+
+/* ---- transformer block -------------------------------------------------- */
+
+/* Phi3RMSNorm (transformers 4.47.1 modeling_phi3.py Phi3RMSNorm.forward; call
+ * sites OmniGen/transformer.py:196-214): y = bf16(bf16(x * rsqrt(mean(x^2)+eps)) * w),
+ * fp32 accumulation. x,y: (rows, H) bf16 row-major; w: (H) bf16. H % 8 == 0. */
+int vgpt_rmsnorm_fwd(const void* x, const void* w, void* y, int64_t rows, int64_t H, float eps,
+                     void* stream);
+
+/* Phi3RotaryEmbedding.forward (cos/sin table): cos/sin[t][i] = f(pos[t] * inv_freq[i]),
+ * i < half; rounded to bf16 and stored back as fp32 when round_bf16 != 0 (the
+ * reference casts cos/sin to the model dtype, LVM/transform/sdpa_transform.py:52). */
+int vgpt_rope_table(const int64_t* position_ids, const float* inv_freq, float* cos_out,
+                    float* sin_out, int64_t tokens, int half, int round_bf16, void* stream);
+
+/* apply_rotary_pos_emb on the q and k parts of a fused qkv buffer, in place
+ * (LVM/transform/sdpa_transform.py:53). qkv: (tokens, (n_q+2*n_kv)*hd) bf16;
+ * cos,sin: (tokens, hd/2) fp32. (hd/2) % 8 == 0. */
+int vgpt_rope_qk_inplace(void* qkv, const float* cos_t, const float* sin_t, int64_t tokens,
+                         int n_q_heads, int n_kv_heads, int head_dim, void* stream);
+
+/* nn.Linear without bias on MFMA: C[M,N] = A[M,K] W[N,K]^T (+ epilogue), bf16 in,
+ * fp32 accumulate, bf16 out. Replaces qkv_proj / o_proj / down_proj
+ * (LVM/transform/sdpa_transform.py:39,89; Phi3MLP.down_proj). K % 64 == 0, N % 4 == 0.
+ * lda/ldw/ldc/ldr are row strides in elements. `extra` is R (M,N) for EPI_RESID,
+ * bias (N) for EPI_BIAS, ignored for EPI_NONE. */
+int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void* extra, int64_t M, int64_t N,
+                   int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int epilogue,
+                   void* stream);
+
+/* Phi3MLP first half, fused: out[M,I] = act(A Wg^T) * (A Wu^T) where
+ * W_gate_up (2I, K) = [Wg ; Wu] as stored by Phi3MLP.gate_up_proj.
+ * K % 64 == 0, I % 64 == 0. */
+int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, void* out, int64_t M, int64_t I,
+                           int64_t K, int64_t lda, int64_t ldw, int64_t ldo, int act, void* stream);
+
+/* ---- block-masked attention ---------------------------------------------- */
+
+/* (B,L,L) bool/uint8 mask (1 = visible; LVM/processor.py:682-731) -> bit-packed rows
+ * bits[b][q][w] (w < W = ceil(L/32)); bit j of word w = mask[b][q][32w+j]; bits past L are 0. */
+int vgpt_mask_pack_bool(const uint8_t* mask, uint32_t* bits, int64_t B, int64_t L, void* stream);
+/* Same from the additive float mask the reference hands to SDPA
+ * (OmniGen/transformer.py:139-145: 0 visible, finfo.min masked). is_f32: 0 bf16, 1 fp32.
+ * mask is (B,1,L,L) contiguous. */
+int vgpt_mask_pack_additive(const void* mask, int is_f32, uint32_t* bits, int64_t B, int64_t L,
+                            void* stream);
+/* Tile summary: one byte per (b, 128-row q block, 64-key tile): 2 bits per 32-row
+ * q sub-block (0 = all masked, 1 = all visible, 2 = mixed).
+ * summary: (B, ceil(L/128), ceil(L/64)) uint8. */
+int vgpt_mask_tile_summary(const uint32_t* bits, uint8_t* summary, int64_t B, int64_t L,
+                           void* stream);
+/* Number of query rows with no visible key (the reference would average over all keys
+ * there; this library does not support it). count: 1 x int32, zeroed by the callee. */
+int vgpt_mask_count_empty_rows(const uint32_t* bits, int32_t* count, int64_t B, int64_t L,
+                               void* stream);
+
+/* softmax(q k^T * scale + mask) v with the mask given as bits + tile summary.
+ * Replaces module.local_attn (F.scaled_dot_product_attention,
+ * LVM/transform/sdpa_transform.py:78-86,152). q,k,v,o are bf16 with element strides
+ * (batch, head, seq); the head_dim axis is contiguous. head_dim == 96 or 128... see
+ * vgpt_attn_supported(). n_kv_heads must divide n_heads (repeat_kv).
+ * variant: 0 = default (hardware transposed LDS reads), 1 = reference-slow path. */
+int vgpt_attn_blockmask_fwd(const void* q, const void* k, const void* v, void* o,
+                            const uint32_t* bits, const uint8_t* summary, int64_t B, int64_t L,
+                            int n_heads, int n_kv_heads, int head_dim, int64_t q_sb, int64_t q_sh,
+                            int64_t q_ss, int64_t k_sb, int64_t k_sh, int64_t k_ss, int64_t v_sb,
+                            int64_t v_sh, int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
+                            float scale, int variant, void* stream);
+int vgpt_attn_supported(int head_dim);
+
+/* ---- model glue ---------------------------------------------------------- */
+
+/* embed_tokens gather (LVM/model.py:430-432): out[r] = table[ids[r]]. H % 8 == 0. */
+int vgpt_embed_gather(const int64_t* ids, const void* table, void* out, int64_t rows, int64_t H,
+                      int64_t vocab, void* stream);
+
+/* PatchEmbedMR + cropped 2-D sincos position embedding, scattered into the token
+ * sequence (LVM/model.py:149-154,268-289,299-306,436-453).
+ * x: (n_frames, C, h, w) bf16; Wp: (H, C*p*p) bf16; bias: (H) bf16;
+ * pos_embed: (pos_max*pos_max, H) bf16; dst_row[f]: first row of frame f in `seq`
+ * ((rows,H) bf16). patch p = 2, C*p*p == 16. */
+int vgpt_patch_embed_fwd(const void* x, const void* Wp, const void* bias, const void* pos_embed,
+                         const int32_t* dst_row, void* seq, int n_frames, int C, int h, int w,
+                         int64_t H, int pos_max, void* stream);
+
+/* TimestepEmbedder.timestep_embedding (LVM/model.py:39-58): out[n] = [cos(t f) | sin(t f)]
+ * (dim = 2*half) rounded to bf16. freqs: (half) fp32 computed by the host exactly as
+ * the reference does. t: (n) fp32. */
+int vgpt_timestep_sinusoid(const float* t, const float* freqs, void* out, int n, int half,
+                           void* stream);
+
+/* Small-M Linear: out[m][n] = post(sum_k pre(x[m][k]) W[n][k] + bias[n]), M <= 32.
+ * pre/post: VGPT_ACT_NONE or VGPT_ACT_SILU. Replaces the TimestepEmbedder MLP
+ * (LVM/model.py:32-36) and FinalLayer.adaLN_modulation (LVM/model.py:74-77).
+ * out rows may be scattered: row m is written at out + out_row[m]*ldo when out_row != NULL
+ * (time tokens scattered into the sequence, LVM/model.py:442-446). K % 8 == 0. */
+int vgpt_linear_small(const void* x, const void* W, const void* bias, void* out,
+                      const int32_t* out_row, int M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
+                      int pre_act, int post_act, void* stream);
+
+/* FinalLayer (LayerNorm no-affine eps + modulate + Linear(H -> p*p*C)) + unpatchify
+ * (LVM/model.py:79-83,255-265,478-486). hidden: (rows,H) bf16; src_row[f] first row of
+ * frame f; mod: (n_frames, 2H) bf16 = [shift | scale]; Wf: (p*p*C, H) bf16; bf: (p*p*C);
+ * out: (n_frames, C, h, w) bf16. p = 2, p*p*C == 16. */
+int vgpt_final_layer_fwd(const void* hidden, const int32_t* src_row, const void* mod,
+                         const void* Wf, const void* bf, void* out, int n_frames, int C, int h,
+                         int w, int64_t H, float eps, void* stream);
+
+/* ---- sampler (LVM/scheduler.py:161-208) ---------------------------------- */
+
+/* timesteps[i] = sigma[*step] for i < n (scheduler.py:169). */
+int vgpt_sampler_set_timesteps(const float* sigma, const int32_t* step, float* timesteps, int n,
+                               void* stream);
+/* One Euler step with optional x1->v conversion and image CFG (scheduler.py:178-204).
+ * z: (n_frames, elems) fp32 state, z_model: same shape bf16 copy handed to the model,
+ * pred: (n_frames, elems) bf16. With use_cfg the first half of the frames is the
+ * conditional branch, the second half the unconditional one. */
+int vgpt_euler_cfg_update(float* z, void* z_model, const void* pred, const float* sigma,
+                          const int32_t* step, int n_frames, int64_t elems, int pred_type,
+                          int use_cfg, float cfg_scale, void* stream);
+/* *step += 1 */
+int vgpt_sampler_advance(int32_t* step, void* stream);
+/* z_model = bf16(z) */
+int vgpt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+/* ---- hipGraph helpers (sampler loop under graph capture) ----------------- */
+int vgpt_graph_begin_capture(void* stream);
+int vgpt_graph_end_capture(void* stream, void** graph_exec_out);
+int vgpt_graph_launch(void* graph_exec, void* stream);
+int vgpt_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGPT_H */

@@ -1,0 +1,396 @@
+"""GPU parity of every HIP entry point against the CPU oracle (oracle/restate.py), called through
+the C ABI (video-gpt_amd/ops.py -> libvgpt_hip.so).
+
+Tolerances (bf16 kernels vs the fp32 oracle evaluated on the SAME bf16-rounded inputs):
+  rel-L2 <= 4e-3 for single ops whose only error is the final bf16 rounding (bf16 eps = 7.8e-3,
+  RMS rounding error ~ eps/ (2*sqrt(3)) = 2.3e-3), <= 1e-2 where an intermediate is rounded to
+  bf16 as the reference's bf16 path also does (attention probabilities, RoPE tables).
+Integer / bit work (mask packing, tile summary, gathers) is compared bit-exactly.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restate as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def bf(x):  # round to bf16, keep fp32 container (oracle input)
+    return x.to(BF).float()
+
+
+def g(seed):
+    return torch.Generator("cpu").manual_seed(seed)
+
+
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("rows,H", [(5, 192), (37, 3072), (3, 4096), (2, 8192), (0, 64), (130, 1032)])
+def test_rmsnorm(ops, rows, H):
+    x = bf(torch.randn(rows, H, generator=g(1)) * 3)
+    w = bf(1 + 0.1 * torch.randn(H, generator=g(2)))
+    y = ops.rmsnorm(x.to(DEV, BF), w.to(DEV, BF), 1e-5)
+    ref = R.rmsnorm(x, w, 1e-5)
+    assert y.shape == (rows, H)
+    if rows:
+        assert rel_l2(y, ref) < 4e-3
+
+
+def test_rmsnorm_rejects_odd_width(ops):
+    with pytest.raises(Exception):
+        ops.rmsnorm(torch.zeros(2, 100, device=DEV, dtype=BF), torch.ones(100, device=DEV, dtype=BF), 1e-5)
+
+
+@pytest.mark.parametrize("hd,nh,nkv", [(96, 2, 2), (96, 32, 32), (128, 4, 2), (64, 3, 1)])
+def test_rope(ops, hd, nh, nkv):
+    B, L = 2, 77
+    pos = torch.randint(0, 3100, (B, L), generator=g(3))
+    qkv = bf(torch.randn(B, L, (nh + 2 * nkv) * hd, generator=g(4)))
+    inv = ops.rope_inv_freq(hd, 10000.0, DEV)
+    cos, sin = ops.rope_table(pos.to(DEV), inv, round_bf16=True)
+    rc, rs = R.rope_cos_sin(pos, hd, 10000.0, BF)
+    # table: bf16-rounded cos/sin of the fp32 angle (device sinf/cosf vs torch: allow 1 bf16 ulp)
+    assert (cos.cpu() - rc[..., : hd // 2].float().reshape(-1, hd // 2)).abs().max() <= 2 ** -7
+    assert (sin.cpu() - rs[..., : hd // 2].float().reshape(-1, hd // 2)).abs().max() <= 2 ** -7
+    out = ops.rope_qk_inplace(qkv.to(DEV, BF).clone(), cos, sin, nh, nkv, hd).cpu().float()
+    q = qkv[..., : nh * hd].view(B, L, nh, hd).transpose(1, 2)
+    k = qkv[..., nh * hd:(nh + nkv) * hd].view(B, L, nkv, hd).transpose(1, 2)
+    rq, rk = R.apply_rope(q, k, rc.float(), rs.float())
+    assert rel_l2(out[..., : nh * hd], rq.transpose(1, 2).reshape(B, L, -1)) < 6e-3
+    assert rel_l2(out[..., nh * hd:(nh + nkv) * hd], rk.transpose(1, 2).reshape(B, L, -1)) < 6e-3
+    assert torch.equal(out[..., (nh + nkv) * hd:], qkv[..., (nh + nkv) * hd:])  # v untouched
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 576, 192), (128, 128, 64), (1, 4, 64), (258, 3072, 3072),
+                                   (1000, 192, 512), (6192, 3072, 1024)])
+@pytest.mark.parametrize("epi", ["none", "resid", "bias"])
+def test_gemm(ops, M, N, K, epi):
+    if epi != "none" and M > 1000:
+        pytest.skip("covered by the 'none' case")
+    a = bf(torch.randn(M, K, generator=g(5)))
+    w = bf(torch.randn(N, K, generator=g(6)) * 0.05)
+    ref = a.double() @ w.double().t()
+    kw = {}
+    if epi == "resid":
+        r = bf(torch.randn(M, N, generator=g(7)))
+        kw["residual"] = r.to(DEV, BF)
+        ref = ref + r.double()
+    elif epi == "bias":
+        b = bf(torch.randn(N, generator=g(8)))
+        kw["bias"] = b.to(DEV, BF)
+        ref = ref + b.double()
+    y = ops.linear(a.to(DEV, BF), w.to(DEV, BF), **kw)
+    assert y.shape == (M, N)
+    assert rel_l2(y, ref) < 4e-3
+    # element-wise: bf16 rounding of the exact value, 1 ulp slack for the fp32 accumulation order
+    err = (y.cpu().double() - ref).abs()
+    assert float((err / (ref.abs() + 1e-2)).max()) < 2e-2
+
+
+def test_gemm_is_not_transposed(ops):
+    """A = I with an asymmetric W catches swapped row/col maps (cdna guide §3)."""
+    K = 128
+    a = torch.eye(K)
+    w = torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 251 - 125.0  # exact in bf16
+    y = ops.linear(a.to(DEV, BF), w.to(DEV, BF))
+    assert torch.equal(y.cpu().float(), w.t().contiguous())
+
+
+def test_gemm_rejects_bad_k(ops):
+    with pytest.raises(Exception):
+        ops.linear(torch.zeros(4, 100, device=DEV, dtype=BF), torch.zeros(8, 100, device=DEV, dtype=BF))
+
+
+@pytest.mark.parametrize("M,I,K,act", [(300, 512, 192, "silu"), (70, 64, 64, "gelu_pytorch_tanh"),
+                                       (129, 8192, 3072, "silu"), (33, 144, 128, "gelu")])
+def test_gated_mlp(ops, M, I, K, act):
+    x = bf(torch.randn(M, K, generator=g(9)))
+    w = bf(torch.randn(2 * I, K, generator=g(10)) * 0.05)
+    gate, up = (x.double() @ w.double().t()).chunk(2, dim=-1)
+    ref = up * R._ACT[act](gate)
+    y = ops.gated_mlp_act(x.to(DEV, BF), w.to(DEV, BF), ops.act_code(act))
+    assert rel_l2(y, ref) < 4e-3
+
+
+# ---------------------------------------------------------------------------------------------
+
+def _np_bits(mask: np.ndarray) -> np.ndarray:
+    B, L, _ = mask.shape
+    W = (L + 31) // 32
+    padded = np.zeros((B, L, W * 32), dtype=np.uint8)
+    padded[:, :, :L] = mask
+    return np.packbits(padded.reshape(B, L, W, 32), axis=-1, bitorder="little").view("<u4").reshape(B, L, W)
+
+
+def _np_summary(mask: np.ndarray) -> np.ndarray:
+    B, L, _ = mask.shape
+    nqb, nkt = (L + 127) // 128, (L + 63) // 64
+    out = np.zeros((B, nqb, nkt), dtype=np.uint8)
+    for b in range(B):
+        for qb in range(nqb):
+            for kt in range(nkt):
+                byte = 0
+                for sub in range(4):
+                    q0 = qb * 128 + sub * 32
+                    rows = mask[b, q0:min(q0 + 32, L), kt * 64:min(kt * 64 + 64, L)]
+                    if rows.shape[0] == 0 or not rows.any():
+                        code = 0
+                    elif rows.all() and kt * 64 + 64 <= L:
+                        code = 1
+                    else:
+                        code = 2
+                    byte |= code << (2 * sub)
+                out[b, qb, kt] = byte
+    return out
+
+
+def _random_block_mask(B, L, seed):
+    rng = np.random.default_rng(seed)
+    m = np.zeros((B, L, L), dtype=np.uint8)
+    for b in range(B):
+        cuts = np.sort(rng.choice(np.arange(1, L), size=min(5, L - 1), replace=False))
+        bounds = [0, *cuts.tolist(), L]
+        for i in range(len(bounds) - 1):
+            for j in range(i + 1):
+                if rng.random() < 0.7 or i == j:
+                    m[b, bounds[i]:bounds[i + 1], bounds[j]:bounds[j + 1]] = 1
+        m[b] |= np.eye(L, dtype=np.uint8)  # no empty rows
+        flip = rng.random((L, L)) < 0.02
+        m[b] &= ~(flip & ~np.eye(L, dtype=bool))
+    return m
+
+
+@pytest.mark.parametrize("B,L", [(2, 72), (1, 300), (2, 129), (1, 64), (1, 33)])
+def test_mask_pack_and_summary(ops, B, L):
+    m = _random_block_mask(B, L, 11)
+    pm = ops.pack_mask(torch.from_numpy(m).to(DEV).bool())
+    assert np.array_equal(pm.bits.cpu().numpy().view(np.uint32), _np_bits(m))
+    assert np.array_equal(pm.summary.cpu().numpy(), _np_summary(m))
+    assert pm.count_empty_rows() == 0
+    # additive form of the same mask (OmniGen/transformer.py:139-145)
+    for dt in (BF, torch.float32):
+        add = R.additive_mask(torch.from_numpy(m).bool(), dt)
+        pm2 = ops.pack_mask(add.to(DEV))
+        assert torch.equal(pm2.bits, pm.bits) and torch.equal(pm2.summary, pm.summary)
+
+
+def test_mask_collator_layout(ops):
+    batch = R.collate_inference(4, 8, 256)
+    m = batch["attention_mask"].numpy().astype(np.uint8)
+    pm = ops.pack_mask(batch["attention_mask"].to(DEV))
+    assert np.array_equal(pm.bits.cpu().numpy().view(np.uint32), _np_bits(m))
+    assert np.array_equal(pm.summary.cpu().numpy(), _np_summary(m))
+
+
+def test_mask_empty_rows_counted(ops):
+    m = np.ones((1, 40, 40), dtype=np.uint8)
+    m[0, 7] = 0
+    m[0, 39] = 0
+    assert ops.pack_mask(torch.from_numpy(m).to(DEV)).count_empty_rows() == 2
+
+
+def _ref_attention(q, k, v, mask, scale):
+    """(B,h,L,d) fp64 reference with the reference's additive-min mask semantics."""
+    s = torch.matmul(q.double(), k.double().transpose(2, 3)) * scale
+    s = s.masked_fill(~mask[:, None].bool(), float("-inf"))
+    return torch.matmul(torch.softmax(s, dim=-1), v.double())
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("B,L,nh,nkv,hd", [(2, 72, 2, 2, 96), (1, 300, 3, 3, 96), (2, 129, 4, 2, 128),
+                                           (1, 200, 2, 1, 64), (1, 1, 1, 1, 96)])
+def test_attention_fused_qkv(ops, variant, B, L, nh, nkv, hd):
+    m = _random_block_mask(B, L, 12)
+    qkv = bf(torch.randn(B, L, (nh + 2 * nkv) * hd, generator=g(13)))
+    pm = ops.pack_mask(torch.from_numpy(m).to(DEV))
+    out = ops.attention_qkv(qkv.to(DEV, BF), pm, nh, nkv, hd, variant=variant)
+    q = qkv[..., : nh * hd].view(B, L, nh, hd).transpose(1, 2)
+    k = qkv[..., nh * hd:(nh + nkv) * hd].view(B, L, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
+    v = qkv[..., (nh + nkv) * hd:].view(B, L, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
+    ref = _ref_attention(q, k, v, torch.from_numpy(m), 1 / math.sqrt(hd)).transpose(1, 2).reshape(B, L, -1)
+    assert rel_l2(out, ref) < 1e-2
+    assert float((out.cpu().double() - ref).abs().max()) < 0.05
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention_forced_rescale(ops, variant):
+    """Spike one key late in the sequence so the running max jumps at a later tile (online-softmax rescale)."""
+    B, L, nh, hd = 1, 256, 1, 96
+    q = bf(torch.randn(B, nh, L, hd, generator=g(14)))
+    k = bf(torch.randn(B, nh, L, hd, generator=g(15)))
+    v = bf(torch.randn(B, nh, L, hd, generator=g(16)))
+    k[0, 0, 200] = q[0, 0, 5] * 4.0  # huge score for (q=5, key=200), third tile
+    mask = torch.ones(B, L, L, dtype=torch.bool)
+    out = ops.sdpa(q.to(DEV, BF), k.to(DEV, BF), v.to(DEV, BF), attn_mask=mask.to(DEV), variant=variant)
+    ref = _ref_attention(q, k, v, mask, 1 / math.sqrt(hd))
+    assert rel_l2(out, ref) < 1e-2
+    assert float((out.cpu().double()[0, 0, 5] - ref[0, 0, 5]).abs().max()) < 0.05
+
+
+def test_attention_sdpa_seam_real_layout(ops):
+    """The local_attn slot on (B,h,S,d) tensors with the 256^2 / C=4 / G=8 collator mask, additive form."""
+    batch = R.collate_inference(4, 8, 256)
+    mask = batch["attention_mask"]
+    B, L = mask.shape[:2]
+    nh, hd = 2, 96
+    q = bf(torch.randn(B, nh, L, hd, generator=g(17)))
+    k = bf(torch.randn(B, nh, L, hd, generator=g(18)))
+    v = bf(torch.randn(B, nh, L, hd, generator=g(19)))
+    add = R.additive_mask(mask, BF)
+    out = ops.sdpa(q.to(DEV, BF), k.to(DEV, BF), v.to(DEV, BF), attn_mask=add.to(DEV), dropout_p=0.0,
+                   is_causal=False)
+    ref = _ref_attention(q, k, v, mask, 1 / math.sqrt(hd))
+    assert rel_l2(out, ref) < 1e-2
+    out1 = ops.sdpa(q.to(DEV, BF), k.to(DEV, BF), v.to(DEV, BF), attn_mask=mask.to(DEV), variant=1)
+    assert rel_l2(out1, ref) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------
+
+def test_embed_gather(ops):
+    table = bf(torch.randn(64, 192, generator=g(20)))
+    ids = torch.randint(0, 64, (2, 37), generator=g(21))
+    out = ops.embed_gather(ids.to(DEV), table.to(DEV, BF))
+    assert torch.equal(out.cpu().float(), table[ids])
+
+
+@pytest.mark.parametrize("cfg,hw", [(R.TINY, (8, 8)), (R.TINY, (4, 12)), (R.Phi3Cfg(), (32, 32))])
+def test_patch_embed(ops, cfg, hw):
+    h, w = hw
+    H = cfg.hidden_size
+    nf = 3
+    x = bf(torch.randn(nf, 4, h, w, generator=g(22)))
+    wt = bf(torch.randn(H, 4, 2, 2, generator=g(23)) * 0.2)
+    b = bf(torch.randn(H, generator=g(24)) * 0.1)
+    pos = bf(R.make_pos_embed(cfg))
+    ntok = (h // 2) * (w // 2)
+    rows = ntok * nf + 7
+    seq = torch.full((rows, H), 9.0, dtype=BF, device=DEV)
+    dst = torch.tensor([3, 3 + 2 * ntok, 3 + ntok], dtype=torch.int32, device=DEV)
+    ops.patch_embed(x.to(DEV, BF), wt.to(DEV, BF), b.to(DEV, BF), pos[0].to(DEV, BF), dst, seq, cfg.pos_embed_max_size)
+    seq = seq.cpu().float()
+    for f, r0 in enumerate(dst.tolist()):
+        ref = R.patch_embed(x[f:f + 1], wt, b, 2) + R.cropped_pos_embed(pos, cfg, h, w)
+        assert rel_l2(seq[r0:r0 + ntok], ref[0]) < 4e-3
+    assert torch.all(seq[:3] == 9.0) and torch.all(seq[3 + 3 * ntok:] == 9.0)
+
+
+def test_timestep_sinusoid_and_mlp(ops):
+    H = 192
+    t = torch.tensor([0.0, 0.02, 0.37, 0.5, 0.9, 1.0])
+    freqs = ops.timestep_freqs(256, DEV)
+    emb = ops.timestep_sinusoid(t.to(DEV), freqs)
+    ref = R.timestep_embedding(t, 256)
+    assert (emb.cpu().float() - ref).abs().max() <= 2 ** -8
+    p = {"tt.mlp.0.weight": bf(torch.randn(H, 256, generator=g(25)) * 0.05), "tt.mlp.0.bias": bf(torch.randn(H, generator=g(26)) * 0.05),
+         "tt.mlp.2.weight": bf(torch.randn(H, H, generator=g(27)) * 0.05), "tt.mlp.2.bias": bf(torch.randn(H, generator=g(28)) * 0.05)}
+    d = {k: v.to(DEV, BF) for k, v in p.items()}
+    h1 = ops.linear_small(emb, d["tt.mlp.0.weight"], d["tt.mlp.0.bias"], post_act=ops.ACT_SILU)
+    out = ops.linear_small(h1, d["tt.mlp.2.weight"], d["tt.mlp.2.bias"])
+    ref = R.timestep_embedder(p, "tt", t, torch.float32)
+    assert rel_l2(out, ref) < 1e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 10, 64), (16, 3072, 3072), (32, 100, 256), (9, 6144, 192)])
+def test_linear_small(ops, M, N, K):
+    x = bf(torch.randn(M, K, generator=g(29)))
+    w = bf(torch.randn(N, K, generator=g(30)) * 0.05)
+    b = bf(torch.randn(N, generator=g(31)))
+    out = ops.linear_small(x.to(DEV, BF), w.to(DEV, BF), b.to(DEV, BF), pre_act=ops.ACT_SILU)
+    ref = bf(torch.nn.functional.silu(x)).double() @ w.double().t() + b.double()
+    assert rel_l2(out, ref) < 4e-3
+    # scattered rows (time tokens written into the sequence)
+    rows = torch.randperm(M + 5, generator=g(32))[:M].to(torch.int32)
+    seq = torch.zeros(M + 5, N, dtype=BF, device=DEV)
+    ops.linear_small(x.to(DEV, BF), w.to(DEV, BF), b.to(DEV, BF), out=seq, out_row=rows.to(DEV), ldo=N)
+    ref2 = x.double() @ w.double().t() + b.double()
+    assert rel_l2(seq.cpu()[rows.long()], ref2) < 4e-3
+
+
+@pytest.mark.parametrize("cfg,hw", [(R.TINY, (8, 8)), (R.TINY, (4, 12)), (R.Phi3Cfg(), (32, 32))])
+def test_final_layer(ops, cfg, hw):
+    h, w = hw
+    H = cfg.hidden_size
+    nf = 3
+    ntok = (h // 2) * (w // 2)
+    hidden = bf(torch.randn(nf * ntok + 5, H, generator=g(33)))
+    c = bf(torch.randn(nf, H, generator=g(34)))
+    p = {"final_layer.adaLN_modulation.1.weight": bf(torch.randn(2 * H, H, generator=g(35)) * 0.05),
+         "final_layer.adaLN_modulation.1.bias": bf(torch.randn(2 * H, generator=g(36)) * 0.05),
+         "final_layer.linear.weight": bf(torch.randn(16, H, generator=g(37)) * 0.05),
+         "final_layer.linear.bias": bf(torch.randn(16, generator=g(38)) * 0.05)}
+    d = {k: v.to(DEV, BF) for k, v in p.items()}
+    mod = ops.linear_small(c.to(DEV, BF), d["final_layer.adaLN_modulation.1.weight"],
+                           d["final_layer.adaLN_modulation.1.bias"], pre_act=ops.ACT_SILU)
+    src = torch.tensor([2, 2 + 2 * ntok, 2 + ntok], dtype=torch.int32, device=DEV)
+    out = torch.empty(nf, 4, h, w, dtype=BF, device=DEV)
+    ops.final_layer(hidden.to(DEV, BF), src, mod, d["final_layer.linear.weight"], d["final_layer.linear.bias"], out)
+    for f, r0 in enumerate(src.tolist()):
+        y = R.final_layer(p, hidden[None, r0:r0 + ntok], c[f:f + 1])
+        ref = R.unpatchify(y, h, w, 2, 4)
+        assert rel_l2(out[f:f + 1], ref) < 1e-2
+
+
+@pytest.mark.parametrize("pred_type", ["x1", "v"])
+@pytest.mark.parametrize("use_cfg", [True, False])
+def test_euler_cfg_update(ops, pred_type, use_cfg):
+    nf, elems = 4, 4 * 8 * 8
+    sigma = R.scheduler_sigma(5, 1.0)
+    z0 = torch.randn(nf, elems, generator=g(39))
+    if use_cfg:
+        z0[nf // 2:] = z0[: nf // 2]
+    preds = [bf(torch.randn(nf, elems, generator=g(40 + i))) for i in range(5)]
+    z = z0.clone().to(DEV)
+    zm = torch.empty(nf, elems, dtype=BF, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ts = torch.empty(nf, dtype=torch.float32, device=DEV)
+    sig_d = sigma.to(DEV)
+    for i in range(5):
+        ops.sampler_set_timesteps(sig_d, step, ts)
+        assert torch.allclose(ts.cpu(), torch.full((nf,), float(sigma[i])))
+        ops.euler_cfg_update(z, zm, preds[i].to(DEV, BF), sig_d, step, ops.PRED_X1 if pred_type == "x1" else ops.PRED_V,
+                             use_cfg, 1.6)
+        ops.sampler_advance(step)
+    it = iter(preds)
+
+    def func(zl, t):
+        pr = next(it)
+        out = [pr[j] for j in range(nf)]
+        if use_cfg and pred_type == "v":  # CFG of the 'v' path lives in forward_with_cfg (LVM/model.py:555-562)
+            half = nf // 2
+            cond = [out[half + j] + 1.6 * (out[j] - out[half + j]) for j in range(half)]
+            out = cond + cond
+        return out
+
+    ref = R.scheduler_call(sigma, [z0[j] for j in range(nf)], func, use_cfg, 1.6, pred_type)
+    assert rel_l2(z, torch.stack(ref)) < 1e-5
+    assert rel_l2(zm, torch.stack(ref)) < 4e-3
+    assert int(step.item()) == 5
+
+
+def test_hip_graph_replay(ops):
+    """A captured launch sequence replays with updated device-side state (sampler loop under hipGraph)."""
+    x = torch.randn(4, 256, device=DEV).to(BF)
+    w = torch.ones(256, device=DEV, dtype=BF)
+    y = torch.empty_like(x)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        graph = ops.HipGraph().capture(lambda: (ops.rmsnorm(x, w, 1e-5, out=y), ops.sampler_advance(step)))
+        for _ in range(3):
+            graph.replay()
+    s.synchronize()
+    assert int(step.item()) == 3
+    assert rel_l2(y, R.rmsnorm(x.cpu().float(), w.cpu().float(), 1e-5)) < 4e-3

@@ -1,0 +1,97 @@
+"""ctypes binding of libvgpt_hip.so (C ABI declared in include/vgpt.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, an
+exception is raised.  `load()` only dlopens the library (no GPU needed); compute entry points
+need a gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvgpt_hip.so")
+
+# enums mirrored from include/vgpt.h
+ACT_SILU, ACT_GELU, ACT_GELU_TANH, ACT_NONE = 0, 1, 2, 3
+EPI_NONE, EPI_RESID, EPI_BIAS = 0, 1, 2
+PRED_V, PRED_X1 = 0, 1
+
+_P = c_void_p
+_I64 = c_int64
+
+# name -> (restype, argtypes); every symbol declared in include/vgpt.h
+SIGNATURES = {
+    "vgpt_last_error": (c_char_p, []),
+    "vgpt_abi_version": (c_int, []),
+    "vgpt_rmsnorm_fwd": (c_int, [_P, _P, _P, _I64, _I64, c_float, _P]),
+    "vgpt_rope_table": (c_int, [_P, _P, _P, _P, _I64, c_int, c_int, _P]),
+    "vgpt_rope_qk_inplace": (c_int, [_P, _P, _P, _I64, c_int, c_int, c_int, _P]),
+    "vgpt_gemm_bf16": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
+    "vgpt_gated_mlp_act_fwd": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
+    "vgpt_mask_pack_bool": (c_int, [_P, _P, _I64, _I64, _P]),
+    "vgpt_mask_pack_additive": (c_int, [_P, c_int, _P, _I64, _I64, _P]),
+    "vgpt_mask_tile_summary": (c_int, [_P, _P, _I64, _I64, _P]),
+    "vgpt_mask_count_empty_rows": (c_int, [_P, _P, _I64, _I64, _P]),
+    "vgpt_attn_blockmask_fwd": (
+        c_int,
+        [_P, _P, _P, _P, _P, _P, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, c_int, _P],
+    ),
+    "vgpt_attn_supported": (c_int, [c_int]),
+    "vgpt_embed_gather": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P]),
+    "vgpt_patch_embed_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64, c_int, _P]),
+    "vgpt_timestep_sinusoid": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "vgpt_linear_small": (c_int, [_P, _P, _P, _P, _P, c_int, _I64, _I64, _I64, _I64, c_int, c_int, _P]),
+    "vgpt_final_layer_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64, c_float, _P]),
+    "vgpt_sampler_set_timesteps": (c_int, [_P, _P, _P, c_int, _P]),
+    "vgpt_euler_cfg_update": (c_int, [_P, _P, _P, _P, _P, c_int, _I64, c_int, c_int, c_float, _P]),
+    "vgpt_sampler_advance": (c_int, [_P, _P]),
+    "vgpt_cast_f32_to_bf16": (c_int, [_P, _P, _I64, _P]),
+    "vgpt_graph_begin_capture": (c_int, [_P]),
+    "vgpt_graph_end_capture": (c_int, [_P, POINTER(c_void_p)]),
+    "vgpt_graph_launch": (c_int, [_P, _P]),
+    "vgpt_graph_destroy": (c_int, [_P]),
+}
+
+
+class VgptError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libvgpt_hip.so and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VgptError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            continue  # reported by check_exports(); calling it raises AttributeError
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def missing_exports():
+    lib = load()
+    return [n for n in SIGNATURES if not hasattr(lib, n)]
+
+
+def call(name: str, *args) -> None:
+    """Call an int-returning entry point, raising VgptError with vgpt_last_error() on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.vgpt_last_error()
+        raise VgptError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,276 @@
+// bf16 NT GEMM on MFMA for the transformer's Linear layers (qkv_proj, o_proj, gate_up_proj,
+// down_proj): C[M,N] = A[M,K] * W[N,K]^T, fp32 accumulate.
+//
+// Reference arithmetic: nn.Linear calls at LVM/transform/sdpa_transform.py:39,89 and
+// Phi3MLP.forward (transformers==4.47.1): down_proj(up * act(gate)), [gate|up] = gate_up_proj(x).
+//
+// Structure (gfx950):
+//   - 128(m) x 128(n) x 64(k) tile, 256 threads = 4 waves in a 2(n) x 2(m) grid, each wave
+//     64 x 64 = 4 x 4 MFMA 16x16x32 sub-tiles (64 accumulator registers).
+//   - A and W tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip),
+//     double-buffered; one barrier per k-tile, the next tile's DMA is issued before the
+//     current tile's MFMAs.
+//   - LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with (row & 7)
+//     on the SOURCE address (the LDS-DMA destination is lane-linear), and the same XOR is
+//     applied on the ds_read_b128 side: conflict-free for the 16-lane b128 groups.
+//   - operands are swapped (W is the MFMA "A" operand) so each lane ends up with 4
+//     consecutive n of one m: 8-byte bf16 stores.
+//   - 1-D grid with an XCD-aware, grouped tile order so blocks that share an XCD's L2 work
+//     on neighbouring tiles.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
+constexpr int LDS_BYTES = 4 * TILE_BYTES; // {A,W} x 2 buffers = 64 KiB
+
+enum { MODE_PLAIN = 0, MODE_GATED = 1 };
+
+struct GemmArgs {
+    const bf16* A;
+    const bf16* W;
+    bf16* C;
+    const bf16* extra;
+    int M, N, K;
+    int64_t lda, ldw, ldc, ldr;
+    int epi;   // VGPT_EPI_*
+    int act;   // gated mode
+    int I;     // gated mode: intermediate size
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0,
+                                     0);
+}
+
+// weight row feeding n-slot s of a tile (gated mode interleaves gate/up every 16 slots)
+template <int MODE>
+__device__ __forceinline__ int w_row_of_slot(int n0, int s, int I) {
+    if (MODE == MODE_GATED) {
+        // n0 = first output column of this tile (tile covers 64 output columns)
+        return ((s >> 4) & 1 ? I : 0) + n0 + (s >> 5) * 16 + (s & 15);
+    }
+    return n0 + s;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- tile order: XCD-aware remap (bijective), then grouped along m ----
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GROUP = 8;
+    const int in_group = GROUP * g.tiles_n;
+    const int group_id = bid / in_group;
+    const int first_m = group_id * GROUP;
+    const int gsz = min(g.tiles_m - first_m, GROUP);
+    const int tm = first_m + (bid % in_group) % gsz;
+    const int tn = (bid % in_group) / gsz;
+    const int m0 = tm * BM;
+    const int n0 = tn * (MODE == MODE_GATED ? 64 : BN);
+
+    // ---- staging addresses: wave w stages slabs [4w, 4w+4) of both tiles (8 rows each) ----
+    const int srow = lane >> 3;            // row inside the 8-row slab
+    const int schunk = (lane & 7) ^ srow;  // source 16-B chunk (XOR swizzle)
+    const bf16* a_src[4];
+    const bf16* w_src[4];
+    const int n_rows_w = (MODE == MODE_GATED) ? 2 * g.I : g.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + srow;
+        const int am = min(m0 + r, g.M - 1);
+        a_src[i] = g.A + (int64_t)am * g.lda + schunk * 8;
+        const int wr = min(w_row_of_slot<MODE>(n0, r, g.I), n_rows_w - 1);
+        w_src[i] = g.W + (int64_t)wr * g.ldw + schunk * 8;
+    }
+    char* sA = smem;                  // [2][TILE_BYTES]
+    char* sW = smem + 2 * TILE_BYTES; // [2][TILE_BYTES]
+
+    auto stage = [&](int buf, int kt) {
+        const int koff = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int slab_off = (wave * 4 + i) * 1024;
+            glds16(a_src[i] + koff, sA + buf * TILE_BYTES + slab_off);
+            glds16(w_src[i] + koff, sW + buf * TILE_BYTES + slab_off);
+        }
+    };
+
+    // ---- fragment read addresses ----
+    const int wn = wave & 1, wm = wave >> 1;
+    const int frow = lane & 15;  // row inside a 16-row sub-tile
+    const int fk = lane >> 4;    // 16-B chunk inside a 32-wide k-step
+    // byte offset of (row, chunk g) = row*128 + ((g ^ (row&7)) * 16); row&7 == frow&7 here
+    int w_off[4], a_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        w_off[i] = (wn * 64 + i * 16 + frow) * 128;
+        a_off[i] = (wm * 64 + i * 16 + frow) * 128;
+    }
+    const int sw = frow & 7;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile kt landed for every wave; buffer buf^1 is free
+        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+        const char* bA = sA + buf * TILE_BYTES;
+        const char* bW = sW + buf * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fk) ^ sw) * 16;
+            bf16x8 wf[4], af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wf[i] = *reinterpret_cast<const bf16x8*>(bW + w_off[i] + coff);
+                af[i] = *reinterpret_cast<const bf16x8*>(bA + a_off[i] + coff);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0,
+                                                                        0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds m = lane&15, n = (lane>>4)*4 + reg of each 16x16 sub-tile ----
+    const int em = lane & 15, en = (lane >> 4) * 4;
+    if (MODE == MODE_PLAIN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + em;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + wn * 64 + i * 16 + en;
+                if (n >= g.N) continue;
+                f32x4 v = acc[i][j];
+                if (g.epi == VGPT_EPI_RESID) {
+                    bf16x4 r = *reinterpret_cast<const bf16x4*>(g.extra + (int64_t)m * g.ldr + n);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] += bf2f(r[t]);
+                } else if (g.epi == VGPT_EPI_BIAS) {
+                    bf16x4 r = *reinterpret_cast<const bf16x4*>(g.extra + n);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] += bf2f(r[t]);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = f2bf(v[t]);
+                *reinterpret_cast<bf16x4*>(g.C + (int64_t)m * g.ldc + n) = o;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + em;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int n = n0 + (wn * 2 + p) * 16 + en;  // output column
+                if (n >= g.I) continue;
+                const f32x4 gate = acc[2 * p][j], up = acc[2 * p + 1][j];
+                bf16x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = f2bf(act_apply(gate[t], g.act) * up[t]);
+                *reinterpret_cast<bf16x4*>(g.C + (int64_t)m * g.ldc + n) = o;
+            }
+        }
+    }
+}
+
+template <int MODE>
+int launch(const GemmArgs& g, hipStream_t s, const char* name) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) {
+            vgpt_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+            return VGPT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_kernel<MODE>, dim3(g.tiles_m * g.tiles_n), dim3(256), LDS_BYTES, s,
+                       g);
+    VGPT_CHECK_LAUNCH(name);
+    return VGPT_OK;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+VGPT_EXPORT int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void* extra, int64_t M,
+                               int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
+                               int64_t ldr, int epilogue, void* stream) {
+    VGPT_REQUIRE(A && W && C, VGPT_ERR_INVALID, "vgpt_gemm_bf16: null pointer");
+    VGPT_REQUIRE(M >= 0 && N > 0 && K > 0, VGPT_ERR_INVALID, "vgpt_gemm_bf16: bad shape");
+    VGPT_REQUIRE(epilogue == VGPT_EPI_NONE || epilogue == VGPT_EPI_RESID || epilogue == VGPT_EPI_BIAS,
+                 VGPT_ERR_INVALID, "vgpt_gemm_bf16: unknown epilogue %d", epilogue);
+    VGPT_REQUIRE(epilogue == VGPT_EPI_NONE || extra, VGPT_ERR_INVALID,
+                 "vgpt_gemm_bf16: epilogue needs `extra`");
+    VGPT_REQUIRE(K % BK == 0, VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16: K=%ld not a multiple of 64",
+                 (long)K);
+    VGPT_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && (epilogue != VGPT_EPI_RESID || ldr % 4 == 0),
+                 VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16: N/ldc/ldr must be multiples of 4");
+    VGPT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && aligned16(A) && aligned16(W) &&
+                     ((uintptr_t)C & 7) == 0,
+                 VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16: operands must be 16-byte aligned rows");
+    VGPT_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16: dimension too large");
+    if (M == 0) return VGPT_OK;
+    GemmArgs g;
+    g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = (bf16*)C; g.extra = (const bf16*)extra;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+    g.epi = epilogue; g.act = VGPT_ACT_NONE; g.I = 0;
+    g.tiles_m = (int)cdiv(M, BM); g.tiles_n = (int)cdiv(N, BN);
+    return launch<MODE_PLAIN>(g, (hipStream_t)stream, "vgpt_gemm_bf16");
+}
+
+VGPT_EXPORT int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, void* out, int64_t M,
+                                       int64_t I, int64_t K, int64_t lda, int64_t ldw, int64_t ldo,
+                                       int act, void* stream) {
+    VGPT_REQUIRE(A && W_gate_up && out, VGPT_ERR_INVALID, "vgpt_gated_mlp_act_fwd: null pointer");
+    VGPT_REQUIRE(M >= 0 && I > 0 && K > 0, VGPT_ERR_INVALID, "vgpt_gated_mlp_act_fwd: bad shape");
+    VGPT_REQUIRE(act >= VGPT_ACT_SILU && act <= VGPT_ACT_GELU_TANH, VGPT_ERR_INVALID,
+                 "vgpt_gated_mlp_act_fwd: unknown activation %d", act);
+    VGPT_REQUIRE(K % BK == 0, VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gated_mlp_act_fwd: K=%ld not a multiple of 64", (long)K);
+    VGPT_REQUIRE(I % 16 == 0 && ldo % 4 == 0, VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gated_mlp_act_fwd: I must be a multiple of 16, ldo of 4");
+    VGPT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && aligned16(A) && aligned16(W_gate_up) &&
+                     ((uintptr_t)out & 7) == 0,
+                 VGPT_ERR_UNSUPPORTED, "vgpt_gated_mlp_act_fwd: operands must be 16-byte aligned rows");
+    VGPT_REQUIRE(M < (1 << 30) && I < (1 << 29) && K < (1 << 30), VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gated_mlp_act_fwd: dimension too large");
+    if (M == 0) return VGPT_OK;
+    GemmArgs g;
+    g.A = (const bf16*)A; g.W = (const bf16*)W_gate_up; g.C = (bf16*)out; g.extra = nullptr;
+    g.M = (int)M; g.N = (int)I; g.K = (int)K;
+    g.lda = lda; g.ldw = ldw; g.ldc = ldo; g.ldr = 0;
+    g.epi = VGPT_EPI_NONE; g.act = act; g.I = (int)I;
+    g.tiles_m = (int)cdiv(M, BM); g.tiles_n = (int)cdiv(I, 64);
+    return launch<MODE_GATED>(g, (hipStream_t)stream, "vgpt_gated_mlp_act_fwd");
+}

@@ -1,0 +1,364 @@
+"""Tensor-level wrappers over the C ABI (include/vgpt.h).
+
+PyTorch is used for device memory and streams only: every function takes CUDA(ROCm) tensors,
+checks shapes/dtypes on the host, and launches the HIP kernel on the current torch stream.
+Nothing here falls back to torch ops for the arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_GELU_TANH, ACT_NONE, ACT_SILU, EPI_BIAS, EPI_NONE, EPI_RESID,
+                   PRED_V, PRED_X1, VgptError, call)
+
+BF16 = torch.bfloat16
+
+_ACTS = {"silu": ACT_SILU, "swish": ACT_SILU, "gelu": ACT_GELU, "gelu_new": ACT_GELU_TANH,
+         "gelu_pytorch_tanh": ACT_GELU_TANH, "gelu_tanh": ACT_GELU_TANH}
+
+
+def act_code(name: str) -> int:
+    if name not in _ACTS:
+        raise VgptError(f"unsupported hidden_act {name!r}")
+    return _ACTS[name]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str, contiguous=True):
+    if not t.is_cuda:
+        raise VgptError(f"{name}: expected a GPU tensor (libvgpt_hip has no CPU path)")
+    if t.dtype != dtype:
+        raise VgptError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise VgptError(f"{name}: expected a contiguous tensor")
+
+
+# ---- transformer block ---------------------------------------------------------------------
+
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None):
+    _chk(x, BF16, "rmsnorm.x"); _chk(weight, BF16, "rmsnorm.weight")
+    H = x.shape[-1]
+    if weight.numel() != H:
+        raise VgptError("rmsnorm: weight size mismatch")
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        _chk(out, BF16, "rmsnorm.out")
+    call("vgpt_rmsnorm_fwd", x.data_ptr(), weight.data_ptr(), out.data_ptr(), x.numel() // H, H,
+         float(eps), _stream())
+    return out
+
+
+def rope_inv_freq(head_dim: int, theta: float, device) -> torch.Tensor:
+    """Phi3RotaryEmbedding.inv_freq, computed on the host exactly as transformers does."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    return inv.to(device)
+
+
+def rope_table(position_ids: torch.Tensor, inv_freq: torch.Tensor, round_bf16: bool = True):
+    _chk(position_ids, torch.int64, "rope_table.position_ids"); _chk(inv_freq, torch.float32, "rope_table.inv_freq")
+    tokens, half = position_ids.numel(), inv_freq.numel()
+    cos = torch.empty(tokens, half, dtype=torch.float32, device=position_ids.device)
+    sin = torch.empty_like(cos)
+    call("vgpt_rope_table", position_ids.data_ptr(), inv_freq.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+         tokens, half, int(round_bf16), _stream())
+    return cos, sin
+
+
+def rope_qk_inplace(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_q_heads: int,
+                    n_kv_heads: int, head_dim: int):
+    _chk(qkv, BF16, "rope.qkv"); _chk(cos, torch.float32, "rope.cos"); _chk(sin, torch.float32, "rope.sin")
+    width = (n_q_heads + 2 * n_kv_heads) * head_dim
+    if qkv.shape[-1] != width:
+        raise VgptError("rope: qkv last dim mismatch")
+    tokens = qkv.numel() // width
+    if cos.numel() != tokens * (head_dim // 2) or sin.numel() != cos.numel():
+        raise VgptError("rope: cos/sin table size mismatch")
+    call("vgpt_rope_qk_inplace", qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), tokens, n_q_heads,
+         n_kv_heads, head_dim, _stream())
+    return qkv
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, residual: Optional[torch.Tensor] = None,
+           bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """out = x @ weight.T (+ residual | + bias) on the MFMA GEMM; x (..., K), weight (N, K)."""
+    _chk(x, BF16, "linear.x"); _chk(weight, BF16, "linear.weight")
+    K = x.shape[-1]
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise VgptError("linear: K mismatch")
+    M = x.numel() // K
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=BF16, device=x.device)
+    else:
+        _chk(out, BF16, "linear.out")
+    if residual is not None and bias is not None:
+        raise VgptError("linear: residual and bias together are not supported")
+    epi, extra, ldr = EPI_NONE, None, 0
+    if residual is not None:
+        _chk(residual, BF16, "linear.residual")
+        if residual.numel() != M * N:
+            raise VgptError("linear: residual shape mismatch")
+        epi, extra, ldr = EPI_RESID, residual, N
+    elif bias is not None:
+        _chk(bias, BF16, "linear.bias")
+        epi, extra = EPI_BIAS, bias
+    call("vgpt_gemm_bf16", x.data_ptr(), weight.data_ptr(), out.data_ptr(), _ptr(extra), M, N, K, K, K, N,
+         ldr, epi, _stream())
+    return out
+
+
+def gated_mlp_act(x: torch.Tensor, w_gate_up: torch.Tensor, act: int = ACT_SILU,
+                  out: Optional[torch.Tensor] = None):
+    """act(x Wg^T) * (x Wu^T) with W_gate_up = [Wg ; Wu] (2I, K)."""
+    _chk(x, BF16, "gated_mlp.x"); _chk(w_gate_up, BF16, "gated_mlp.w")
+    K = x.shape[-1]
+    I = w_gate_up.shape[0] // 2
+    if w_gate_up.shape[1] != K or w_gate_up.shape[0] != 2 * I:
+        raise VgptError("gated_mlp: weight shape mismatch")
+    M = x.numel() // K
+    if out is None:
+        out = torch.empty(*x.shape[:-1], I, dtype=BF16, device=x.device)
+    else:
+        _chk(out, BF16, "gated_mlp.out")
+    call("vgpt_gated_mlp_act_fwd", x.data_ptr(), w_gate_up.data_ptr(), out.data_ptr(), M, I, K, K, K, I,
+         act, _stream())
+    return out
+
+
+# ---- attention --------------------------------------------------------------------------------
+
+class PackedMask:
+    """Bit-packed (B,L,L) visibility mask + tile summary consumed by the attention kernel."""
+
+    def __init__(self, bits: torch.Tensor, summary: torch.Tensor, B: int, L: int):
+        self.bits, self.summary, self.B, self.L = bits, summary, B, L
+
+    def count_empty_rows(self) -> int:
+        cnt = torch.empty(1, dtype=torch.int32, device=self.bits.device)
+        call("vgpt_mask_count_empty_rows", self.bits.data_ptr(), cnt.data_ptr(), self.B, self.L, _stream())
+        return int(cnt.item())
+
+
+def _alloc_mask(B: int, L: int, device):
+    W = (L + 31) // 32
+    bits = torch.empty(B, L, W, dtype=torch.int32, device=device)
+    summary = torch.empty(B, (L + 127) // 128, (L + 63) // 64, dtype=torch.uint8, device=device)
+    return bits, summary
+
+
+def pack_mask(mask: torch.Tensor) -> PackedMask:
+    """mask: (B,L,L) bool/uint8 (True = visible), or the additive (B,1,L,L) bf16/fp32 mask."""
+    if not mask.is_cuda:
+        raise VgptError("pack_mask: expected a GPU tensor")
+    if mask.dim() == 4:
+        if mask.shape[1] != 1:
+            raise VgptError("pack_mask: additive mask must be (B,1,L,L)")
+        B, _, L, L2 = mask.shape
+        if mask.dtype not in (torch.float32, BF16):
+            raise VgptError("pack_mask: additive mask must be bf16 or fp32")
+        mask = mask.contiguous()
+        bits, summary = _alloc_mask(B, L, mask.device)
+        call("vgpt_mask_pack_additive", mask.data_ptr(), int(mask.dtype == torch.float32), bits.data_ptr(),
+             B, L, _stream())
+    else:
+        if mask.dim() != 3:
+            raise VgptError("attention_mask parameter was unavailable or invalid")
+        B, L, L2 = mask.shape
+        if mask.dtype == torch.bool:
+            m8 = mask.contiguous().view(torch.uint8)
+        elif mask.dtype == torch.uint8:
+            m8 = mask.contiguous()
+        else:
+            m8 = (mask != 0).contiguous().view(torch.uint8)
+        bits, summary = _alloc_mask(B, L, mask.device)
+        call("vgpt_mask_pack_bool", m8.data_ptr(), bits.data_ptr(), B, L, _stream())
+    if L != L2:
+        raise VgptError("pack_mask: mask must be square")
+    call("vgpt_mask_tile_summary", bits.data_ptr(), summary.data_ptr(), B, L, _stream())
+    return PackedMask(bits, summary, B, L)
+
+
+def attention_qkv(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: int, head_dim: int,
+                  scale: Optional[float] = None, out: Optional[torch.Tensor] = None, variant: int = 0):
+    """Attention on the fused (B, L, (n_q+2n_kv)*hd) projection buffer (RoPE already applied)."""
+    _chk(qkv, BF16, "attention.qkv")
+    B, L, width = qkv.shape
+    if width != (n_heads + 2 * n_kv_heads) * head_dim or B != pm.B or L != pm.L:
+        raise VgptError("attention: qkv / mask shape mismatch")
+    if out is None:
+        out = torch.empty(B, L, n_heads * head_dim, dtype=BF16, device=qkv.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(head_dim)
+    es = qkv.element_size()
+    kq = qkv.data_ptr() + n_heads * head_dim * es
+    vq = kq + n_kv_heads * head_dim * es
+    sb, ss = L * width, width
+    call("vgpt_attn_blockmask_fwd", qkv.data_ptr(), kq, vq, out.data_ptr(), pm.bits.data_ptr(),
+         pm.summary.data_ptr(), B, L, n_heads, n_kv_heads, head_dim,
+         sb, head_dim, ss, sb, head_dim, ss, sb, head_dim, ss,
+         L * n_heads * head_dim, head_dim, n_heads * head_dim, float(scale), variant, _stream())
+    return out
+
+
+def sdpa(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attn_mask=None, dropout_p: float = 0.0,
+         is_causal: bool = False, scale: Optional[float] = None, variant: int = 0):
+    """Drop-in for the `local_attn` slot (F.scaled_dot_product_attention) on (B, heads, S, d) tensors.
+
+    attn_mask: PackedMask, a (B,S,S) bool mask, or the additive (B,1,S,S) mask the reference builds.
+    """
+    if dropout_p != 0.0:
+        raise VgptError("sdpa: dropout is not supported")
+    if is_causal or attn_mask is None:
+        raise VgptError("sdpa: an explicit block mask is required (is_causal is not used by the reference path)")
+    for n, t in (("query", query), ("key", key), ("value", value)):
+        _chk(t, BF16, f"sdpa.{n}", contiguous=False)
+        if t.stride(-1) != 1:
+            raise VgptError(f"sdpa.{n}: head_dim axis must be contiguous")
+    B, Hq, S, d = query.shape
+    Hkv = key.shape[1]
+    pm = attn_mask if isinstance(attn_mask, PackedMask) else pack_mask(attn_mask)
+    out = torch.empty(B, Hq, S, d, dtype=BF16, device=query.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(d)
+    call("vgpt_attn_blockmask_fwd", query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),
+         pm.bits.data_ptr(), pm.summary.data_ptr(), B, S, Hq, Hkv, d,
+         query.stride(0), query.stride(1), query.stride(2), key.stride(0), key.stride(1), key.stride(2),
+         value.stride(0), value.stride(1), value.stride(2), out.stride(0), out.stride(1), out.stride(2),
+         float(scale), variant, _stream())
+    return out
+
+
+# ---- model glue -----------------------------------------------------------------------------
+
+def embed_gather(ids: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None):
+    _chk(ids, torch.int64, "embed.ids"); _chk(table, BF16, "embed.table")
+    V, H = table.shape
+    if out is None:
+        out = torch.empty(*ids.shape, H, dtype=BF16, device=ids.device)
+    call("vgpt_embed_gather", ids.data_ptr(), table.data_ptr(), out.data_ptr(), ids.numel(), H, V, _stream())
+    return out
+
+
+def patch_embed(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, pos_embed: torch.Tensor,
+                dst_row: torch.Tensor, seq: torch.Tensor, pos_max: int):
+    """x: (n_frames, C, h, w); writes H-wide token rows into seq (rows, H) at dst_row[f] + t."""
+    _chk(x, BF16, "patch_embed.x"); _chk(weight, BF16, "patch_embed.weight"); _chk(bias, BF16, "patch_embed.bias")
+    _chk(pos_embed, BF16, "patch_embed.pos_embed"); _chk(dst_row, torch.int32, "patch_embed.dst_row")
+    _chk(seq, BF16, "patch_embed.seq")
+    nf, C, h, w = x.shape
+    H = weight.shape[0]
+    if dst_row.numel() != nf:
+        raise VgptError("patch_embed: dst_row size mismatch")
+    call("vgpt_patch_embed_fwd", x.data_ptr(), weight.data_ptr(), bias.data_ptr(), pos_embed.data_ptr(),
+         dst_row.data_ptr(), seq.data_ptr(), nf, C, h, w, H, pos_max, _stream())
+    return seq
+
+
+def timestep_freqs(dim: int, device, max_period: float = 10000.0) -> torch.Tensor:
+    """freqs of TimestepEmbedder.timestep_embedding (LVM/model.py:50-53), host-computed."""
+    half = dim // 2
+    f = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+    return f.to(device)
+
+
+def timestep_sinusoid(t: torch.Tensor, freqs: torch.Tensor, out: Optional[torch.Tensor] = None):
+    _chk(t, torch.float32, "timestep.t"); _chk(freqs, torch.float32, "timestep.freqs")
+    n, half = t.numel(), freqs.numel()
+    if out is None:
+        out = torch.empty(n, 2 * half, dtype=BF16, device=t.device)
+    call("vgpt_timestep_sinusoid", t.data_ptr(), freqs.data_ptr(), out.data_ptr(), n, half, _stream())
+    return out
+
+
+def linear_small(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], pre_act: int = ACT_NONE,
+                 post_act: int = ACT_NONE, out: Optional[torch.Tensor] = None,
+                 out_row: Optional[torch.Tensor] = None, ldo: Optional[int] = None):
+    _chk(x, BF16, "linear_small.x"); _chk(weight, BF16, "linear_small.weight")
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=x.device)
+    if ldo is None:
+        ldo = out.shape[-1]
+    call("vgpt_linear_small", x.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(out_row), M, N,
+         K, x.stride(0), ldo, pre_act, post_act, _stream())
+    return out
+
+
+def final_layer(hidden: torch.Tensor, src_row: torch.Tensor, mod: torch.Tensor, weight: torch.Tensor,
+                bias: torch.Tensor, out: torch.Tensor, eps: float = 1e-6):
+    """hidden (rows,H); mod (n_frames,2H) [shift|scale]; out (n_frames, C, h, w)."""
+    _chk(hidden, BF16, "final.hidden"); _chk(src_row, torch.int32, "final.src_row"); _chk(mod, BF16, "final.mod")
+    _chk(weight, BF16, "final.weight"); _chk(bias, BF16, "final.bias"); _chk(out, BF16, "final.out")
+    nf, C, h, w = out.shape
+    H = hidden.shape[-1]
+    call("vgpt_final_layer_fwd", hidden.data_ptr(), src_row.data_ptr(), mod.data_ptr(), weight.data_ptr(),
+         bias.data_ptr(), out.data_ptr(), nf, C, h, w, H, float(eps), _stream())
+    return out
+
+
+# ---- sampler ----------------------------------------------------------------------------------
+
+def sampler_set_timesteps(sigma: torch.Tensor, step: torch.Tensor, timesteps: torch.Tensor):
+    call("vgpt_sampler_set_timesteps", sigma.data_ptr(), step.data_ptr(), timesteps.data_ptr(),
+         timesteps.numel(), _stream())
+
+
+def euler_cfg_update(z: torch.Tensor, z_model: torch.Tensor, pred: torch.Tensor, sigma: torch.Tensor,
+                     step: torch.Tensor, pred_type: int, use_cfg: bool, cfg_scale: float):
+    _chk(z, torch.float32, "euler.z"); _chk(z_model, BF16, "euler.z_model"); _chk(pred, BF16, "euler.pred")
+    nf = z.shape[0]
+    call("vgpt_euler_cfg_update", z.data_ptr(), z_model.data_ptr(), pred.data_ptr(), sigma.data_ptr(),
+         step.data_ptr(), nf, z.numel() // nf, pred_type, int(use_cfg), float(cfg_scale), _stream())
+
+
+def sampler_advance(step: torch.Tensor):
+    call("vgpt_sampler_advance", step.data_ptr(), _stream())
+
+
+def cast_f32_to_bf16(src: torch.Tensor, dst: torch.Tensor):
+    call("vgpt_cast_f32_to_bf16", src.data_ptr(), dst.data_ptr(), src.numel(), _stream())
+
+
+class HipGraph:
+    """hipGraph capture/replay of a fixed launch sequence on the current torch stream."""
+
+    def __init__(self):
+        self._exec = None
+
+    def capture(self, fn):
+        stream = _stream()
+        call("vgpt_graph_begin_capture", stream)
+        try:
+            fn()
+        finally:
+            out = ctypes.c_void_p()
+            call("vgpt_graph_end_capture", stream, ctypes.byref(out))
+        self._exec = out.value
+        return self
+
+    def replay(self):
+        if self._exec is None:
+            raise VgptError("HipGraph.replay before capture")
+        call("vgpt_graph_launch", self._exec, _stream())
+
+    def __del__(self):
+        if getattr(self, "_exec", None):
+            try:
+                call("vgpt_graph_destroy", self._exec)
+            except Exception:
+                pass
+            self._exec = None
