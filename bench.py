@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py — next-clip denoise throughput of the HIP path (BASELINE.json metric, config[1]).
+
+Workload (N=1): 256^2 px -> latent (4,32,32) -> 256 tokens/frame, 258-token blocks; C=4 condition
+frames + G=8 generated frames, image CFG on (B=2, L=3096, 5160 real tokens), Phi-3-mini-class
+denoiser (H 3072, 32 layers, 32x96 heads, I 8192, SiLU), x1 prediction, bf16, random-init weights,
+synthetic latents, noise from torch.Generator("cpu").manual_seed(42).  One "step" = one Euler step
+of the sampler = one full forward over condition+denoise tokens (the reference recomputes
+everything every step, LVM/scheduler.py:174) + x1->v + CFG + update, replayed from a hipGraph.
+metric = denoised clip-tokens/sec = G*N*steps / time (whole job: summed over ranks; replicas only,
+each rank samples its own clip — weak scaling, no data-path collective).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BF = torch.bfloat16
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def full_config(M, layers=32):
+    return M.Phi3Config(vocab_size=32064, hidden_size=3072, intermediate_size=8192, num_hidden_layers=layers,
+                        num_attention_heads=32, num_key_value_heads=32, hidden_act="silu", rms_norm_eps=1e-5,
+                        rope_theta=10000.0, pad_token_id=2)
+
+
+def build_model(M, cfg, device, seed=0):
+    """Random-init weights on the device: N(0, 0.02) Linear/Conv/Embedding weights and biases, norm gains
+    1 + 0.1 N(0,1), zero-initialised heads re-randomised."""
+    with torch.device("meta"):
+        model = M.LVM(cfg)
+    model = model.to_empty(device=device)
+    g = torch.Generator(device=device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("layernorm.weight") or name == "llm.norm.weight":
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g, device=device))
+            else:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g, device=device))
+        pe = M.get_2d_sincos_pos_embed(cfg.hidden_size, model.pos_embed_max_size, interpolation_scale=1.0, base_size=64)
+        model.pos_embed.copy_(torch.from_numpy(pe).float().unsqueeze(0))
+    return model.to(BF).eval()
+
+
+def visible_pairs(mask, valid):
+    """number of visible (q,k) pairs over real (non-pad) query rows — attention FLOPs = 4*H*pairs per layer."""
+    return int(mask[valid].sum().item())
+
+
+def cpu_baseline(cfg_full, batch, layers_sample=2):
+    """CPU restatement of the reference path (oracle/restate.py) on a bounded sample: `layers_sample`
+    of the 32 layers at full width over the full cfg-2 sequence; throughput scaled by layers."""
+    from oracle import restate as R
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    oc = R.Phi3Cfg(hidden_size=cfg_full.hidden_size, intermediate_size=cfg_full.intermediate_size,
+                   num_hidden_layers=layers_sample, num_attention_heads=cfg_full.num_attention_heads,
+                   num_key_value_heads=cfg_full.num_key_value_heads, vocab_size=64, pad_token_id=2)
+    p = R.make_params(oc, seed=0, pos_embed=False)
+    B, L = batch["input_ids"].shape
+    x = torch.randn(B, L, oc.hidden_size, generator=torch.Generator("cpu").manual_seed(1)) * 0.5
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        R.transformer(p, oc, x, batch["attention_mask"], batch["position_ids"])
+        dt = time.perf_counter() - t0
+    step_s = dt * cfg_full.num_hidden_layers / layers_sample
+    return {"value": 8 * 256 / step_s, "unit": "clip-tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{layers_sample} of {cfg_full.num_hidden_layers} decoder layers (fp32, torch CPU) over the full "
+                      f"B=2 x L={L} cfg-2 sequence took {dt:.2f}s; scaled x{cfg_full.num_hidden_layers // layers_sample} "
+                      "to one denoise step (embedders/final layer/Euler update are <0.1% and omitted)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers => INVALID as a benchmark")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    importlib.import_module("video-gpt_amd")
+    M = importlib.import_module("video-gpt_amd.model")
+    P = importlib.import_module("video-gpt_amd.processor")
+    E = importlib.import_module("video-gpt_amd.engine")
+    S = importlib.import_module("video-gpt_amd.scheduler")
+    ops = importlib.import_module("video-gpt_amd.ops")
+
+    # ---- workload: cfg-2 ----
+    C, G, hw = 4, 8, (32, 32)
+    N = (hw[0] // 2) * (hw[1] // 2)
+    cfg = full_config(M, args.layers)
+    model = build_model(M, cfg, device, seed=0)
+    tok = P.SpecialTokenizer(10, 11, 12)
+    proc = P.LVMProcessor(tok)
+    prompt = "".join(f"<img><|image_{i + 1}|></img>" if i < C else f"<|diffusion|><|image_{i + 1}|>" for i in range(C + G))
+    prompt_ = "".join(f"<|diffusion|><|image_{i + 1}|>" for i in range(G))
+    imgs = [torch.zeros(3, hw[0] * 8, hw[1] * 8) for _ in range(C)]
+    batch = proc.prompt_condition_frame_block_inference([prompt, prompt_], [imgs, []], height=hw[0] * 8, width=hw[1] * 8,
+                                                        use_img_cfg=True, frame_blocks=[C, G])
+    g = torch.Generator("cpu").manual_seed(42 + rank)
+    noise = [torch.randn(1, 4, *hw, generator=g) for _ in range(G)]
+    z = [n.to(device, BF) for n in noise] * 2
+    cond = [torch.randn(1, 4, *hw, generator=torch.Generator("cpu").manual_seed(1000 + i)).to(device, BF) for i in range(C)]
+    total_steps = args.warmup + args.steps
+    sched = S.LVMScheduler(num_steps=max(total_steps, 1), time_shifting_factor=1)
+    eng = E.StaticDenoiser(model, batch["input_ids"].to(device), batch["position_ids"].to(device),
+                           batch["attention_mask"].to(device), cond, batch["input_image_sizes"],
+                           batch["denoise_image_sizes"], batch["time_emb_inx"], len(z), hw, True, 1.6, "x1",
+                           sigma=sched.sigma)
+
+    B, L = batch["input_ids"].shape
+    valid = batch["input_ids"] != 2
+    real_tokens = int(valid.sum())
+    H, I, nl = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    pairs = visible_pairs(batch["attention_mask"], valid)
+    flops_linear = 2 * (4 * H * H + 3 * H * I) * real_tokens * nl
+    flops_attn = 4 * H * pairs * nl
+    flops_step = flops_linear + flops_attn
+
+    stream = torch.cuda.Stream(device=device)
+    use_graph = not args.no_graph
+    with torch.cuda.stream(stream):
+        eng.set_latents(torch.cat(z, dim=0))
+        if use_graph:
+            eng.capture()
+        eng.run(args.warmup, use_graph=use_graph)
+        stream.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run(args.steps, use_graph=use_graph)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    value = world * G * N * args.steps / elapsed
+    finite = bool(torch.isfinite(eng.z).all().item())
+
+    # ---- roofline of the dominant kernel: the plain NT GEMM (qkv_proj, o_proj, down_proj launches),
+    #      HIP events around every one of its launches during one extra eager denoise step ----
+    roof = None
+    if rank == 0:
+        ev = []
+        orig_linear = ops.linear
+
+        def timed_linear(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(stream)
+            out = orig_linear(*a, **k)
+            e.record(stream)
+            ev.append((s, e))
+            return out
+
+        with torch.cuda.stream(stream):
+            ops.linear = timed_linear
+            try:
+                eng.step.zero_()
+                ops.sampler_set_timesteps(eng.sigma, eng.step, eng.ts)
+                eng.forward_step()
+            finally:
+                ops.linear = orig_linear
+            stream.synchronize()
+        t_gemm = sum(s.elapsed_time(e) for s, e in ev) * 1e-3
+        n_launch = len(ev)
+        alg = 2 * (4 * H * H + H * I) * real_tokens * nl  # qkv (3H^2) + o (H^2) + down (HI), real tokens
+        achieved = alg / t_gemm / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<MODE_PLAIN> (qkv_proj/o_proj/down_proj)",
+                "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "launches": n_launch, "avg_launch_us": round(t_gemm / max(n_launch, 1) * 1e6, 1),
+                "alg_flops_per_launch": alg / max(n_launch, 1),
+                "whole_step": {"alg_tflop": round(flops_step / 1e12, 2),
+                               "achieved": round(flops_step / (ms_per_step * 1e-3) / 1e12, 1),
+                               "frac": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}}
+
+    if rank == 0:
+        line = {"metric": "denoised clip-tokens/sec (256^2, 8-frame next-clip, CFG, x1)", "value": round(value, 1),
+                "unit": "clip-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "cfg-2 single-GPU inference: 256^2, C=4 cond + G=8 gen frames, CFG (B=2, L=3096, "
+                                       f"{real_tokens} real tokens), Phi-3-mini-class denoiser {nl} layers, x1 prediction, "
+                                       "hipGraph sampler step" + ("" if nl == 32 else " [DEBUG layer count: INVALID]"),
+                           "global_batch": world, "parallelism": f"replicas x{world}", "graph": use_graph,
+                           "finite": finite},
+                "roofline": roof}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg, batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

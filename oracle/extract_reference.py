@@ -131,3 +131,27 @@ def reference_stage1_batch(F_list, N: int, sp: int = 1):
     tix = {b: [s[0] - 1 for s in den[b]] for b in sizes}
     return dict(input_ids=ids, position_ids=pos, attention_mask=mask, input_image_sizes=inp,
                 denoise_image_sizes=den, time_emb_inx=tix)
+
+
+def reference_frame_block_training_batch(frame_blocks_list, N: int, sp: int = 1):
+    """Stage-2+ layout: prompt as LVM/train_helper/data.py:358-380, collated by
+    process_mllm_input_frame_block_training (LVM/processor.py:893-914)."""
+    ns = collator_classes()
+    side = int(round(math.sqrt(N))) * 16
+    proc = types.SimpleNamespace(text_tokenizer=StubTokenizer())
+    layout = ns.LVMProcessor.process_multi_modal_prompt_frame_block_training
+    rows = []
+    for fbs in frame_blocks_list:
+        prompt, i, j, n_img = "", 0, 0, 0
+        for k, fb in enumerate(fbs):
+            for _ in range(fb):
+                prompt += f"<|diffusion|><|image_{i + 1}|>"; i += 1; n_img += 1
+            if k != len(fbs) - 1:
+                for _ in range(fb):
+                    prompt += f"<img><|image_{j + 1}|></img>"; j += 1
+        row = layout(proc, prompt, [torch.zeros(3, side, side) for _ in range(n_img)], fbs)
+        row["frame_blocks"] = fbs
+        rows.append(row)
+    coll = ns.LVMCollator(pad_token_id=2, hidden_size=8, sequence_parallel_size=sp)
+    ids, pos, mask, pixel_values, sizes, fb = coll.process_mllm_input_frame_block_training(rows)
+    return dict(input_ids=ids, position_ids=pos, attention_mask=mask, image_sizes=sizes, frame_blocks=fb)

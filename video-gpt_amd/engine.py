@@ -1,0 +1,176 @@
+"""StaticDenoiser: one next-clip denoise step as a fixed, allocation-free launch sequence, and the
+Euler sampling loop over it replayed from a hipGraph.
+
+This is the execution plan behind `LVMScheduler.__call__` when it drives
+`LVM.frame_block_forward_with_cfg` (LVM/scheduler.py:161-208 calling LVM/model.py:519-566 once per
+step with `past_key_values=None`).  All buffers are allocated once per clip; a step is
+  set_timesteps -> sequence assembly (embedding gather, condition patch-embed, time tokens,
+  noisy patch-embed) -> 32 x [rmsnorm, qkv GEMM, RoPE, block-masked attention, o_proj GEMM +
+  residual, rmsnorm, gate_up GEMM + act*up, down GEMM + residual] -> final norm -> t_embedder /
+  adaLN -> final layer + unpatchify -> Euler / x1->v / CFG update -> step counter += 1,
+every launch reading the step index and sigma table from device memory, so the captured graph is
+identical for every step.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .ops import BF16, VgptError
+
+
+def _rows(sizes: Dict[int, list], L: int, span: bool):
+    out = []
+    for b in sizes.keys():
+        for item in sizes[b]:
+            out.append(b * L + (item[0] if span else item))
+    return out
+
+
+class StaticDenoiser:
+    def __init__(self, model, input_ids, position_ids, attention_mask, input_img_latents, input_image_sizes,
+                 denoise_image_sizes, time_emb_inx, n_frames: int, latent_hw, use_img_cfg: bool, img_cfg_scale: float,
+                 prediction_type: str = "v", sigma: Optional[torch.Tensor] = None):
+        model._check_ready()
+        self.model = model
+        cfg = model.llm.config
+        self.cfg = cfg
+        dev = input_ids.device
+        self.dev = dev
+        B, L = input_ids.shape
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        self.B, self.L, self.H = B, L, H
+        self.nf = n_frames
+        self.h, self.w = latent_hw
+        C = model.in_channels
+        self.use_cfg = bool(use_img_cfg)
+        self.cfg_scale = float(img_cfg_scale)
+        if prediction_type not in ("v", "x1"):
+            raise VgptError(f"unknown prediction_type {prediction_type!r}")
+        self.pred_type = ops.PRED_X1 if prediction_type == "x1" else ops.PRED_V
+        if self.use_cfg and n_frames % 2:
+            raise VgptError("CFG needs an even number of latent frames")
+
+        # static inputs
+        self.input_ids = input_ids.contiguous()
+        self.pm = attention_mask if isinstance(attention_mask, ops.PackedMask) else ops.pack_mask(attention_mask)
+        self.rope = model.llm.rope_tables(position_ids)
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+        self.cond = None
+        if input_img_latents is not None and len(input_img_latents) > 0:
+            shapes = {tuple(t.shape[-2:]) for t in input_img_latents}
+            if len(shapes) != 1:
+                raise VgptError("StaticDenoiser needs condition frames of one resolution")
+            self.cond = torch.cat([t.to(BF16) for t in input_img_latents], dim=0).contiguous()
+            rows = _rows(input_image_sizes, L, True)
+            if len(rows) != self.cond.shape[0]:
+                raise AssertionError("input_image_sizes and input_img_latents disagree")
+            self.cond_rows = i32(rows)
+        x_rows = _rows(denoise_image_sizes, L, True)
+        t_rows = _rows(time_emb_inx, L, False)
+        if len(x_rows) != n_frames or len(t_rows) != n_frames:
+            raise AssertionError("denoise_image_sizes / time_emb_inx disagree with the number of latents")
+        self.x_rows, self.t_rows = i32(x_rows), i32(t_rows)
+
+        # per-step state
+        M = B * L
+        e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+        self.z = e(n_frames, C * self.h * self.w, dt=torch.float32)
+        self.z_model = e(n_frames, C, self.h, self.w)
+        self.pred = e(n_frames, C, self.h, self.w)
+        self.ts = e(n_frames, dt=torch.float32)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sigma = None
+        if sigma is not None:
+            self.set_sigma(sigma)
+        # workspaces
+        nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.hid = e(B, L, H)
+        self.nrm = e(B, L, H)
+        self.qkv = e(B, L, (nq + 2 * nk) * hd)
+        self.ctx = e(B, L, nq * hd)
+        self.act = e(B, L, I)
+        self.temb_sin = e(n_frames, 256)
+        self.tt_h = e(n_frames, H)
+        self.te_h = e(n_frames, H)
+        self.temb = e(n_frames, H)
+        self.mod = e(n_frames, 2 * H)
+        self.graph = None
+
+    def set_sigma(self, sigma: torch.Tensor):
+        self.sigma = sigma.to(self.dev, torch.float32).contiguous()
+        self.num_steps = self.sigma.numel() - 1
+
+    def set_latents(self, z: torch.Tensor):
+        """z: (n_frames, C, h, w) any float dtype; becomes the fp32 sampler state."""
+        self.z.copy_(z.reshape(self.nf, -1).to(torch.float32))
+        ops.cast_f32_to_bf16(self.z, self.z_model)
+        self.step.zero_()
+
+    # ---- one denoise forward: z_model, ts -> pred ----
+    def forward_step(self):
+        m, cfg, H = self.model, self.cfg, self.H
+        seq2d = self.hid.view(-1, H)
+        pos = m.pos_embed[0]
+        ops.embed_gather(self.input_ids, m.llm.embed_tokens.weight, out=self.hid)
+        if self.cond is not None:
+            ops.patch_embed(self.cond, m.input_x_embedder.proj.weight, m.input_x_embedder.proj.bias, pos,
+                            self.cond_rows, seq2d, m.pos_embed_max_size)
+        ops.timestep_sinusoid(self.ts, m.time_token.freqs(self.dev), out=self.temb_sin)
+        tt = m.time_token.mlp
+        ops.linear_small(self.temb_sin, tt[0].weight, tt[0].bias, post_act=ops.ACT_SILU, out=self.tt_h)
+        ops.linear_small(self.tt_h, tt[2].weight, tt[2].bias, out=seq2d, out_row=self.t_rows, ldo=H)
+        ops.patch_embed(self.z_model, m.x_embedder.proj.weight, m.x_embedder.proj.bias, pos, self.x_rows, seq2d,
+                        m.pos_embed_max_size)
+        nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        for layer in m.llm.layers:
+            at, mlp = layer.self_attn, layer.mlp
+            ops.rmsnorm(self.hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=self.nrm)
+            ops.linear(self.nrm, at.qkv_proj.weight, out=self.qkv)
+            ops.rope_qk_inplace(self.qkv, self.rope[0], self.rope[1], nq, nk, hd)
+            ops.attention_qkv(self.qkv, self.pm, nq, nk, hd, out=self.ctx)
+            ops.linear(self.ctx, at.o_proj.weight, residual=self.hid, out=self.hid)
+            ops.rmsnorm(self.hid, layer.post_attention_layernorm.weight,
+                        layer.post_attention_layernorm.variance_epsilon, out=self.nrm)
+            ops.gated_mlp_act(self.nrm, mlp.gate_up_proj.weight, mlp.act, out=self.act)
+            ops.linear(self.act, mlp.down_proj.weight, residual=self.hid, out=self.hid)
+        ops.rmsnorm(self.hid, m.llm.norm.weight, m.llm.norm.variance_epsilon, out=self.nrm)
+        te = m.t_embedder.mlp
+        ops.linear_small(self.temb_sin, te[0].weight, te[0].bias, post_act=ops.ACT_SILU, out=self.te_h)
+        ops.linear_small(self.te_h, te[2].weight, te[2].bias, out=self.temb)
+        ada = m.final_layer.adaLN_modulation[1]
+        ops.linear_small(self.temb, ada.weight, ada.bias, pre_act=ops.ACT_SILU, out=self.mod)
+        ops.final_layer(self.nrm.view(-1, H), self.x_rows, self.mod, m.final_layer.linear.weight,
+                        m.final_layer.linear.bias, self.pred)
+
+    def sampler_step(self):
+        """LVM/scheduler.py:168-204 for one i: timesteps, model call, x1->v, CFG, Euler, i += 1."""
+        ops.sampler_set_timesteps(self.sigma, self.step, self.ts)
+        self.forward_step()
+        ops.euler_cfg_update(self.z, self.z_model, self.pred, self.sigma, self.step, self.pred_type, self.use_cfg,
+                             self.cfg_scale)
+        ops.sampler_advance(self.step)
+
+    def capture(self):
+        """Capture one sampler step into a hipGraph (must run on a non-default stream)."""
+        # one eager step first: kernels set their attributes on first launch, which is not capturable
+        saved = (self.z.clone(), self.z_model.clone(), self.step.clone())
+        self.sampler_step()
+        torch.cuda.current_stream().synchronize()
+        self.z.copy_(saved[0]); self.z_model.copy_(saved[1]); self.step.copy_(saved[2])
+        torch.cuda.current_stream().synchronize()
+        self.graph = ops.HipGraph().capture(self.sampler_step)
+        return self
+
+    def run(self, num_steps: Optional[int] = None, use_graph: bool = True):
+        n = self.num_steps if num_steps is None else num_steps
+        if use_graph and self.graph is None:
+            self.capture()
+        for _ in range(n):
+            if use_graph:
+                self.graph.replay()
+            else:
+                self.sampler_step()
+        return self.z

@@ -56,6 +56,8 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[tor
         out = torch.empty_like(x)
     else:
         _chk(out, BF16, "rmsnorm.out")
+    if x.numel() == 0:
+        return out
     call("vgpt_rmsnorm_fwd", x.data_ptr(), weight.data_ptr(), out.data_ptr(), x.numel() // H, H,
          float(eps), _stream())
     return out

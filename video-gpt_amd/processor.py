@@ -1,0 +1,415 @@
+"""Input assembly for the clip-token sequence: prompt layout, left padding, RoPE positions, block
+attention masks and the index dictionaries the model consumes.
+
+Mirrors the interface of the reference's `LVMProcessor` / `LVMCollator` for the video path
+(LVM/processor.py:128-274 prompt layouts, :442-534 positions, :575-731 masks, :812-838 padding,
+:869-1000 batch assembly) — same method names, argument meaning and return structure — but the
+masks are produced from a closed-form visibility rule over per-token attributes instead of
+painting slices block by block:
+
+  every frame is a block of `bl = N + 2` tokens; a CLEAN block is `<img>`, N image slots, `</img>`,
+  a NOISY block is `<|diffusion|>`, one time slot, N image slots; consecutive noisy blocks that are
+  denoised together form a CLIP.
+
+  * a clean key k is visible to every row q >= thr(k) (sequence order), with thr = k for `<img>` and
+    `</img>` and thr = block_start + 1 for the image slots (bidirectional inside the frame);
+  * a noisy key is visible only to rows of the same clip: its `<|diffusion|>` column to all of them,
+    its time column to rows at in-block offset >= 1, its image columns to image rows (offset >= 2);
+  * pad columns are never visible, pad rows see everything.
+
+The three layouts of the reference (next-clip inference, stage-1 interleaved, stage-2+ frame-block
+groups) differ only in block order and clip membership.  Bit-exactness against the reference's own
+collator is pinned by tests/golden/collator_*.npz (tests/test_collator.py).
+"""
+from __future__ import annotations
+
+import re
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+PAD, CLEAN, NOISY = 0, 1, 2
+
+
+# ------------------------------------------------------------------------------------------------
+# block plans: list of (kind, clip_id) in sequence order, plus RoPE block indices
+# ------------------------------------------------------------------------------------------------
+
+def plan_inference(frame_blocks: Sequence[int]):
+    """[C, G] -> C clean blocks then one clip of G noisy blocks; positions run on (LVM/processor.py:502-534)."""
+    *clean, g = frame_blocks
+    kinds = [(CLEAN, -1)] * int(sum(clean)) + [(NOISY, 0)] * int(g)
+    return kinds, list(range(len(kinds)))
+
+
+def plan_stage1(n_blocks: int):
+    """noisy_0, clean_0, noisy_1, ... (2F-1 blocks); noisy_i and clean_i share position block i (:442-467)."""
+    kinds, pos = [], []
+    for i in range(n_blocks):
+        if i % 2 == 0:
+            kinds.append((NOISY, i // 2))
+        else:
+            kinds.append((CLEAN, -1))
+        pos.append(i // 2)
+    return kinds, pos
+
+
+def plan_frame_block_training(frame_blocks: Sequence[int]):
+    """[noisy x fb, clean x fb] per group, last group noisy only; separate position counters (:469-500)."""
+    kinds, pos = [], []
+    noisy_ctr = clean_ctr = 0
+    for k, fb in enumerate(frame_blocks):
+        for _ in range(fb):
+            kinds.append((NOISY, k)); pos.append(noisy_ctr); noisy_ctr += 1
+        if k != len(frame_blocks) - 1:
+            for _ in range(fb):
+                kinds.append((CLEAN, -1)); pos.append(clean_ctr); clean_ctr += 1
+    return kinds, pos
+
+
+def block_mask(kinds, bl: int, pad: int) -> np.ndarray:
+    """(L, L) uint8 visibility of one row of the batch from its block plan (closed-form rule)."""
+    n = len(kinds) * bl
+    L = n + pad
+    kind = np.zeros(L, dtype=np.int8)
+    clip = np.full(L, -1, dtype=np.int32)
+    off = np.zeros(L, dtype=np.int32)
+    thr = np.zeros(L, dtype=np.int64)
+    idx = np.arange(L)
+    for i, (kd, cl) in enumerate(kinds):
+        s = pad + i * bl
+        kind[s:s + bl] = kd
+        clip[s:s + bl] = cl
+        off[s:s + bl] = np.arange(bl)
+        if kd == CLEAN:
+            thr[s:s + bl] = s + 1
+            thr[s] = s
+            thr[s + bl - 1] = s + bl - 1
+    q_is_noisy = (kind == NOISY)[:, None]
+    k_kind = kind[None, :]
+    vis_clean = (k_kind == CLEAN) & (idx[:, None] >= thr[None, :])
+    k_off, q_off = off[None, :], off[:, None]
+    same_clip = q_is_noisy & (k_kind == NOISY) & (clip[:, None] == clip[None, :])
+    vis_noisy = same_clip & ((k_off == 0) | ((k_off == 1) & (q_off >= 1)) | ((k_off >= 2) & (q_off >= 2)))
+    m = vis_clean | vis_noisy
+    m[:pad, :] = True
+    return m.astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+
+class LVMCollator:
+    def __init__(self, pad_token_id: int = 2, hidden_size: int = 3072, sequence_parallel_size: int = 1):
+        self.pad_token_id = pad_token_id
+        self.hidden_size = hidden_size
+        self.sequence_parallel_size = sequence_parallel_size
+
+    # -- padding (LVM/processor.py:812-838) --
+    def pad_input_ids_training(self, input_ids: List[List[int]], image_sizes: Dict[int, list]):
+        max_l = max(len(r) for r in input_ids)
+        sp = self.sequence_parallel_size
+        if max_l % sp != 0:
+            max_l += sp - max_l % sp
+        ids = np.full((len(input_ids), max_l), self.pad_token_id, dtype=np.int64)
+        valid = np.zeros((len(input_ids), max_l), dtype=np.uint8)
+        for i, row in enumerate(input_ids):
+            pad = max_l - len(row)
+            ids[i, pad:] = row
+            valid[i, pad:] = 1
+            if i in image_sizes:
+                image_sizes[i] = [[s + pad, e + pad] for s, e in image_sizes[i]]
+        return torch.from_numpy(ids), torch.from_numpy(valid), image_sizes
+
+    # -- positions --
+    @staticmethod
+    def _block_len(sizes, lead: int):
+        pad = sizes[0][0] - lead
+        token_l = sizes[-1][-1] - pad
+        if token_l % len(sizes) != 0:
+            raise AssertionError("sequence is not a whole number of equal frame blocks")
+        return pad, token_l // len(sizes)
+
+    @staticmethod
+    def _positions(pad: int, bl: int, pos_blocks):
+        row = np.zeros(pad + len(pos_blocks) * bl, dtype=np.int64)
+        for i, pb in enumerate(pos_blocks):
+            row[pad + i * bl: pad + (i + 1) * bl] = np.arange(pb * bl, (pb + 1) * bl)
+        return row
+
+    def create_position_frame_block_inference(self, image_sizes, frame_blocks):
+        rows, block_ls = [], []
+        for b in image_sizes.keys():
+            # row 0 starts with a clean block (<img> precedes the first image), later rows (the CFG
+            # branch) with a noisy one (<|diffusion|>, time) — LVM/processor.py:508-511
+            pad, bl = self._block_len(image_sizes[b], 1 if b == 0 else 2)
+            block_ls.append(bl)
+            _, pos_blocks = plan_inference(frame_blocks[b])
+            rows.append(self._positions(pad, bl, pos_blocks))
+        return torch.from_numpy(np.stack(rows)), block_ls
+
+    def create_position_training(self, image_sizes):
+        rows, block_ls = [], []
+        for b in image_sizes.keys():
+            pad, bl = self._block_len(image_sizes[b], 2)
+            block_ls.append(bl)
+            _, pos_blocks = plan_stage1(len(image_sizes[b]))
+            rows.append(self._positions(pad, bl, pos_blocks))
+        return torch.from_numpy(np.stack(rows)), block_ls
+
+    def create_position_frame_block_training(self, image_sizes, frame_blocks):
+        rows, block_ls = [], []
+        for b in image_sizes.keys():
+            pad, bl = self._block_len(image_sizes[b], 2)
+            block_ls.append(bl)
+            _, pos_blocks = plan_frame_block_training(frame_blocks[b])
+            rows.append(self._positions(pad, bl, pos_blocks))
+        return torch.from_numpy(np.stack(rows)), block_ls
+
+    # -- masks --
+    @staticmethod
+    def _masks(attention_mask, block_ls, plans):
+        seq_len = attention_mask.size(-1)
+        out = np.empty((attention_mask.size(0), seq_len, seq_len), dtype=np.uint8)
+        for i in range(attention_mask.size(0)):
+            valid = int(attention_mask[i].sum())
+            kinds = plans(i, valid // block_ls[i])
+            if len(kinds) * block_ls[i] != valid:
+                raise AssertionError("block plan does not cover the valid tokens")
+            out[i] = block_mask(kinds, block_ls[i], seq_len - valid)
+        return torch.from_numpy(out).to(torch.bool)
+
+    def create_mask_frame_block_inference(self, attention_mask, block_ls, frame_blocks):
+        return self._masks(attention_mask, block_ls, lambda i, n: plan_inference(frame_blocks[i])[0])
+
+    def create_mask_training(self, attention_mask, block_ls):
+        return self._masks(attention_mask, block_ls, lambda i, n: plan_stage1(n)[0])
+
+    def create_mask_frame_block_training(self, attention_mask, block_ls, frame_blocks):
+        return self._masks(attention_mask, block_ls, lambda i, n: plan_frame_block_training(frame_blocks[i])[0])
+
+    # -- batch assembly --
+    @staticmethod
+    def _gather(mllm_inputs, with_frame_blocks: bool):
+        pixel_values, image_sizes, frame_blocks = [], {}, {}
+        for b, x in enumerate(mllm_inputs):
+            if x["pixel_values"] is not None:
+                pixel_values.extend(x["pixel_values"])
+                for size in x["image_sizes"]:
+                    image_sizes.setdefault(b, []).append(size)
+                    if with_frame_blocks:
+                        frame_blocks[b] = x["frame_blocks"]
+        pixel_values = [p.unsqueeze(0) for p in pixel_values]
+        return pixel_values, image_sizes, frame_blocks
+
+    def process_mllm_input_frame_block_inference(self, mllm_inputs, block_aware=False):
+        pixel_values, image_sizes, frame_blocks = self._gather(mllm_inputs, True)
+        ids, valid, image_sizes = self.pad_input_ids_training([x["input_ids"] for x in mllm_inputs], image_sizes)
+        position_ids, block_ls = self.create_position_frame_block_inference(image_sizes, frame_blocks)
+        mask = self.create_mask_frame_block_inference(valid, block_ls, frame_blocks)
+        return ids, position_ids, mask, pixel_values, image_sizes, frame_blocks
+
+    def process_mllm_input_training(self, mllm_inputs, block_aware=False):
+        if block_aware:
+            raise NotImplementedError("block_aware masks are not used by the reference's scripts")
+        pixel_values, image_sizes, _ = self._gather(mllm_inputs, False)
+        ids, valid, image_sizes = self.pad_input_ids_training([x["input_ids"] for x in mllm_inputs], image_sizes)
+        position_ids, block_ls = self.create_position_training(image_sizes)
+        mask = self.create_mask_training(valid, block_ls)
+        return ids, position_ids, mask, pixel_values, image_sizes
+
+    def process_mllm_input_frame_block_training(self, mllm_inputs, block_aware=False):
+        pixel_values, image_sizes, frame_blocks = self._gather(mllm_inputs, True)
+        ids, valid, image_sizes = self.pad_input_ids_training([x["input_ids"] for x in mllm_inputs], image_sizes)
+        position_ids, block_ls = self.create_position_frame_block_training(image_sizes, frame_blocks)
+        mask = self.create_mask_frame_block_training(valid, block_ls, frame_blocks)
+        return ids, position_ids, mask, pixel_values, image_sizes, frame_blocks
+
+    def process_mllm_input_frame_block_call(self, features):
+        """LVM/processor.py:964-1000: split the per-row image slots into condition / denoise / time indices."""
+        ids, position_ids, mask, pixel_values, sizes, frame_blocks = self.process_mllm_input_frame_block_inference(features)
+        denoise, inputs, time_inx, input_images = {}, {}, {}, []
+        pv = 0
+        for b in sizes.keys():
+            n_clean = int(sum(frame_blocks[b][:-1]))
+            inputs[b] = sizes[b][:n_clean]
+            denoise[b] = sizes[b][n_clean:]
+            time_inx[b] = [s[0] - 1 for s in denoise[b]]
+            input_images.extend(pixel_values[pv:pv + n_clean])
+            pv += n_clean
+        return {"input_ids": ids, "attention_mask": mask, "position_ids": position_ids,
+                "input_pixel_values": input_images, "input_image_sizes": inputs, "denoise_image_sizes": denoise,
+                "output_images": [], "time_emb_inx": time_inx, "frame_blocks": frame_blocks}
+
+    def collate_stage1(self, mllm_inputs, frame_num: int):
+        """TrainDataCollator.__call__ (LVM/train_helper/data.py:422-458) without the video I/O."""
+        ids, position_ids, mask, pixel_values, sizes = self.process_mllm_input_training(mllm_inputs)
+        denoise = {b: [s for i, s in enumerate(sizes[b]) if i % 2 == 0] for b in sizes}
+        inputs = {b: [s for i, s in enumerate(sizes[b]) if i % 2 == 1] for b in sizes}
+        time_inx = {b: [s[0] - 1 for s in denoise[b]] for b in sizes}
+        per = 2 * frame_num - 1
+        return {"input_ids": ids, "attention_mask": mask, "position_ids": position_ids,
+                "input_pixel_values": [p for i, p in enumerate(pixel_values) if i % per % 2 == 1],
+                "input_image_sizes": inputs, "denoise_image_sizes": denoise,
+                "output_images": [p for i, p in enumerate(pixel_values) if i % per % 2 == 0],
+                "time_emb_inx": time_inx}
+
+
+# ------------------------------------------------------------------------------------------------
+
+class SpecialTokenizer:
+    """Minimal stand-in for the Phi-3 tokenizer on the video path, which only ever tokenises the
+    special tags `<img>`, `</img>`, `<|diffusion|>` (LVM/pipeline.py:426-439).  Pass a real
+    `transformers` tokenizer to LVMProcessor when a checkpoint directory is available."""
+
+    def __init__(self, img: int = 32001, img_end: int = 32002, diffusion: int = 32003, bos: int = 1):
+        self.table = {"<img>": img, "</img>": img_end, "<|diffusion|>": diffusion}
+        self.bos = bos
+
+    def __call__(self, text: str):
+        ids, pos = [self.bos], 0
+        while pos < len(text):
+            for tag, tid in self.table.items():
+                if text.startswith(tag, pos):
+                    ids.append(tid)
+                    pos += len(tag)
+                    break
+            else:
+                raise ValueError(f"SpecialTokenizer cannot tokenise {text[pos:pos + 16]!r}; pass a real tokenizer")
+
+        class _Out:
+            input_ids = ids
+        return _Out()
+
+
+class LVMProcessor:
+    """Prompt layout + collation for the next-clip path (LVM/processor.py:23-421).  Image decoding /
+    resizing (PIL, torchvision) is host preprocessing outside the accelerated path: images are
+    accepted as float tensors (3, H, W) in [-1, 1] with H, W multiples of 16."""
+
+    _TAG = re.compile(r"<\|image_\d+\|>")
+
+    def __init__(self, text_tokenizer=None, max_image_size: int = 1024, sequence_parallel_size: int = 1):
+        self.text_tokenizer = text_tokenizer if text_tokenizer is not None else SpecialTokenizer()
+        self.max_image_size = max_image_size
+        self.sequence_parallel_size = sequence_parallel_size
+        self.collator = LVMCollator(sequence_parallel_size=sequence_parallel_size)
+
+    @classmethod
+    def from_pretrained(cls, model_name, sequence_parallel_size: int = 1):
+        import os
+        tok = None
+        if os.path.isdir(model_name):
+            try:
+                from transformers import AutoTokenizer
+                tok = AutoTokenizer.from_pretrained(model_name)
+            except Exception:
+                tok = None
+        return cls(tok, sequence_parallel_size=sequence_parallel_size)
+
+    def process_image(self, image):
+        if not torch.is_tensor(image) or image.dim() != 3:
+            raise ValueError("Input must be a (3, H, W) tensor normalised to [-1, 1]")
+        if image.shape[-1] % 16 or image.shape[-2] % 16:
+            raise ValueError("image sides must be multiples of 16")
+        return image
+
+    def _chunks(self, text: str):
+        chunks = [list(self.text_tokenizer(c).input_ids) for c in self._TAG.split(text)]
+        chunks = [c[1:] if c and c[0] == 1 else c for c in chunks]
+        tags = self._TAG.findall(text)
+        ids = [int(t.split("|")[1].split("_")[-1]) for t in tags]
+        uniq = sorted(set(ids))
+        assert uniq == list(range(1, len(uniq) + 1)), f"image_ids must be continuous from 1, got {uniq}"
+        return chunks, ids, uniq
+
+    @staticmethod
+    def _ntok(img) -> int:
+        return img.size(-2) * img.size(-1) // 16 // 16
+
+    def process_multi_modal_prompt_frame_block(self, text, input_images, frame_blocks, height=None, width=None):
+        """LVM/processor.py:128-179."""
+        input_images = input_images or []
+        chunks, image_ids, uniq = self._chunks(text)
+        assert len(uniq) == len(input_images) + frame_blocks[-1], "image tags and images disagree"
+        input_images = [input_images[x - 1] for x in image_ids[:frame_blocks[0]]]
+        ids, sizes, idx = [], [], 0
+        for k, fb in enumerate(frame_blocks):
+            last = k == len(frame_blocks) - 1
+            for _ in range(fb):
+                ids.extend(chunks[idx])
+                if last:
+                    ids.append(0)  # time slot
+                    n = height * width // 256 if height is not None and width is not None else self._ntok(input_images[0])
+                else:
+                    n = self._ntok(input_images[idx])
+                sizes.append([len(ids), len(ids) + n])
+                ids.extend([0] * n)
+                idx += 1
+        return {"input_ids": ids, "pixel_values": input_images, "image_sizes": sizes}
+
+    def process_multi_modal_prompt_training(self, text, input_images):
+        """LVM/processor.py:181-218 (stage 1: every even chunk is followed by a time slot)."""
+        chunks, image_ids, uniq = self._chunks(text)
+        assert len(uniq) == len(input_images)
+        input_images = [input_images[x - 1] for x in image_ids]
+        ids, sizes = [], []
+        for i, c in enumerate(chunks):
+            ids.extend(c)
+            if i != len(chunks) - 1:
+                if i % 2 == 0:
+                    ids.append(0)
+                n = self._ntok(input_images[i])
+                sizes.append([len(ids), len(ids) + n])
+                ids.extend([0] * n)
+        return {"input_ids": ids, "pixel_values": input_images, "image_sizes": sizes}
+
+    def process_multi_modal_prompt_frame_block_training(self, text, input_images, frame_blocks):
+        """LVM/processor.py:220-274."""
+        chunks, image_ids, uniq = self._chunks(text)
+        assert len(uniq) == len(input_images)
+        input_images = [input_images[x - 1] for x in image_ids]
+        ids, sizes, idx = [], [], 0
+
+        def emit(noisy: bool):
+            nonlocal idx
+            ids.extend(chunks[idx])
+            if noisy:
+                ids.append(0)
+            n = self._ntok(input_images[idx])
+            sizes.append([len(ids), len(ids) + n])
+            ids.extend([0] * n)
+            idx += 1
+
+        for k, fb in enumerate(frame_blocks):
+            for _ in range(fb):
+                emit(True)
+            if k != len(frame_blocks) - 1:
+                for _ in range(fb):
+                    emit(False)
+        return {"input_ids": ids, "pixel_values": input_images, "image_sizes": sizes}
+
+    def prompt_condition_frame_block_inference(self, instructions, input_images=None, height: int = 1024,
+                                               width: int = 1024, use_img_cfg: bool = True,
+                                               use_input_image_size_as_output: bool = False,
+                                               frame_blocks: Optional[List[int]] = None) -> Dict:
+        """LVM/processor.py:366-421."""
+        if input_images is None:
+            use_img_cfg = False
+        if isinstance(instructions, str):
+            instructions, input_images = [instructions], [input_images]
+        imgs = input_images[0]
+        imgs = [self.process_image(x) for x in imgs] if imgs else None
+        row = self.process_multi_modal_prompt_frame_block(instructions[0], imgs, frame_blocks)
+        row["frame_blocks"] = frame_blocks
+        rows = [row]
+        if use_img_cfg:
+            imgs1 = input_images[1]
+            imgs1 = [self.process_image(x) for x in imgs1] if imgs1 else None
+            cfg_blocks = [0, frame_blocks[-1]]
+            cfg_row = self.process_multi_modal_prompt_frame_block(
+                instructions[1], imgs1, cfg_blocks, height=row["pixel_values"][0].size(-2),
+                width=row["pixel_values"][0].size(-1))
+            cfg_row["frame_blocks"] = cfg_blocks
+            rows.append(cfg_row)
+        return self.collator.process_mllm_input_frame_block_call(rows)

@@ -1,0 +1,125 @@
+"""LVMScheduler: Euler rectified-flow sampler (mirror of LVM/scheduler.py:119-208).
+
+`__call__(z, func, model_kwargs, ...)` keeps the reference contract:
+`func(z, timesteps, past_key_values=None, prediction_type=..., **model_kwargs) -> (pred, cache)`.
+
+Two execution paths, same arithmetic:
+  * fast path — `func` is `LVM.frame_block_forward_with_cfg` of this package and the latents are a
+    list of equal-shape frames: the whole step (model + x1->v + CFG + Euler) runs from one
+    hipGraph captured once per clip (engine.StaticDenoiser);
+  * generic path — any other `func`: the model call is the caller's, the x1->v / CFG / Euler update
+    is one HIP kernel per step.
+The sampler state is kept in fp32 and rounded to the model dtype only where it enters the model
+(the reference rounds the state to bf16 after every step; an fp32 state is closer to its fp32 CPU
+path).  KV caching is not used, exactly as the reference passes `past_key_values=None` every step
+(LVM/scheduler.py:174).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .ops import BF16, VgptError
+
+
+class LVMScheduler:
+    def __init__(self, num_steps: int = 50, time_shifting_factor: int = 1, begin_time=None):
+        self.num_steps = num_steps
+        self.time_shift = time_shifting_factor
+        t = torch.linspace(0 if begin_time is None else begin_time, 1, num_steps + 1)
+        self.sigma = t / (t + time_shifting_factor - time_shifting_factor * t)
+        self.use_graph = True
+        self.last_engine = None
+
+    # ---- fast path ----
+    def _fast_path_engine(self, z, func, model_kwargs, prediction_type):
+        from .engine import StaticDenoiser
+        from .model import LVM
+        owner = getattr(func, "__self__", None)
+        if not isinstance(owner, LVM) or getattr(func, "__name__", "") != "frame_block_forward_with_cfg":
+            return None
+        if not isinstance(z, (list, tuple)) or len({tuple(t.shape) for t in z}) != 1:
+            return None
+        lat = model_kwargs.get("input_img_latents")
+        if lat is not None and len(lat) > 0 and len({tuple(t.shape) for t in lat}) != 1:
+            return None
+        need = ("input_ids", "input_image_sizes", "attention_mask", "position_ids", "denoise_image_sizes",
+                "time_emb_inx", "use_img_cfg", "img_cfg_scale")
+        if any(k not in model_kwargs for k in need) or model_kwargs.get("offload_model"):
+            return None
+        return StaticDenoiser(owner, model_kwargs["input_ids"], model_kwargs["position_ids"],
+                              model_kwargs["attention_mask"], lat, model_kwargs["input_image_sizes"],
+                              model_kwargs["denoise_image_sizes"], model_kwargs["time_emb_inx"], len(z),
+                              tuple(z[0].shape[-2:]), model_kwargs["use_img_cfg"], model_kwargs["img_cfg_scale"],
+                              prediction_type, sigma=self.sigma)
+
+    def __call__(self, z, func, model_kwargs, use_kv_cache: bool = True, offload_kv_cache: bool = True,
+                 prediction_type: str = "v", vae=None, noise_level=None):
+        is_list = isinstance(z, (list, tuple))
+        frames = list(z) if is_list else [z]
+        if not frames[0].is_cuda:
+            raise VgptError("LVMScheduler runs on the MI355X HIP path only (latents must be on the GPU)")
+        out_dtype = frames[0].dtype
+        if noise_level is not None:  # LVM/scheduler.py:162-163 (RNG stays torch's)
+            frames = [f * noise_level + torch.randn_like(f) * (1 - noise_level) for f in frames]
+
+        engine = self._fast_path_engine(frames, func, model_kwargs, prediction_type) if is_list else None
+        if engine is not None:
+            self.last_engine = engine
+            stream = torch.cuda.current_stream()
+            side = None
+            if self.use_graph and stream.cuda_stream == 0:  # the legacy default stream cannot be captured
+                side = torch.cuda.Stream()
+                side.wait_stream(stream)
+            with torch.cuda.stream(side) if side is not None else _null():
+                engine.set_latents(torch.cat(frames, dim=0))
+                zf = engine.run(self.num_steps, use_graph=self.use_graph)
+            if side is not None:
+                stream.wait_stream(side)
+            zf = zf.view(len(frames), *frames[0].shape[1:]).to(out_dtype)
+            return [zf[i:i + 1] for i in range(len(frames))]
+
+        # ---- generic path ----
+        dev = frames[0].device
+        shapes = [tuple(f.shape) for f in frames]
+        sizes = [f.numel() for f in frames]
+        uniform = len(set(sizes)) == 1
+        if not uniform:
+            raise VgptError("generic sampler path needs latents of one size (mixed resolutions: call per size)")
+        n, elems = len(frames), sizes[0]
+        zf = torch.cat([f.reshape(1, -1) for f in frames], dim=0).to(torch.float32).contiguous()
+        zm = torch.empty(n, elems, dtype=BF16, device=dev)
+        ops.cast_f32_to_bf16(zf, zm)
+        sigma = self.sigma.to(dev, torch.float32).contiguous()
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        ts = torch.empty(n if is_list else frames[0].shape[0], dtype=torch.float32, device=dev)
+        use_cfg = bool(model_kwargs.get("use_img_cfg", False))
+        scale = float(model_kwargs.get("img_cfg_scale", 1.0))
+        # for 'v' predictions the CFG combination already happened inside func (LVM/model.py:555-562)
+        kernel_cfg = use_cfg and prediction_type == "x1"
+        for _ in range(self.num_steps):
+            ops.sampler_set_timesteps(sigma, step, ts)
+            z_in = [zm[i].view(shapes[i]) for i in range(n)] if is_list else zm.view(shapes[0])
+            pred, _cache = func(z_in, ts, past_key_values=None, prediction_type=prediction_type, **model_kwargs)
+            if is_list:
+                pred = torch.cat([p.reshape(1, -1) for p in pred], dim=0)
+            pred = pred.reshape(n, elems).to(BF16).contiguous()
+            if kernel_cfg and not is_list:
+                raise VgptError("x1 + CFG on a batched tensor is not supported; pass a list of frames")
+            ops.euler_cfg_update(zf, zm, pred, sigma, step, ops.PRED_X1 if prediction_type == "x1" else ops.PRED_V,
+                                 kernel_cfg, scale)
+            ops.sampler_advance(step)
+        out = zf.to(out_dtype)
+        if is_list:
+            return [out[i].view(shapes[i]) for i in range(n)]
+        return out.view(shapes[0])
+
+
+class _null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
