@@ -102,12 +102,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-
     importlib.import_module("video-gpt_amd")
+    D = importlib.import_module("video-gpt_amd.dist_utils")
+    D.init_from_env("nccl", device)
     M = importlib.import_module("video-gpt_amd.model")
     P = importlib.import_module("video-gpt_amd.processor")
     E = importlib.import_module("video-gpt_amd.engine")
@@ -154,20 +151,8 @@ def main():
             eng.capture()
         eng.run(args.warmup, use_graph=use_graph)
         stream.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        eng.run(args.steps, use_graph=use_graph)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # barrier + synchronize on both sides, MAX over ranks (dist_utils.timed_region)
+        elapsed = D.timed_region(lambda: eng.run(args.steps, use_graph=use_graph), torch.cuda.synchronize, device)
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     value = world * G * N * args.steps / elapsed
     finite = bool(torch.isfinite(eng.z).all().item())
@@ -224,8 +209,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, batch)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        D.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz.  Run in the build container (needs /root/reference):
+
+    python tests/make_golden.py
+
+Vectors whose name starts with `ref_` come from the REFERENCE'S OWN classes executed through
+oracle/extract_reference.py (collator, prompt layout, LVMScheduler, TimestepEmbedder, FinalLayer,
+PatchEmbedMR, sincos tables) — they pin the oracle and the product's host logic.  `oracle_*`
+vectors come from the CPU restatement (oracle/restate.py) where the reference cannot run here
+(the Phi3 decoder stack and LVM.frame_block_forward: parity unpinned by the reference, see
+oracle/__init__.py); they freeze the oracle so that GPU parity tests have a committed target.
+Only data is stored (inputs / expected outputs), never reference source text.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import extract_reference as X  # noqa: E402
+from oracle import restate as R  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def pack_mask(m: torch.Tensor):
+    a = m.numpy().astype(np.uint8)
+    return np.packbits(a.reshape(a.shape[0], -1), axis=-1), np.asarray(a.shape)
+
+
+def flat_sizes(d):
+    """{b: [[s,e],...]} -> (n,3) int array [b,s,e]; {b: [t,...]} -> (n,2)."""
+    rows = []
+    for b, items in d.items():
+        for it in items:
+            rows.append([b, *it] if isinstance(it, (list, tuple)) else [b, it])
+    return np.asarray(rows, dtype=np.int64).reshape(len(rows), -1)
+
+
+def save_batch(name, batch, extra=None):
+    bits, shape = pack_mask(batch["attention_mask"])
+    d = dict(input_ids=batch["input_ids"].numpy(), position_ids=batch["position_ids"].numpy(), mask_bits=bits,
+             mask_shape=shape)
+    for k in ("input_image_sizes", "denoise_image_sizes", "time_emb_inx", "image_sizes"):
+        if k in batch:
+            d[k] = flat_sizes(batch[k])
+    if extra:
+        d.update(extra)
+    np.savez_compressed(os.path.join(OUT, name), **d)
+
+
+def collator_vectors():
+    for C, G, N, sp in [(2, 2, 16, 1), (1, 3, 4, 4), (4, 8, 256, 1)]:
+        save_batch(f"ref_collator_infer_C{C}G{G}N{N}sp{sp}.npz", X.reference_inference_batch(C, G, N, sp=sp),
+                   dict(C=C, G=G, N=N, sp=sp))
+    for Fl, N in [([3, 2], 16), ([8, 8], 256)]:
+        save_batch(f"ref_collator_stage1_F{'_'.join(map(str, Fl))}N{N}.npz", X.reference_stage1_batch(Fl, N),
+                   dict(F=np.asarray(Fl), N=N))
+    for fbl, N in [([[1, 2, 2], [3, 1]], 16), ([[4, 4, 8]], 64)]:
+        b = X.reference_frame_block_training_batch(fbl, N)
+        flat = np.asarray([x for fb in fbl for x in fb] + [-1] + [len(fb) for fb in fbl])
+        save_batch(f"ref_collator_fbtrain_{'x'.join(str(len(f)) for f in fbl)}N{N}.npz", b,
+                   dict(frame_blocks_flat=flat, N=N))
+
+
+def scheduler_vectors():
+    Sched = X.scheduler_class()
+    out = {}
+    g = torch.Generator("cpu").manual_seed(7)
+    n, shp = 4, (1, 4, 6, 6)
+    z0 = [torch.randn(*shp, generator=g) for _ in range(n)]
+    a = [torch.randn(*shp, generator=g) * 0.3 for _ in range(n)]
+    c = [torch.randn(*shp, generator=g) for _ in range(n)]
+    out["z0"] = torch.stack(z0).numpy(); out["a"] = torch.stack(a).numpy(); out["c"] = torch.stack(c).numpy()
+
+    def func(z, timesteps, past_key_values=None, prediction_type="v", **kw):
+        pred = [a[j] * z[j] + c[j] * (1 + timesteps[j]) for j in range(len(z))]
+        if kw["use_img_cfg"] and prediction_type == "v":  # what LVM.frame_block_forward_with_cfg does for 'v'
+            h = len(pred) // 2
+            cond = [pred[h + j] + kw["img_cfg_scale"] * (pred[j] - pred[h + j]) for j in range(h)]
+            pred = cond + cond
+        return pred, None
+
+    for steps in (1, 3):
+        for pt in ("x1", "v"):
+            for cfg_on in (True, False):
+                for shift, begin in ((1, None), (3.0, 0.2)):
+                    s = Sched(num_steps=steps, time_shifting_factor=shift, begin_time=begin)
+                    z = s([t.clone() for t in z0], func, dict(use_img_cfg=cfg_on, img_cfg_scale=1.6), prediction_type=pt)
+                    key = f"steps{steps}_{pt}_cfg{int(cfg_on)}_shift{shift}_begin{begin}"
+                    out[key] = torch.stack(z).numpy()
+                    out["sigma_" + key] = s.sigma.numpy()
+    np.savez_compressed(os.path.join(OUT, "ref_scheduler.npz"), **out)
+
+
+def leaf_vectors():
+    L = X.model_leaf_classes()
+    out = {}
+    H = 64
+    torch.manual_seed(3)
+    te = L.TimestepEmbedder(H)
+    fl = L.FinalLayer(H, 2, 4)
+    pe = L.PatchEmbedMR(2, 4, H, bias=True)
+    with torch.no_grad():
+        for m in (te, fl, pe):
+            for p_ in m.parameters():
+                p_.normal_(0, 0.05)
+        t = torch.tensor([0.0, 0.013, 0.5, 0.77, 1.0])
+        x = torch.randn(3, 9, H)
+        cvec = torch.randn(3, H)
+        lat = torch.randn(2, 4, 6, 10)
+        out["t"] = t.numpy(); out["te_out"] = te(t).numpy(); out["te_sin"] = L.TimestepEmbedder.timestep_embedding(t, 256).numpy()
+        out["fl_x"] = x.numpy(); out["fl_c"] = cvec.numpy(); out["fl_out"] = fl(x, cvec).numpy()
+        out["pe_x"] = lat.numpy(); out["pe_out"] = pe(lat).numpy()
+        for n_, p_ in list(te.named_parameters()):
+            out["te." + n_] = p_.numpy()
+        for n_, p_ in list(fl.named_parameters()):
+            out["fl." + n_] = p_.numpy()
+        for n_, p_ in list(pe.named_parameters()):
+            out["pe." + n_] = p_.numpy()
+    out["sincos_64_12_b64"] = L.get_2d_sincos_pos_embed(64, 12, interpolation_scale=1.0, base_size=64)
+    out["sincos_32_7_b1_i2"] = L.get_2d_sincos_pos_embed(32, 7, interpolation_scale=2.0, base_size=1)
+    np.savez_compressed(os.path.join(OUT, "ref_leaf_modules.npz"), **out)
+
+
+def oracle_e2e_vectors():
+    """Tiny next-clip case (tests/smoke_case.py) frozen from the restatement."""
+    from tests import smoke_case as SC
+    cfg = R.TINY
+    p, batch, z, cond = SC.build_case(cfg)
+    out = {}
+    t = torch.full((len(z),), 0.3)
+    okw = {k: batch[k] for k in ("input_ids", "input_image_sizes", "attention_mask", "position_ids",
+                                 "denoise_image_sizes", "time_emb_inx")}
+    for pt in ("x1", "v"):
+        out[f"fwd_{pt}"] = torch.cat(R.frame_block_forward_with_cfg(p, cfg, z, t, True, 1.6, pt, input_img_latents=cond, **okw)).numpy()
+        out[f"sample3_{pt}"] = torch.cat(SC.oracle_sample(cfg, p, batch, z, cond, 3, pt)).numpy()
+    g = torch.Generator("cpu").manual_seed(5)
+    B, L = batch["input_ids"].shape
+    emb = (torch.randn(B, L, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).float()
+    out["llm_hidden"] = R.transformer(p, cfg, emb, batch["attention_mask"], batch["position_ids"]).numpy()
+    np.savez_compressed(os.path.join(OUT, "oracle_tiny_e2e.npz"), **out)
+
+
+if __name__ == "__main__":
+    if not X.available():
+        raise SystemExit("reference checkout not found: golden vectors can only be regenerated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    collator_vectors()
+    scheduler_vectors()
+    leaf_vectors()
+    oracle_e2e_vectors()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

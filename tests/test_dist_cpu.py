@@ -1,0 +1,48 @@
+"""world_size-2 gloo coverage of the N>1 path (replicas: unit sharding, barrier, max-over-ranks timing)."""
+import importlib
+import os
+import socket
+import time
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    D = importlib.import_module("video-gpt_amd.dist_utils")
+    r, w = D.init_from_env("gloo")
+    units = D.shard_units(7, r, w)
+    elapsed = D.timed_region(lambda: time.sleep(0.05 * (r + 1)), lambda: None)
+    total = D.sum_over_ranks(float(len(units)))
+    q.put((r, units, elapsed, total))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_replica_sharding_and_timing_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, u0, e0, t0), (r1, u1, e1, t1) = res
+    assert sorted(u0 + u1) == list(range(7)) and not set(u0) & set(u1)
+    assert t0 == t1 == 7.0                       # whole-job units = sum over ranks
+    assert abs(e0 - e1) < 1e-9 and e0 >= 0.1     # both ranks report the slowest rank's time
+
+
+def test_single_process_is_a_noop():
+    D = importlib.import_module("video-gpt_amd.dist_utils")
+    assert D.shard_units(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert D.max_over_ranks(1.5) == 1.5
