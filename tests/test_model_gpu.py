@@ -92,16 +92,17 @@ def test_seam_replace_attention_matches_fused(case):
 
 
 @pytest.mark.parametrize("prediction_type", ["x1", "v"])
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_sampler_fast_path(case, prediction_type, use_graph):
+@pytest.mark.parametrize("use_graph,pack", [(True, True), (False, True), (True, False)])
+def test_sampler_fast_path(case, prediction_type, use_graph, pack):
     cfg, p, batch, z, cond, model = case
     S = importlib.import_module("video-gpt_amd.scheduler")
     steps = 3
     sched = S.LVMScheduler(num_steps=steps, time_shifting_factor=1)
     sched.use_graph = use_graph
+    sched.pack_padding = pack
     out = sched([x.to(DEV, BF) for x in z], model.frame_block_forward_with_cfg, SC.model_kwargs(batch, cond, DEV),
                 prediction_type=prediction_type)
-    assert sched.last_engine is not None
+    assert sched.last_engine is not None and sched.last_engine.packed == pack
     ref = SC.oracle_sample(cfg, p, batch, z, cond, steps, prediction_type)
     assert SC.rel_l2(torch.cat(out), torch.cat(ref)) < TOL
 

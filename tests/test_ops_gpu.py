@@ -73,7 +73,9 @@ def test_rope(ops, hd, nh, nkv):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 576, 192), (128, 128, 64), (1, 4, 64), (258, 3072, 3072),
-                                   (1000, 192, 512), (6192, 3072, 1024)])
+                                   (1000, 192, 512), (6192, 3072, 1024),
+                                   # large grids take the 256x256-tile kernel (m tail / n tail)
+                                   (5160, 9216, 192), (4000, 2052, 64)])
 @pytest.mark.parametrize("epi", ["none", "resid", "bias"])
 def test_gemm(ops, M, N, K, epi):
     if epi != "none" and M > 1000:
@@ -113,7 +115,8 @@ def test_gemm_rejects_bad_k(ops):
 
 
 @pytest.mark.parametrize("M,I,K,act", [(300, 512, 192, "silu"), (70, 64, 64, "gelu_pytorch_tanh"),
-                                       (129, 8192, 3072, "silu"), (33, 144, 128, "gelu")])
+                                       (129, 8192, 3072, "silu"), (33, 144, 128, "gelu"),
+                                       (2100, 8192, 256, "silu"), (5160, 4112, 64, "silu")])
 def test_gated_mlp(ops, M, I, K, act):
     x = bf(torch.randn(M, K, generator=g(9)))
     w = bf(torch.randn(2 * I, K, generator=g(10)) * 0.05)

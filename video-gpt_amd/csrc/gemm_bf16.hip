@@ -21,9 +21,23 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
-constexpr int LDS_BYTES = 4 * TILE_BYTES; // {A,W} x 2 buffers = 64 KiB
+constexpr int BK = 64;
+
+// Tile configuration: BM x BN block tile, WM x WN waves, every wave owns (BM/WM) x (BN/WN).
+//   Cfg128: 128x128, 2x2 waves of 64x64   (64 KiB LDS, 2 blocks/CU)  — small problems
+//   Cfg256: 256x256, 2x4 waves of 128x64  (128 KiB LDS, 1 block/CU)  — halves the L2->LDS bytes per FLOP
+template <int BM_, int BN_, int WM_, int WN_>
+struct TileCfg {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int NWAVES = WM * WN, THREADS = NWAVES * 64;
+    static constexpr int MI = BM / WM / 16, NI = BN / WN / 16;  // 16x16 sub-tiles per wave
+    static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
+    static constexpr int LDS_BYTES = 2 * (A_BYTES + W_BYTES);
+    static constexpr int A_SLABS = BM / 8 / NWAVES, W_SLABS = BN / 8 / NWAVES;  // 8-row slabs per wave
+    static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "slabs must divide over waves");
+};
+using Cfg128 = TileCfg<128, 128, 2, 2>;
+using Cfg256 = TileCfg<256, 256, 2, 4>;
 
 enum { MODE_PLAIN = 0, MODE_GATED = 1 };
 
@@ -56,8 +70,9 @@ __device__ __forceinline__ int w_row_of_slot(int n0, int s, int I) {
     return n0 + s;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
+template <int MODE, typename C>
+__global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
+    constexpr int BM = C::BM, BN = C::BN, MI = C::MI, NI = C::NI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -78,53 +93,53 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     const int tm = first_m + (bid % in_group) % gsz;
     const int tn = (bid % in_group) / gsz;
     const int m0 = tm * BM;
-    const int n0 = tn * (MODE == MODE_GATED ? 64 : BN);
+    const int n0 = tn * (MODE == MODE_GATED ? BN / 2 : BN);
 
-    // ---- staging addresses: wave w stages slabs [4w, 4w+4) of both tiles (8 rows each) ----
+    // ---- staging addresses: wave w stages its share of 8-row slabs of both tiles ----
     const int srow = lane >> 3;            // row inside the 8-row slab
     const int schunk = (lane & 7) ^ srow;  // source 16-B chunk (XOR swizzle)
-    const bf16* a_src[4];
-    const bf16* w_src[4];
+    const bf16* a_src[C::A_SLABS];
+    const bf16* w_src[C::W_SLABS];
     const int n_rows_w = (MODE == MODE_GATED) ? 2 * g.I : g.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + srow;
+    for (int i = 0; i < C::A_SLABS; ++i) {
+        const int r = (wave * C::A_SLABS + i) * 8 + srow;
         const int am = min(m0 + r, g.M - 1);
         a_src[i] = g.A + (int64_t)am * g.lda + schunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < C::W_SLABS; ++i) {
+        const int r = (wave * C::W_SLABS + i) * 8 + srow;
         const int wr = min(w_row_of_slot<MODE>(n0, r, g.I), n_rows_w - 1);
         w_src[i] = g.W + (int64_t)wr * g.ldw + schunk * 8;
     }
-    char* sA = smem;                  // [2][TILE_BYTES]
-    char* sW = smem + 2 * TILE_BYTES; // [2][TILE_BYTES]
+    char* sA = smem;                    // [2][A_BYTES]
+    char* sW = smem + 2 * C::A_BYTES;   // [2][W_BYTES]
 
     auto stage = [&](int buf, int kt) {
         const int koff = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int slab_off = (wave * 4 + i) * 1024;
-            glds16(a_src[i] + koff, sA + buf * TILE_BYTES + slab_off);
-            glds16(w_src[i] + koff, sW + buf * TILE_BYTES + slab_off);
-        }
+        for (int i = 0; i < C::A_SLABS; ++i)
+            glds16(a_src[i] + koff, sA + buf * C::A_BYTES + (wave * C::A_SLABS + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < C::W_SLABS; ++i)
+            glds16(w_src[i] + koff, sW + buf * C::W_BYTES + (wave * C::W_SLABS + i) * 1024);
     };
 
     // ---- fragment read addresses ----
-    const int wn = wave & 1, wm = wave >> 1;
+    const int wn = wave % C::WN, wm = wave / C::WN;
     const int frow = lane & 15;  // row inside a 16-row sub-tile
     const int fk = lane >> 4;    // 16-B chunk inside a 32-wide k-step
     // byte offset of (row, chunk g) = row*128 + ((g ^ (row&7)) * 16); row&7 == frow&7 here
-    int w_off[4], a_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        w_off[i] = (wn * 64 + i * 16 + frow) * 128;
-        a_off[i] = (wm * 64 + i * 16 + frow) * 128;
-    }
+    const int w_base = (wn * (NI * 16) + frow) * 128;
+    const int a_base = (wm * (MI * 16) + frow) * 128;
     const int sw = frow & 7;
 
-    f32x4 acc[4][4];
+    f32x4 acc[NI][MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.K / BK;
     stage(0, 0);
@@ -133,21 +148,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tile kt landed for every wave; buffer buf^1 is free
         if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-        const char* bA = sA + buf * TILE_BYTES;
-        const char* bW = sW + buf * TILE_BYTES;
+        const char* bA = sA + buf * C::A_BYTES + a_base;
+        const char* bW = sW + buf * C::W_BYTES + w_base;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int coff = ((ks * 4 + fk) ^ sw) * 16;
-            bf16x8 wf[4], af[4];
+            bf16x8 wf[NI], af[MI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf[i] = *reinterpret_cast<const bf16x8*>(bW + w_off[i] + coff);
-                af[i] = *reinterpret_cast<const bf16x8*>(bA + a_off[i] + coff);
-            }
+            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(bW + i * 2048 + coff);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const bf16x8*>(bA + j * 2048 + coff);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0,
                                                                         0, 0);
         }
@@ -157,12 +171,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     const int em = lane & 15, en = (lane >> 4) * 4;
     if (MODE == MODE_PLAIN) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + em;
+        for (int j = 0; j < MI; ++j) {
+            const int m = m0 + wm * (MI * 16) + j * 16 + em;
             if (m >= g.M) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = n0 + wn * 64 + i * 16 + en;
+            for (int i = 0; i < NI; ++i) {
+                const int n = n0 + wn * (NI * 16) + i * 16 + en;
                 if (n >= g.N) continue;
                 f32x4 v = acc[i][j];
                 if (g.epi == VGPT_EPI_RESID) {
@@ -182,12 +196,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + em;
+        for (int j = 0; j < MI; ++j) {
+            const int m = m0 + wm * (MI * 16) + j * 16 + em;
             if (m >= g.M) continue;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int n = n0 + (wn * 2 + p) * 16 + en;  // output column
+            for (int p = 0; p < NI / 2; ++p) {
+                const int n = n0 + (wn * (NI / 2) + p) * 16 + en;  // output column
                 if (n >= g.I) continue;
                 const f32x4 gate = acc[2 * p][j], up = acc[2 * p + 1][j];
                 bf16x4 o;
@@ -199,22 +213,43 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
-template <int MODE>
-int launch(const GemmArgs& g, hipStream_t s, const char* name) {
+template <int MODE, typename C>
+int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE, C>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) {
             vgpt_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return VGPT_ERR_HIP;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_kernel<MODE>, dim3(g.tiles_m * g.tiles_n), dim3(256), LDS_BYTES, s,
-                       g);
+    g.tiles_m = (int)cdiv(g.M, C::BM);
+    g.tiles_n = (int)cdiv(n_out, MODE == MODE_GATED ? C::BN / 2 : C::BN);
+    hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C>), dim3(g.tiles_m * g.tiles_n), dim3(C::THREADS),
+                       C::LDS_BYTES, s, g);
     VGPT_CHECK_LAUNCH(name);
     return VGPT_OK;
+}
+
+// 0 = heuristic, 128 / 256 = forced (VGPT_GEMM_TILE, read once; for A/B measurements)
+int forced_tile() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VGPT_GEMM_TILE");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+template <int MODE>
+int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
+    const int f = forced_tile();
+    // the 256-tile pays off once the grid fills the chip (>= ~half of the 256 CUs with 256x256 tiles)
+    const int64_t big_tiles = cdiv(g.M, 256) * cdiv(n_out, MODE == MODE_GATED ? 128 : 256);
+    const bool use256 = f == 256 || (f != 128 && big_tiles >= 128);
+    return use256 ? launch_cfg<MODE, Cfg256>(g, n_out, s, name) : launch_cfg<MODE, Cfg128>(g, n_out, s, name);
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -245,8 +280,8 @@ VGPT_EXPORT int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
     g.epi = epilogue; g.act = VGPT_ACT_NONE; g.I = 0;
-    g.tiles_m = (int)cdiv(M, BM); g.tiles_n = (int)cdiv(N, BN);
-    return launch<MODE_PLAIN>(g, (hipStream_t)stream, "vgpt_gemm_bf16");
+    g.tiles_m = g.tiles_n = 0;
+    return launch<MODE_PLAIN>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16");
 }
 
 VGPT_EXPORT int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, void* out, int64_t M,
@@ -271,6 +306,6 @@ VGPT_EXPORT int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, voi
     g.M = (int)M; g.N = (int)I; g.K = (int)K;
     g.lda = lda; g.ldw = ldw; g.ldc = ldo; g.ldr = 0;
     g.epi = VGPT_EPI_NONE; g.act = act; g.I = (int)I;
-    g.tiles_m = (int)cdiv(M, BM); g.tiles_n = (int)cdiv(I, 64);
-    return launch<MODE_GATED>(g, (hipStream_t)stream, "vgpt_gated_mlp_act_fwd");
+    g.tiles_m = g.tiles_n = 0;
+    return launch<MODE_GATED>(g, I, (hipStream_t)stream, "vgpt_gated_mlp_act_fwd");
 }

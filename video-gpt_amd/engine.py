@@ -21,18 +21,50 @@ from . import ops
 from .ops import BF16, VgptError
 
 
-def _rows(sizes: Dict[int, list], L: int, span: bool):
+def _rows(sizes: Dict[int, list], row_of, span: bool):
     out = []
     for b in sizes.keys():
         for item in sizes[b]:
-            out.append(b * L + (item[0] if span else item))
+            out.append(row_of(b, item[0] if span else item))
     return out
+
+
+def count_left_pads(attention_mask) -> List[int]:
+    """Left-pad length of every row, read off the mask itself: pad rows are the leading all-ones rows
+    (LVM/processor.py:726-727); a real first token only sees itself."""
+    B, L, _ = attention_mask.shape
+    if L <= 1:
+        return [0] * B
+    lead = torch.cumprod(attention_mask.to(torch.bool).all(-1).to(torch.int64), dim=1).sum(1)
+    return [int(v) for v in lead.tolist()]
+
+
+def pack_left_padded(input_ids, position_ids, attention_mask, pads: List[int]):
+    """Drop the left-pad tokens of every batch row and lay the real tokens of all rows out as ONE
+    sequence with a block-diagonal mask (row b's real-token sub-mask on the diagonal, everything
+    between different rows masked).  Pad rows never influence real rows (pad columns are masked,
+    LVM/processor.py:722-727) and the model only reads real positions, so the outputs are unchanged;
+    the attention kernel skips the off-diagonal tiles through its tile summary.
+    Returns (ids (1,M), positions (1,M), mask (1,M,M) bool, offsets, pads)."""
+    B, L = input_ids.shape
+    lens = [L - p for p in pads]
+    offsets = [0]
+    for n in lens[:-1]:
+        offsets.append(offsets[-1] + n)
+    M = sum(lens)
+    ids = torch.cat([input_ids[b, pads[b]:] for b in range(B)]).view(1, M)
+    pos = torch.cat([position_ids[b, pads[b]:] for b in range(B)]).view(1, M)
+    mask = torch.zeros(1, M, M, dtype=torch.bool, device=attention_mask.device)
+    for b in range(B):
+        o, n, p = offsets[b], lens[b], pads[b]
+        mask[0, o:o + n, o:o + n] = attention_mask[b, p:, p:].to(torch.bool)
+    return ids.contiguous(), pos.contiguous(), mask, offsets
 
 
 class StaticDenoiser:
     def __init__(self, model, input_ids, position_ids, attention_mask, input_img_latents, input_image_sizes,
                  denoise_image_sizes, time_emb_inx, n_frames: int, latent_hw, use_img_cfg: bool, img_cfg_scale: float,
-                 prediction_type: str = "v", sigma: Optional[torch.Tensor] = None):
+                 prediction_type: str = "v", sigma: Optional[torch.Tensor] = None, pack_padding: bool = True):
         model._check_ready()
         self.model = model
         cfg = model.llm.config
@@ -40,6 +72,14 @@ class StaticDenoiser:
         dev = input_ids.device
         self.dev = dev
         B, L = input_ids.shape
+        row_of = lambda b, s: b * L + s
+        self.packed = False
+        pads = count_left_pads(attention_mask) if pack_padding and not isinstance(attention_mask, ops.PackedMask) else []
+        if any(pads):
+            input_ids, position_ids, attention_mask, offs = pack_left_padded(input_ids, position_ids, attention_mask, pads)
+            row_of = lambda b, s: offs[b] + s - pads[b]
+            B, L = input_ids.shape
+            self.packed = True
         H, I = cfg.hidden_size, cfg.intermediate_size
         self.B, self.L, self.H = B, L, H
         self.nf = n_frames
@@ -64,12 +104,12 @@ class StaticDenoiser:
             if len(shapes) != 1:
                 raise VgptError("StaticDenoiser needs condition frames of one resolution")
             self.cond = torch.cat([t.to(BF16) for t in input_img_latents], dim=0).contiguous()
-            rows = _rows(input_image_sizes, L, True)
+            rows = _rows(input_image_sizes, row_of, True)
             if len(rows) != self.cond.shape[0]:
                 raise AssertionError("input_image_sizes and input_img_latents disagree")
             self.cond_rows = i32(rows)
-        x_rows = _rows(denoise_image_sizes, L, True)
-        t_rows = _rows(time_emb_inx, L, False)
+        x_rows = _rows(denoise_image_sizes, row_of, True)
+        t_rows = _rows(time_emb_inx, row_of, False)
         if len(x_rows) != n_frames or len(t_rows) != n_frames:
             raise AssertionError("denoise_image_sizes / time_emb_inx disagree with the number of latents")
         self.x_rows, self.t_rows = i32(x_rows), i32(t_rows)

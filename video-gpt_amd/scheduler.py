@@ -31,6 +31,7 @@ class LVMScheduler:
         t = torch.linspace(0 if begin_time is None else begin_time, 1, num_steps + 1)
         self.sigma = t / (t + time_shifting_factor - time_shifting_factor * t)
         self.use_graph = True
+        self.pack_padding = True
         self.last_engine = None
 
     # ---- fast path ----
@@ -53,7 +54,7 @@ class LVMScheduler:
                               model_kwargs["attention_mask"], lat, model_kwargs["input_image_sizes"],
                               model_kwargs["denoise_image_sizes"], model_kwargs["time_emb_inx"], len(z),
                               tuple(z[0].shape[-2:]), model_kwargs["use_img_cfg"], model_kwargs["img_cfg_scale"],
-                              prediction_type, sigma=self.sigma)
+                              prediction_type, sigma=self.sigma, pack_padding=self.pack_padding)
 
     def __call__(self, z, func, model_kwargs, use_kv_cache: bool = True, offload_kv_cache: bool = True,
                  prediction_type: str = "v", vae=None, noise_level=None):
