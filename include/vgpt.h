@@ -172,6 +172,40 @@ int vgpt_sampler_advance(int32_t* step, void* stream);
 /* z_model = bf16(z) */
 int vgpt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 
+/* ---- VAE conv stack (diffusers==0.29.0 AutoencoderKL, sdxl-vae layout; fp32 like the reference:
+ *      LVM/pipeline.py:110-117 encode, :558-590 decode, LVM/train/train_x1_stage1_noiseinput.py:190) ---- */
+
+/* GroupNorm statistics: stats[(n*groups+g)*2 + {0,1}] = {mean, rsqrt(var+eps)} over (C/groups, HW).
+ * x: (N, C, HW) fp32. */
+int vgpt_groupnorm_stats(const float* x, float* stats, int64_t N, int C, int HW, int groups, float eps,
+                         void* stream);
+
+/* Implicit-GEMM convolution on the fp32 MFMA, NCHW fp32:
+ *   y = conv(f(x), w) + bias + resid,  f = optional nearest-x2 upsample, then optional
+ *   GroupNorm(gn_stats, gamma, beta)[+SiLU] applied on load (zero padding applied after f).
+ * ksize 3 (stride 1 pad 1 | stride 2 with Downsample2D's (0,1,0,1) pad) or 1.  w: (Cout, Cin*k*k) with row
+ * stride ldw, or stored transposed (Cin*k*k, Cout) when w_transposed; w_batch_stride != 0 selects a
+ * per-image weight matrix (attention products).  bias/resid/gn_* may be NULL (gn_groups = 0). */
+int vgpt_conv2d_fwd(const float* x, const float* w, const float* bias, const float* resid,
+                    const float* gn_stats, const float* gn_gamma, const float* gn_beta, float* y, int N,
+                    int Cin, int Hin, int Win, int Cout, int ksize, int stride, int upsample, int gn_groups,
+                    int gn_silu, int w_transposed, int64_t ldw, int64_t w_batch_stride, void* stream);
+
+/* In-place softmax over the KEY axis of S^T (N, keys, queries) with pre-scale (mid-block attention). */
+int vgpt_col_softmax(float* s, int N, int keys, int queries, float scale, void* stream);
+
+/* DiagonalGaussianDistribution.sample + latent scaling (LVM/pipeline.py:110-115):
+ * z = (mean + exp(0.5*clamp(logvar,-30,20)) * noise - shift) * scaling.
+ * moments: (N, 2*per_image) = [mean | logvar] per image; noise, z: (N, per_image). */
+int vgpt_vae_sample(const float* moments, const float* noise, float* z, int N, int64_t per_image, float shift,
+                    float scaling, void* stream);
+
+/* (x*0.5+0.5).clamp(0,1)*255 -> uint8, NCHW -> NHWC (LVM/pipeline.py:585-588). */
+int vgpt_vae_postprocess_u8(const float* x, uint8_t* out, int N, int C, int H, int W, void* stream);
+
+/* y = float(x) * mul + add (latent / scaling_factor + shift before decode, LVM/pipeline.py:573-577). */
+int vgpt_affine_to_f32(const void* x, int x_is_bf16, float* y, int64_t n, float mul, float add, void* stream);
+
 /* ---- hipGraph helpers (sampler loop under graph capture) ----------------- */
 int vgpt_graph_begin_capture(void* stream);
 int vgpt_graph_end_capture(void* stream, void** graph_exec_out);

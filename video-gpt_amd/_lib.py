@@ -48,6 +48,12 @@ SIGNATURES = {
     "vgpt_euler_cfg_update": (c_int, [_P, _P, _P, _P, _P, c_int, _I64, c_int, c_int, c_float, _P]),
     "vgpt_sampler_advance": (c_int, [_P, _P]),
     "vgpt_cast_f32_to_bf16": (c_int, [_P, _P, _I64, _P]),
+    "vgpt_groupnorm_stats": (c_int, [_P, _P, _I64, c_int, c_int, c_int, c_float, _P]),
+    "vgpt_conv2d_fwd": (c_int, [_P] * 8 + [c_int] * 11 + [_I64, _I64, _P]),
+    "vgpt_col_softmax": (c_int, [_P, c_int, c_int, c_int, c_float, _P]),
+    "vgpt_vae_sample": (c_int, [_P, _P, _P, c_int, _I64, c_float, c_float, _P]),
+    "vgpt_vae_postprocess_u8": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vgpt_affine_to_f32": (c_int, [_P, c_int, _P, _I64, c_float, c_float, _P]),
     "vgpt_graph_begin_capture": (c_int, [_P]),
     "vgpt_graph_end_capture": (c_int, [_P, POINTER(c_void_p)]),
     "vgpt_graph_launch": (c_int, [_P, _P]),

@@ -1,0 +1,338 @@
+// VAE encode/decode conv stack (diffusers==0.29.0 AutoencoderKL / sdxl-vae architecture; reference
+// call sites LVM/pipeline.py:110-117,558-590, LVM/utils.py:99-137) in fp32, as the reference runs it.
+//
+// One implicit-GEMM convolution kernel covers every Conv2d / Linear of the VAE:
+//   y[n][co][oy][ox] = bias[co] + resid + sum_{ci,dy,dx} w[co][ci][dy][dx] * f(x)[n][ci][iy][ix]
+//   - 3x3 stride 1 pad 1, 3x3 stride 2 with the (0,1,0,1) zero pad of Downsample2D, 1x1;
+//   - optional nearest x2 upsample folded into the loader (Upsample2D never materialised);
+//   - optional GroupNorm(+SiLU) prologue applied while the input patch is staged into LDS
+//     (stats from vgpt_groupnorm_stats), so the normalised tensor never goes to HBM;
+//   - bias + residual epilogue (resnet skip, attention residual);
+//   - "weights" may be an activation tensor (per-image batch stride, optionally stored [k][co]):
+//     the mid-block attention's Q K^T and P V products run through the same kernel.
+// Math: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, 157 TF/s peak) — 64 output channels x 128
+// pixels per 4-wave block, K chunked by 8 input channels (3x3) or 64 (1x1), operands staged in LDS.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* x; const float* w; const float* bias; const float* resid;
+    const float* gn_stats; const float* gn_gamma; const float* gn_beta;
+    float* y;
+    int N, Cin, Hin, Win, Cout, Hout, Wout;
+    int upsample, gn_groups, gn_silu, w_transposed;
+    int64_t ldw, w_batch_stride;
+    int tiles_x, tiles_y, tiles_co;
+};
+
+constexpr int TCO = 64, TH = 4, TW = 32;  // block tile: 64 output channels x (4 x 32) pixels
+
+template <int KS, int STRIDE>
+struct ConvCfg {
+    static constexpr int CK = (KS == 3) ? 8 : 64;        // input channels per K chunk
+    static constexpr int KC = CK * KS * KS;              // K per chunk (72 / 64)
+    static constexpr int KPAD = KC + 1;                  // weight row stride in LDS (bank spread)
+    static constexpr int PH = (TH - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
+    static constexpr int W_FLOATS = TCO * KPAD, P_FLOATS = CK * PH * PW;
+    static constexpr int LDS_BYTES = (W_FLOATS + P_FLOATS) * 4;
+};
+
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+    using C = ConvCfg<KS, STRIDE>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sW = reinterpret_cast<float*>(smem);
+    float* sP = sW + C::W_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    const int tco = bid % a.tiles_co;
+    const int n = bid / a.tiles_co;
+    const int co0 = tco * TCO, oy0 = ty * TH, ox0 = tx * TW;
+    constexpr int PAD = (KS == 3 && STRIDE == 1) ? 1 : 0;
+    const int Hv = a.Hin << a.upsample, Wv = a.Win << a.upsample;
+    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+    const float* xn = a.x + (int64_t)n * a.Cin * a.Hin * a.Win;
+    const float* wn = a.w + (int64_t)n * a.w_batch_stride;
+    const int cpg = a.gn_groups ? a.Cin / a.gn_groups : 1;
+
+    // wave -> output row `wave` of the tile; 4 co sub-tiles x 2 pixel sub-tiles of 16x16
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int kq = lane >> 4, l16 = lane & 15;
+    // per k-step patch offset of this lane's k (k = s*4 + kq -> ci_local, dy, dx)
+    int koff[C::KC / 4];
+#pragma unroll
+    for (int s = 0; s < C::KC / 4; ++s) {
+        const int kk = s * 4 + kq;
+        const int cl = kk / (KS * KS), tap = kk % (KS * KS);
+        koff[s] = cl * (C::PH * C::PW) + (tap / KS) * C::PW + (tap % KS);
+    }
+    const int prow = wave * STRIDE * C::PW;  // patch row of this wave's output row
+
+    for (int c0 = 0; c0 < a.Cin; c0 += C::CK) {
+        __syncthreads();
+        // ---- stage weights: sW[co][k], k = ci_local*KS*KS + tap ----
+        for (int i = tid; i < TCO * C::KC; i += 256) {
+            int co, k;
+            if (a.w_transposed) { k = i / TCO; co = i % TCO; } else { co = i / C::KC; k = i % C::KC; }
+            const int ci = c0 + k / (KS * KS);
+            float v = 0.f;
+            if (co0 + co < a.Cout && ci < a.Cin) {
+                const int64_t kg = (int64_t)c0 * (KS * KS) + k;
+                v = a.w_transposed ? wn[kg * a.ldw + co0 + co] : wn[(int64_t)(co0 + co) * a.ldw + kg];
+            }
+            sW[co * C::KPAD + k] = v;
+        }
+        // ---- stage input patch with optional upsample / GroupNorm(+SiLU) ----
+        for (int i = tid; i < C::P_FLOATS; i += 256) {
+            const int cl = i / (C::PH * C::PW), r = i % (C::PH * C::PW);
+            const int py = r / C::PW, px = r % C::PW;
+            const int ci = c0 + cl, iy = iy0 + py, ix = ix0 + px;
+            float v = 0.f;
+            if (ci < a.Cin && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+                v = xn[((int64_t)ci * a.Hin + (iy >> a.upsample)) * a.Win + (ix >> a.upsample)];
+                if (a.gn_groups) {
+                    const float* st = a.gn_stats + ((int64_t)n * a.gn_groups + ci / cpg) * 2;
+                    v = (v - st[0]) * st[1] * a.gn_gamma[ci] + a.gn_beta[ci];
+                    if (a.gn_silu) v = v / (1.0f + expf(-v));
+                }
+            }
+            sP[i] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < C::KC / 4; ++s) {
+            float wf[4], pf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = sW[(i * 16 + l16) * C::KPAD + s * 4 + kq];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pf[j] = sP[koff[s] + prow + (j * 16 + l16) * STRIDE];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i], pf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds pixel l16 of sub-tile j, channels (kq*4 + r) of sub-tile i ----
+    const int oy = oy0 + wave;
+    if (oy < a.Hout) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ox = ox0 + j * 16 + l16;
+            if (ox >= a.Wout) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + i * 16 + kq * 4 + r;
+                    if (co >= a.Cout) continue;
+                    const int64_t o = (((int64_t)n * a.Cout + co) * a.Hout + oy) * a.Wout + ox;
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[co];
+                    if (a.resid) v += a.resid[o];
+                    a.y[o] = v;
+                }
+        }
+    }
+}
+
+// ---- GroupNorm statistics: one block per (n, group), two passes (mean, then centred variance) ----
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                       int64_t group_elems, float eps) {
+    __shared__ float red[4];
+    const float* p = x + (int64_t)blockIdx.x * group_elems;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < group_elems; i += 256) s += p[i];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)group_elems;
+    __syncthreads();
+    float v = 0.f;
+    for (int64_t i = threadIdx.x; i < group_elems; i += 256) {
+        const float d = p[i] - mean;
+        v += d * d;
+    }
+    v = wave_sum(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float var = (red[0] + red[1] + red[2] + red[3]) / (float)group_elems;
+        stats[blockIdx.x * 2] = mean;
+        stats[blockIdx.x * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
+// ---- column softmax of S^T (n, keys, queries): softmax over keys for every query column, in place ----
+__global__ __launch_bounds__(256) void col_softmax_kernel(float* __restrict__ s, int keys, int queries, float scale) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= queries) return;
+    float* p = s + (int64_t)blockIdx.y * keys * queries + q;
+    float m = -INFINITY, l = 0.f;
+    for (int k = 0; k < keys; ++k) {
+        const float v = p[(int64_t)k * queries] * scale;
+        const float mn = fmaxf(m, v);
+        l = l * expf(m - mn) + expf(v - mn);
+        m = mn;
+    }
+    const float inv = 1.0f / l;
+    for (int k = 0; k < keys; ++k) {
+        float* e = p + (int64_t)k * queries;
+        *e = expf(*e * scale - m) * inv;
+    }
+}
+
+// ---- latent sampling: z = (mean + exp(0.5 clamp(logvar,-30,20)) * noise - shift) * scaling ----
+__global__ void vae_sample_kernel(const float* __restrict__ moments, const float* __restrict__ noise,
+                                  float* __restrict__ z, int64_t per_image, int64_t total, float shift,
+                                  float scaling) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t n = i / per_image, r = i % per_image;
+    const float mean = moments[n * 2 * per_image + r];
+    float lv = moments[n * 2 * per_image + per_image + r];
+    lv = fminf(fmaxf(lv, -30.0f), 20.0f);
+    z[i] = (mean + expf(0.5f * lv) * noise[i] - shift) * scaling;
+}
+
+// ---- (x*0.5+0.5).clamp(0,1)*255 -> uint8, NCHW -> NHWC (LVM/pipeline.py:585-588) ----
+__global__ void vae_post_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int N, int C, int H,
+                                   int W) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)N * C * H * W;
+    if (i >= total) return;
+    const int c = i % C;
+    const int64_t r = i / C;
+    const int xw = r % W;
+    const int64_t r2 = r / W;
+    const int yh = r2 % H;
+    const int n = r2 / H;
+    float v = x[(((int64_t)n * C + c) * H + yh) * W + xw] * 0.5f + 0.5f;
+    v = fminf(fmaxf(v, 0.f), 1.f) * 255.0f;
+    out[i] = (uint8_t)v;  // truncation, as torch's .to(uint8)
+}
+
+// ---- scale / unscale helpers: y = x * mul + add (latent / scaling_factor + shift) ----
+__global__ void affine_kernel(const void* __restrict__ x, int x_is_bf16, float* __restrict__ y, int64_t n, float mul,
+                              float add) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x_is_bf16 ? bf2f(reinterpret_cast<const bf16*>(x)[i]) : reinterpret_cast<const float*>(x)[i];
+    y[i] = v * mul + add;
+}
+
+template <int KS, int STRIDE>
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+    using C = ConvCfg<KS, STRIDE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_kernel<KS, STRIDE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) {
+            vgpt_set_error("vgpt_conv2d_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return VGPT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const int64_t blocks = (int64_t)a.tiles_x * a.tiles_y * a.tiles_co * a.N;
+    hipLaunchKernelGGL((conv_kernel<KS, STRIDE>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, s, a);
+    VGPT_CHECK_LAUNCH("vgpt_conv2d_fwd");
+    return VGPT_OK;
+}
+
+}  // namespace
+
+VGPT_EXPORT int vgpt_groupnorm_stats(const float* x, float* stats, int64_t N, int C, int HW, int groups, float eps,
+                                     void* stream) {
+    VGPT_REQUIRE(x && stats, VGPT_ERR_INVALID, "vgpt_groupnorm_stats: null pointer");
+    VGPT_REQUIRE(N >= 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, VGPT_ERR_INVALID,
+                 "vgpt_groupnorm_stats: bad shape");
+    if (N == 0) return VGPT_OK;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)(N * groups)), dim3(256), 0, (hipStream_t)stream, x, stats,
+                       (int64_t)(C / groups) * HW, eps);
+    VGPT_CHECK_LAUNCH("vgpt_groupnorm_stats");
+    return VGPT_OK;
+}
+
+VGPT_EXPORT int vgpt_conv2d_fwd(const float* x, const float* w, const float* bias, const float* resid,
+                                const float* gn_stats, const float* gn_gamma, const float* gn_beta, float* y, int N,
+                                int Cin, int Hin, int Win, int Cout, int ksize, int stride, int upsample,
+                                int gn_groups, int gn_silu, int w_transposed, int64_t ldw, int64_t w_batch_stride,
+                                void* stream) {
+    VGPT_REQUIRE(x && w && y, VGPT_ERR_INVALID, "vgpt_conv2d_fwd: null pointer");
+    VGPT_REQUIRE(N >= 0 && Cin > 0 && Hin > 0 && Win > 0 && Cout > 0, VGPT_ERR_INVALID, "vgpt_conv2d_fwd: bad shape");
+    VGPT_REQUIRE((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1), VGPT_ERR_UNSUPPORTED,
+                 "vgpt_conv2d_fwd: only 3x3 (stride 1, 2) and 1x1 convolutions");
+    VGPT_REQUIRE(!(upsample && stride != 1), VGPT_ERR_UNSUPPORTED, "vgpt_conv2d_fwd: upsample needs stride 1");
+    VGPT_REQUIRE(gn_groups == 0 || (gn_stats && gn_gamma && gn_beta && Cin % gn_groups == 0), VGPT_ERR_INVALID,
+                 "vgpt_conv2d_fwd: GroupNorm prologue needs stats/gamma/beta and Cin %% groups == 0");
+    if (N == 0) return VGPT_OK;
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.resid = resid; a.gn_stats = gn_stats; a.gn_gamma = gn_gamma; a.gn_beta = gn_beta;
+    a.y = y; a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout;
+    const int Hv = Hin << (upsample ? 1 : 0), Wv = Win << (upsample ? 1 : 0);
+    a.Hout = stride == 2 ? Hv / 2 : Hv;
+    a.Wout = stride == 2 ? Wv / 2 : Wv;
+    a.upsample = upsample ? 1 : 0; a.gn_groups = gn_groups; a.gn_silu = gn_silu; a.w_transposed = w_transposed;
+    a.ldw = ldw; a.w_batch_stride = w_batch_stride;
+    a.tiles_x = (int)cdiv(a.Wout, TW); a.tiles_y = (int)cdiv(a.Hout, TH); a.tiles_co = (int)cdiv(Cout, TCO);
+    hipStream_t s = (hipStream_t)stream;
+    if (ksize == 1) return launch_conv<1, 1>(a, s);
+    if (stride == 1) return launch_conv<3, 1>(a, s);
+    return launch_conv<3, 2>(a, s);
+}
+
+VGPT_EXPORT int vgpt_col_softmax(float* s, int N, int keys, int queries, float scale, void* stream) {
+    VGPT_REQUIRE(s, VGPT_ERR_INVALID, "vgpt_col_softmax: null pointer");
+    VGPT_REQUIRE(N >= 0 && keys > 0 && queries > 0, VGPT_ERR_INVALID, "vgpt_col_softmax: bad shape");
+    if (N == 0) return VGPT_OK;
+    hipLaunchKernelGGL(col_softmax_kernel, dim3((unsigned)cdiv(queries, 256), N), dim3(256), 0, (hipStream_t)stream, s,
+                       keys, queries, scale);
+    VGPT_CHECK_LAUNCH("vgpt_col_softmax");
+    return VGPT_OK;
+}
+
+VGPT_EXPORT int vgpt_vae_sample(const float* moments, const float* noise, float* z, int N, int64_t per_image,
+                                float shift, float scaling, void* stream) {
+    VGPT_REQUIRE(moments && noise && z, VGPT_ERR_INVALID, "vgpt_vae_sample: null pointer");
+    VGPT_REQUIRE(N >= 0 && per_image > 0, VGPT_ERR_INVALID, "vgpt_vae_sample: bad shape");
+    if (N == 0) return VGPT_OK;
+    const int64_t total = (int64_t)N * per_image;
+    hipLaunchKernelGGL(vae_sample_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, moments,
+                       noise, z, per_image, total, shift, scaling);
+    VGPT_CHECK_LAUNCH("vgpt_vae_sample");
+    return VGPT_OK;
+}
+
+VGPT_EXPORT int vgpt_vae_postprocess_u8(const float* x, uint8_t* out, int N, int C, int H, int W, void* stream) {
+    VGPT_REQUIRE(x && out, VGPT_ERR_INVALID, "vgpt_vae_postprocess_u8: null pointer");
+    VGPT_REQUIRE(N >= 0 && C > 0 && H > 0 && W > 0, VGPT_ERR_INVALID, "vgpt_vae_postprocess_u8: bad shape");
+    if (N == 0) return VGPT_OK;
+    const int64_t total = (int64_t)N * C * H * W;
+    hipLaunchKernelGGL(vae_post_u8_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out,
+                       N, C, H, W);
+    VGPT_CHECK_LAUNCH("vgpt_vae_postprocess_u8");
+    return VGPT_OK;
+}
+
+VGPT_EXPORT int vgpt_affine_to_f32(const void* x, int x_is_bf16, float* y, int64_t n, float mul, float add,
+                                   void* stream) {
+    VGPT_REQUIRE(x && y, VGPT_ERR_INVALID, "vgpt_affine_to_f32: null pointer");
+    VGPT_REQUIRE(n >= 0, VGPT_ERR_INVALID, "vgpt_affine_to_f32: bad shape");
+    if (n == 0) return VGPT_OK;
+    hipLaunchKernelGGL(affine_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x_is_bf16, y,
+                       n, mul, add);
+    VGPT_CHECK_LAUNCH("vgpt_affine_to_f32");
+    return VGPT_OK;
+}

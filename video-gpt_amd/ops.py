@@ -364,3 +364,91 @@ class HipGraph:
             except Exception:
                 pass
             self._exec = None
+
+
+# ---- VAE (fp32, NCHW) -------------------------------------------------------------------------
+
+F32 = torch.float32
+
+
+def groupnorm_stats(x: torch.Tensor, groups: int, eps: float) -> torch.Tensor:
+    _chk(x, F32, "groupnorm_stats.x")
+    N, C = x.shape[:2]
+    HW = x.numel() // max(N * C, 1)
+    stats = torch.empty(N, groups, 2, dtype=F32, device=x.device)
+    call("vgpt_groupnorm_stats", x.data_ptr(), stats.data_ptr(), N, C, HW, groups, float(eps), _stream())
+    return stats
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           resid: Optional[torch.Tensor] = None, gn=None, ksize: int = 3, stride: int = 1, upsample: bool = False,
+           cout: Optional[int] = None, w_transposed: bool = False, ldw: Optional[int] = None,
+           w_batch_stride: int = 0, out: Optional[torch.Tensor] = None):
+    """y = conv(f(x), weight) + bias + resid on the fp32-MFMA implicit GEMM (see include/vgpt.h).
+    gn = (stats, gamma, beta, groups, silu) fuses GroupNorm(+SiLU) into the input load."""
+    _chk(x, F32, "conv2d.x"); _chk(weight, F32, "conv2d.weight")
+    N, Cin, Hin, Win = x.shape
+    if cout is None:
+        cout = weight.shape[0]
+    if ldw is None:
+        ldw = Cin * ksize * ksize
+    Hv, Wv = (Hin * 2, Win * 2) if upsample else (Hin, Win)
+    Ho, Wo = (Hv // 2, Wv // 2) if stride == 2 else (Hv, Wv)
+    if out is None:
+        out = torch.empty(N, cout, Ho, Wo, dtype=F32, device=x.device)
+    else:
+        _chk(out, F32, "conv2d.out")
+    if resid is not None:
+        _chk(resid, F32, "conv2d.resid")
+        if resid.numel() != out.numel():
+            raise VgptError("conv2d: residual shape mismatch")
+    if bias is not None:
+        _chk(bias, F32, "conv2d.bias")
+    stats = gamma = beta = None
+    groups = silu = 0
+    if gn is not None:
+        stats, gamma, beta, groups, silu = gn
+        _chk(stats, F32, "conv2d.gn_stats"); _chk(gamma, F32, "conv2d.gn_gamma"); _chk(beta, F32, "conv2d.gn_beta")
+    call("vgpt_conv2d_fwd", x.data_ptr(), weight.data_ptr(), _ptr(bias), _ptr(resid), _ptr(stats), _ptr(gamma),
+         _ptr(beta), out.data_ptr(), N, Cin, Hin, Win, cout, ksize, stride, int(upsample), int(groups), int(silu),
+         int(w_transposed), int(ldw), int(w_batch_stride), _stream())
+    return out
+
+
+def col_softmax(s: torch.Tensor, scale: float):
+    _chk(s, F32, "col_softmax.s")
+    N, keys, queries = s.shape
+    call("vgpt_col_softmax", s.data_ptr(), N, keys, queries, float(scale), _stream())
+    return s
+
+
+def vae_sample(moments: torch.Tensor, noise: torch.Tensor, shift: float, scaling: float):
+    _chk(moments, F32, "vae_sample.moments"); _chk(noise, F32, "vae_sample.noise")
+    N = moments.shape[0]
+    per = moments.numel() // max(2 * N, 1)
+    if noise.numel() != N * per:
+        raise VgptError("vae_sample: noise shape mismatch")
+    z = torch.empty_like(noise)
+    call("vgpt_vae_sample", moments.data_ptr(), noise.data_ptr(), z.data_ptr(), N, per, float(shift), float(scaling),
+         _stream())
+    return z
+
+
+def vae_postprocess_u8(x: torch.Tensor):
+    _chk(x, F32, "vae_postprocess_u8.x")
+    N, C, H, W = x.shape
+    out = torch.empty(N, H, W, C, dtype=torch.uint8, device=x.device)
+    call("vgpt_vae_postprocess_u8", x.data_ptr(), out.data_ptr(), N, C, H, W, _stream())
+    return out
+
+
+def affine_to_f32(x: torch.Tensor, mul: float, add: float = 0.0):
+    if x.dtype not in (F32, BF16):
+        raise VgptError("affine_to_f32: expected fp32 or bf16 input")
+    x = x.contiguous()
+    if not x.is_cuda:
+        raise VgptError("affine_to_f32: expected a GPU tensor")
+    y = torch.empty(x.shape, dtype=F32, device=x.device)
+    call("vgpt_affine_to_f32", x.data_ptr(), int(x.dtype == BF16), y.data_ptr(), x.numel(), float(mul), float(add),
+         _stream())
+    return y
