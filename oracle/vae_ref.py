@@ -33,6 +33,7 @@ class VaeCfg:
 
 
 TINY_VAE = VaeCfg(block_out_channels=(32, 64), layers_per_block=1, norm_num_groups=8)
+TINY_VAE8 = VaeCfg(block_out_channels=(16, 32, 32, 32), layers_per_block=1, norm_num_groups=8)  # /8 like sdxl-vae
 
 
 def resnet(p, pre, x, groups, eps):

@@ -307,12 +307,42 @@ class LVMProcessor:
                 tok = None
         return cls(tok, sequence_parallel_size=sequence_parallel_size)
 
+    def crop_arr(self, pil_image):
+        """LVM/processor.py:39-64: shrink to max_image_size, enlarge to >= 16, centre-crop to multiples of 16."""
+        from PIL import Image
+        while min(*pil_image.size) >= 2 * self.max_image_size:
+            pil_image = pil_image.resize(tuple(x // 2 for x in pil_image.size), resample=Image.BOX)
+        if max(*pil_image.size) > self.max_image_size:
+            scale = self.max_image_size / max(*pil_image.size)
+            pil_image = pil_image.resize(tuple(round(x * scale) for x in pil_image.size), resample=Image.BICUBIC)
+        if min(*pil_image.size) < 16:
+            scale = 16 / min(*pil_image.size)
+            pil_image = pil_image.resize(tuple(round(x * scale) for x in pil_image.size), resample=Image.BICUBIC)
+        arr = np.array(pil_image)
+        y1, x1 = (arr.shape[0] % 16) // 2, (arr.shape[1] % 16) // 2
+        y2, x2 = arr.shape[0] % 16 - y1, arr.shape[1] % 16 - x1
+        return arr[y1:arr.shape[0] - y2, x1:arr.shape[1] - x2]
+
     def process_image(self, image):
-        if not torch.is_tensor(image) or image.dim() != 3:
-            raise ValueError("Input must be a (3, H, W) tensor normalised to [-1, 1]")
-        if image.shape[-1] % 16 or image.shape[-2] % 16:
-            raise ValueError("image sides must be multiples of 16")
-        return image
+        """PIL image / path -> (3, H, W) float tensor in [-1, 1] (ToTensor + Normalize(0.5, 0.5),
+        LVM/processor.py:31-35,78-86); tensors already in that form pass through."""
+        if torch.is_tensor(image):
+            if image.dtype == torch.uint8 and image.dim() == 3 and image.shape[-1] == 3:  # (H, W, 3) uint8 frame
+                image = (image.permute(2, 0, 1).float().div(255.0) - 0.5) / 0.5
+            if image.dim() != 3 or image.shape[-1] % 16 or image.shape[-2] % 16:
+                raise ValueError("tensor images must be (3, H, W) with sides that are multiples of 16")
+            return image
+        try:
+            from PIL import Image
+        except ImportError as e:  # pragma: no cover
+            raise ValueError("Input must be a PIL.Image object") from e
+        if isinstance(image, str):
+            image = Image.open(image).convert("RGB")
+        elif not isinstance(image, Image.Image):
+            raise ValueError("Input must be a PIL.Image object")
+        arr = self.crop_arr(image)
+        t = torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1).float().div(255.0)
+        return (t - 0.5) / 0.5
 
     def _chunks(self, text: str):
         chunks = [list(self.text_tokenizer(c).input_ids) for c in self._TAG.split(text)]
