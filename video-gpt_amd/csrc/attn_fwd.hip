@@ -36,7 +36,12 @@ struct AttnArgs {
 
 template <int D>
 struct Cfg {
-    static constexpr int KROW = D * 2 + 16;  // bytes
+    // D == 96: K/V tiles are contiguous [key][192 B] images filled by LDS-DMA (global_load_lds); the K
+    // image is XOR-swizzled (chunk ^= (key>>2)&3, applied on the DMA source address and on the read) so the
+    // ds_read_b128 groups are conflict-free without padding.  Other head dims stage through registers
+    // into a padded K image.
+    static constexpr bool GLDS = (D == 96);
+    static constexpr int KROW = GLDS ? D * 2 : D * 2 + 16;  // bytes
     // [key][d] image for transposed reads: (row stride in dwords) % 64 must be 16 or 48
     static constexpr int VROW_TR = (D == 96) ? 192 : (D == 128 ? 320 : 192);
     static constexpr int VROW_T = 64 * 2 + 8;  // [d][key] image of the slow variant
@@ -95,7 +100,36 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     float m_i = -INFINITY, l_i = 0.f;
 
     // ---- staging helpers ----
-    bf16x8 kreg[C::LOADS], vreg[C::LOADS];
+    constexpr bool GLDS = TR && C::GLDS;
+    constexpr int PIECES = (64 * D * 2) / 1024 / 4;  // 1-KiB LDS-DMA pieces per wave per operand
+    // per-lane (key, source chunk) of each DMA piece this wave issues
+    int g_key[GLDS ? PIECES : 1], g_kchunk[GLDS ? PIECES : 1], g_vchunk[GLDS ? PIECES : 1];
+    if constexpr (GLDS) {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int unit = (wave * PIECES + j) * 64 + lane;  // 16-byte unit inside the tile image
+            g_key[j] = unit / C::CHUNKS;
+            g_vchunk[j] = unit % C::CHUNKS;
+            g_kchunk[j] = g_vchunk[j] ^ ((g_key[j] >> 2) & 3);
+        }
+    }
+    auto glds_tile = [&](int buf, int kt) {
+        if constexpr (GLDS) {
+            char* sk = smem + buf * STAGE;
+#pragma unroll
+            for (int j = 0; j < PIECES; ++j) {
+                const int key = min(kt * 64 + g_key[j], a.L - 1);
+                const int piece_off = (wave * PIECES + j) * 1024;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(kbase + (int64_t)key * a.k_ss + g_kchunk[j] * 8),
+                    (__attribute__((address_space(3))) void*)(sk + piece_off), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(vbase + (int64_t)key * a.v_ss + g_vchunk[j] * 8),
+                    (__attribute__((address_space(3))) void*)(sk + C::KBYTES + piece_off), 16, 0, 0);
+            }
+        }
+    };
+    bf16x8 kreg[GLDS ? 1 : C::LOADS], vreg[GLDS ? 1 : C::LOADS];
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < C::LOADS; ++i) {
@@ -129,14 +163,35 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         return -1;
     };
 
+    // mask words of a mixed tile are fetched one tile ahead, BEFORE that tile's LDS-DMA is issued, so the
+    // ordinary loads never sit behind an in-flight DMA in the (in-order) vmcnt queue
+    auto mask_words = [&](int t, uint32_t& w0, uint32_t& w1) {
+        w0 = w1 = 0xffffffffu;
+        if (((sum_row[t] >> (2 * wave)) & 3) == 2) {
+            w0 = (2 * t < a.W) ? bits_row[2 * t] : 0u;
+            w1 = (2 * t + 1 < a.W) ? bits_row[2 * t + 1] : 0u;
+        }
+    };
     int kt = next_active(-1);
     int buf = 0;
-    if (kt >= 0) gload(kt);
+    uint32_t mw0 = 0xffffffffu, mw1 = 0xffffffffu;
+    if (kt >= 0) {
+        mask_words(kt, mw0, mw1);
+        if constexpr (GLDS) glds_tile(0, kt); else gload(kt);
+    }
     while (kt >= 0) {
-        lds_store(buf);
+        if constexpr (GLDS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed
+        } else {
+            lds_store(buf);
+        }
         __syncthreads();
         const int nxt = next_active(kt);
-        if (nxt >= 0) gload(nxt);
+        uint32_t nw0 = 0xffffffffu, nw1 = 0xffffffffu;
+        if (nxt >= 0) {
+            mask_words(nxt, nw0, nw1);
+            if constexpr (GLDS) glds_tile(buf ^ 1, nxt); else gload(nxt);
+        }
         const int code = (sum_row[kt] >> (2 * wave)) & 3;
         if (code) {
             const char* sk = smem + buf * STAGE;
@@ -147,33 +202,32 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) S[kb][i] = 0.f;
-                const char* krow = sk + (kb * 32 + r) * C::KROW + h * 16;
+                const char* krow = sk + (kb * 32 + r) * C::KROW;
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    bf16x8 Kf = *reinterpret_cast<const bf16x8*>(krow + s * 32);
+                    const int kc = GLDS ? ((2 * s + h) ^ ((r >> 2) & 3)) : (2 * s + h);
+                    bf16x8 Kf = *reinterpret_cast<const bf16x8*>(krow + kc * 16);
                     S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf, Qf[s], S[kb], 0, 0, 0);
                 }
             }
-            // ---- scale + mask ----
-            uint32_t w0 = 0xffffffffu, w1 = 0xffffffffu;
+            // ---- mask (mixed tiles only), row max on raw scores; scale folded into the exp2 FMA ----
             if (code == 2) {
-                w0 = (2 * kt < a.W) ? bits_row[2 * kt] : 0u;
-                w1 = (2 * kt + 1 < a.W) ? bits_row[2 * kt + 1] : 0u;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const uint32_t w = (kb ? mw1 : mw0) >> (4 * h);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int bit = (i & 3) + 8 * (i >> 2);
+                        S[kb][i] = ((w >> bit) & 1u) ? S[kb][i] : -INFINITY;
+                    }
+                }
             }
             float mx = -INFINITY;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const uint32_t w = (kb ? w1 : w0) >> (4 * h);
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int bit = (i & 3) + 8 * (i >> 2);
-                    float s = S[kb][i] * a.scale_log2e;
-                    s = ((w >> bit) & 1u) ? s : -INFINITY;
-                    S[kb][i] = s;
-                    mx = fmaxf(mx, s);
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, S[kb][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2e;  // scale > 0: max commutes with it
             const float m_new = fmaxf(m_i, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_i - m_use);
@@ -182,17 +236,20 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(S[kb][i] - m_use);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kb][i], a.scale_log2e, -m_use));
                     S[kb][i] = p;
                     rs += p;
                 }
             rs += __shfl_xor(rs, 32, 64);
             l_i = l_i * alpha + rs;
+            // rescale the accumulator only when some row's running max moved (wave-uniform branch)
+            if (__any(m_new != m_i)) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+            }
             m_i = m_new;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
             // ---- P^T fragments: accumulator registers 8*half..8*half+7 of S[kb] ----
             bf16x8 Pf[4];
 #pragma unroll
@@ -227,6 +284,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         }
         kt = nxt;
         buf ^= 1;
+        mw0 = nw0;
+        mw1 = nw1;
     }
 
     // ---- epilogue: lane holds O^T[d = 32dt + (i&3) + 8(i>>2) + 4h][q = r] ----
@@ -285,6 +344,7 @@ VGPT_EXPORT int vgpt_attn_blockmask_fwd(const void* q, const void* k, const void
                  "vgpt_attn_blockmask_fwd: n_kv_heads must divide n_heads");
     VGPT_REQUIRE(vgpt_attn_supported(head_dim), VGPT_ERR_UNSUPPORTED,
                  "vgpt_attn_blockmask_fwd: head_dim=%d unsupported (64, 96, 128)", head_dim);
+    VGPT_REQUIRE(scale > 0.f, VGPT_ERR_INVALID, "vgpt_attn_blockmask_fwd: scale must be positive");
     VGPT_REQUIRE(variant == 0 || variant == 1, VGPT_ERR_INVALID,
                  "vgpt_attn_blockmask_fwd: unknown variant %d", variant);
     const int64_t strides[] = {q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss};

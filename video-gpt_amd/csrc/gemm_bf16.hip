@@ -17,6 +17,8 @@
 //     consecutive n of one m: 8-byte bf16 stores.
 //   - 1-D grid with an XCD-aware, grouped tile order so blocks that share an XCD's L2 work
 //     on neighbouring tiles.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -70,7 +72,7 @@ __device__ __forceinline__ int w_row_of_slot(int n0, int s, int I) {
     return n0 + s;
 }
 
-template <int MODE, typename C>
+template <int MODE, typename C, bool PIPE>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int BM = C::BM, BN = C::BN, MI = C::MI, NI = C::NI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -142,28 +144,107 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    if constexpr (!PIPE) {
+        // one barrier per k-tile: wait for tile kt, issue tile kt+1's DMA, compute tile kt
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // tile kt landed for every wave; buffer buf^1 is free
+            if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+            const char* bA = sA + buf * C::A_BYTES + a_base;
+            const char* bW = sW + buf * C::W_BYTES + w_base;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int coff = ((ks * 4 + fk) ^ sw) * 16;
+                bf16x8 wf[NI], af[MI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(bW + i * 2048 + coff);
+#pragma unroll
+                for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const bf16x8*>(bA + j * 2048 + coff);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    } else {
+        // Software-pipelined 4-phase loop (256x256 tile, wave tile 128(m) x 64(n)).  A k-tile is four
+        // phases of 16 MFMAs: (ks0,m-half0) (ks0,m-half1) (ks1,m-half0) (ks1,m-half1).  The fragments
+        // of phase p+1 are read from LDS while phase p's MFMAs run (two register sets), the next tile's
+        // DMA is issued in two halves right after the per-tile barrier, and that barrier sits in front of
+        // the LAST phase of a tile so the first fragments of tile kt+1 are prefetched under tile kt.
+        static_assert(MI == 8 && NI == 4, "pipelined loop is written for the 256x256 / 2x4-wave tile");
+        bf16x8 Wf[2][4], Af[2][4];
+        auto ldW = [&](bf16x8(&dst)[4], int buf, int ks) {
+            const char* b = sW + buf * C::W_BYTES + w_base + ((ks * 4 + fk) ^ sw) * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(b + i * 2048);
+        };
+        auto ldA = [&](bf16x8(&dst)[4], int buf, int ks, int mh) {
+            const char* b = sA + buf * C::A_BYTES + a_base + mh * 8192 + ((ks * 4 + fk) ^ sw) * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(b + j * 2048);
+        };
+        auto mma = [&](const bf16x8(&wf)[4], const bf16x8(&af)[4], auto mh) {
+            constexpr int MH = decltype(mh)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][MH * 4 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][MH * 4 + j], 0, 0, 0);
+        };
+        auto stage_half = [&](int buf, int kt, int half) {
+            const int koff = kt * BK;
+#pragma unroll
+            for (int i = 0; i < C::A_SLABS / 2; ++i) {
+                const int ii = half * (C::A_SLABS / 2) + i;
+                glds16(a_src[ii] + koff, sA + buf * C::A_BYTES + (wave * C::A_SLABS + ii) * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < C::W_SLABS / 2; ++i) {
+                const int ii = half * (C::W_SLABS / 2) + i;
+                glds16(w_src[ii] + koff, sW + buf * C::W_BYTES + (wave * C::W_SLABS + ii) * 1024);
+            }
+        };
+        using H0 = std::integral_constant<int, 0>;
+        using H1 = std::integral_constant<int, 1>;
+
+        stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile kt landed for every wave; buffer buf^1 is free
-        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-        const char* bA = sA + buf * C::A_BYTES + a_base;
-        const char* bW = sW + buf * C::W_BYTES + w_base;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + fk) ^ sw) * 16;
-            bf16x8 wf[NI], af[MI];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(bW + i * 2048 + coff);
-#pragma unroll
-            for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const bf16x8*>(bA + j * 2048 + coff);
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < MI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0,
-                                                                        0, 0);
+        __syncthreads();
+        if (nk > 1) stage(1, 1);
+        ldW(Wf[0], 0, 0);
+        ldA(Af[0], 0, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            // phase 1: (ks0, m-half 0)
+            ldA(Af[1], buf, 0, 1);
+            if (kt >= 1 && kt + 1 < nk) stage_half(buf ^ 1, kt + 1, 1);
+            mma(Wf[0], Af[0], H0{});
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 2: (ks0, m-half 1)
+            ldW(Wf[1], buf, 1);
+            ldA(Af[0], buf, 1, 0);
+            mma(Wf[0], Af[1], H1{});
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 3: (ks1, m-half 0)
+            ldA(Af[1], buf, 1, 1);
+            mma(Wf[1], Af[0], H0{});
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 4: (ks1, m-half 1) — every wave has its last fragments of this tile in registers and
+            // its share of tile kt+1 has landed: after the barrier buffer `buf` is free for tile kt+2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 2 < nk) stage_half(buf, kt + 2, 0);
+            if (kt + 1 < nk) {
+                ldW(Wf[0], buf ^ 1, 0);
+                ldA(Af[0], buf ^ 1, 0, 0);
+            }
+            mma(Wf[1], Af[1], H1{});
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -213,11 +294,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
-template <int MODE, typename C>
+template <int MODE, typename C, bool PIPE>
 int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE, C>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE, C, PIPE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) {
             vgpt_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
@@ -227,13 +308,14 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     }
     g.tiles_m = (int)cdiv(g.M, C::BM);
     g.tiles_n = (int)cdiv(n_out, MODE == MODE_GATED ? C::BN / 2 : C::BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C>), dim3(g.tiles_m * g.tiles_n), dim3(C::THREADS),
+    hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C, PIPE>), dim3(g.tiles_m * g.tiles_n), dim3(C::THREADS),
                        C::LDS_BYTES, s, g);
     VGPT_CHECK_LAUNCH(name);
     return VGPT_OK;
 }
 
-// 0 = heuristic, 128 / 256 = forced (VGPT_GEMM_TILE, read once; for A/B measurements)
+// 0 = heuristic, 128 / 256 = forced tile, 257 = 256-tile with the simple (non-pipelined) loop
+// (VGPT_GEMM_TILE, read once; for A/B measurements)
 int forced_tile() {
     static int v = -1;
     if (v < 0) {
@@ -248,8 +330,10 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const int f = forced_tile();
     // the 256-tile pays off once the grid fills the chip (>= ~half of the 256 CUs with 256x256 tiles)
     const int64_t big_tiles = cdiv(g.M, 256) * cdiv(n_out, MODE == MODE_GATED ? 128 : 256);
-    const bool use256 = f == 256 || (f != 128 && big_tiles >= 128);
-    return use256 ? launch_cfg<MODE, Cfg256>(g, n_out, s, name) : launch_cfg<MODE, Cfg128>(g, n_out, s, name);
+    const bool use256 = f == 256 || f == 257 || (f != 128 && big_tiles >= 128);
+    if (!use256) return launch_cfg<MODE, Cfg128, false>(g, n_out, s, name);
+    if (f == 257) return launch_cfg<MODE, Cfg256, false>(g, n_out, s, name);
+    return launch_cfg<MODE, Cfg256, true>(g, n_out, s, name);
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
