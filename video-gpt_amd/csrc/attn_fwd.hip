@@ -196,20 +196,54 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         if (code) {
             const char* sk = smem + buf * STAGE;
             const char* sv = sk + C::KBYTES;
-            // ---- S^T = K Q^T : two 32-key halves ----
+            // ---- S^T = K Q^T : two 32-key halves.  All K fragments are requested up front (one LDS round
+            //      trip for the whole tile instead of one per MFMA), then the two MFMA chains run ----
+            bf16x8 Kf[2][KS];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const char* krow = sk + (kb * 32 + r) * C::KROW;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int kc = GLDS ? ((2 * s + h) ^ ((r >> 2) & 3)) : (2 * s + h);
+                    Kf[kb][s] = *reinterpret_cast<const bf16x8*>(krow + kc * 16);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 S[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) S[kb][i] = 0.f;
-                const char* krow = sk + (kb * 32 + r) * C::KROW;
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const int kc = GLDS ? ((2 * s + h) ^ ((r >> 2) & 3)) : (2 * s + h);
-                    bf16x8 Kf = *reinterpret_cast<const bf16x8*>(krow + kc * 16);
-                    S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf, Qf[s], S[kb], 0, 0, 0);
+                for (int s = 0; s < KS; ++s)
+                    S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[kb][s], Qf[s], S[kb], 0, 0, 0);
+            }
+            // ---- V^T fragments do not depend on the softmax: request them now so their LDS latency hides
+            //      under the softmax VALU work ----
+            bf16x8 Vf[DT][4];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int key0 = (t >> 1) * 32 + (t & 1) * 16 + 4 * h;
+                    if (TR) {
+                        const int li = lane & 15;
+                        const char* p0 = sv + (key0 + (li >> 2)) * C::VROW_TR +
+                                         (dt * 32 + ((lane >> 4) & 1) * 16 + 4 * (li & 3)) * 2;
+                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(p0));
+                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(p0 + 8 * C::VROW_TR));
+                        Vf[dt][t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    } else {
+                        const char* p0 = sv + (dt * 32 + r) * C::VROW_T + key0 * 2;
+                        bf16x4 lo = *reinterpret_cast<const bf16x4*>(p0);
+                        bf16x4 hi = *reinterpret_cast<const bf16x4*>(p0 + 16);
+                        Vf[dt][t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
             // ---- mask (mixed tiles only), row max on raw scores; scale folded into the exp2 FMA ----
             if (code == 2) {
 #pragma unroll
@@ -258,29 +292,10 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
                 for (int j = 0; j < 8; ++j) Pf[t][j] = f2bf(S[t >> 1][8 * (t & 1) + j]);
             // ---- O^T += V^T P^T ----
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int key0 = (t >> 1) * 32 + (t & 1) * 16 + 4 * h;
-                    bf16x8 Vf;
-                    if (TR) {
-                        const int li = lane & 15;
-                        const char* p0 = sv + (key0 + (li >> 2)) * C::VROW_TR +
-                                         (dt * 32 + ((lane >> 4) & 1) * 16 + 4 * (li & 3)) * 2;
-                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(p0));
-                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(p0 + 8 * C::VROW_TR));
-                        Vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    } else {
-                        const char* p0 = sv + (dt * 32 + r) * C::VROW_T + key0 * 2;
-                        bf16x4 lo = *reinterpret_cast<const bf16x4*>(p0);
-                        bf16x4 hi = *reinterpret_cast<const bf16x4*>(p0 + 16);
-                        Vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    }
-                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vf, Pf[t], O[dt], 0, 0, 0);
-                }
-            }
+                for (int t = 0; t < 4; ++t)
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vf[dt][t], Pf[t], O[dt], 0, 0, 0);
         }
         kt = nxt;
         buf ^= 1;
