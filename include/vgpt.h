@@ -206,6 +206,67 @@ int vgpt_vae_postprocess_u8(const float* x, uint8_t* out, int N, int C, int H, i
 /* y = float(x) * mul + add (latent / scaling_factor + shift before decode, LVM/pipeline.py:573-577). */
 int vgpt_affine_to_f32(const void* x, int x_is_bf16, float* y, int64_t n, float mul, float add, void* stream);
 
+/* ---- stage-1 pre-training step (LVM/train_helper/loss.py:128-243, LVM/train/train_x1_stage1_noiseinput.py:351-405;
+ *      the reference gets these from torch.autograd + DeepSpeed) ---------------------------------------- */
+
+/* Attention forward that also returns the base-2 log-sum-exp of the scaled scores, lse (B, n_heads, L) fp32. */
+int vgpt_attn_blockmask_fwd_lse(const void* q, const void* k, const void* v, void* o, float* lse,
+                                const uint32_t* bits, const uint8_t* summary, int64_t B, int64_t L, int n_heads,
+                                int n_kv_heads, int head_dim, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
+                                int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb,
+                                int64_t o_sh, int64_t o_ss, float scale, void* stream);
+/* Attention backward (head_dim 96): dq, dk, dv from q, k, v, o, dout, lse.  strides: 24 x int64 element strides
+ * (batch, head, seq) of q, k, v, o, dout, dq, dk, dv in that order.  delta_ws: (B, n_heads, L) fp32 workspace. */
+int vgpt_attn_blockmask_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                            const float* lse, float* delta_ws, void* dq, void* dk, void* dv, const uint32_t* bits,
+                            const uint8_t* summary, int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim,
+                            const int64_t* strides, float scale, void* stream);
+
+/* (R, C) bf16 row stride ld_in -> (C, Rp) bf16, columns r >= R zero-filled (operands of the backward NT GEMMs). */
+int vgpt_transpose_pad_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t Rp, int64_t ld_in, void* stream);
+/* un-fused gated activation: act = f(gate) * up from gate_up (M, 2I); and its backward d(gate_up). */
+int vgpt_silu_mul_fwd(const void* gate_up, void* act_out, int64_t M, int64_t I, int act, void* stream);
+int vgpt_silu_mul_bwd(const void* gate_up, const void* dact, void* dgate_up, int64_t M, int64_t I, int act, void* stream);
+/* y = f(pre);  dx = f'(pre) * dy  (bf16, n elements). */
+int vgpt_act_fwd(const void* pre, void* y, int64_t n, int act, void* stream);
+int vgpt_act_bwd(const void* pre, const void* dy, void* dx, int64_t n, int act, void* stream);
+/* Phi3RMSNorm backward: dx = d(norm)/dx (+ dres if not NULL), dw += sum_rows dy * xhat (fp32, caller zeroes). */
+int vgpt_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dres, void* dx, float* dw,
+                     int64_t rows, int64_t H, float eps, void* stream);
+/* C[m][n] = alpha * sum_k A[m*sa_m + k*sa_k] * B[k*sb_k + n*sb_n] (+ C); *_f32: 0 = bf16, 1 = fp32.  For the
+ * small heads (patch embeds, timestep MLPs, adaLN, final Linear) whose backward is not worth an MFMA kernel. */
+int vgpt_matmul_generic(const void* A, int a_f32, int64_t sa_m, int64_t sa_k, const void* B, int b_f32, int64_t sb_k,
+                        int64_t sb_n, void* C, int c_f32, int64_t sc_m, int64_t sc_n, int64_t M, int64_t N, int64_t K,
+                        float alpha, int accumulate, void* stream);
+/* out[c] (+)= sum_r X[r*ld + c]  (bias gradients). */
+int vgpt_colsum(const void* X, int x_f32, float* out, int64_t R, int64_t C, int64_t ld, int accumulate, void* stream);
+/* xt[f] = t[f]*x1[f] + (1-t[f])*x0[f]  (loss.py:175,186), fp32 in, bf16 out. */
+int vgpt_lerp_frames(const float* x1, const float* x0, const float* t, void* out, int n_frames, int64_t elems,
+                     void* stream);
+/* loss[f] = mean((x1[f]-pred[f])^2) (loss.py:209-218); dpred (optional, bf16) = d(mean_f loss)/dpred. */
+int vgpt_mse_frames(const void* pred, const float* x1, float* loss, void* dpred, int n_frames, int64_t elems,
+                    void* stream);
+/* FinalLayer split for training: v = LN(x)(1+scale)+shift with xhat / rstd saved; and its backward (dmod fp32
+ * (n_frames, 2H) accumulated with atomics — caller zeroes; dhidden rows written at dst_row[f] + t). */
+int vgpt_ln_mod_fwd(const void* hidden, const int32_t* src_row, const void* mod, void* v_out, float* xhat_out,
+                    float* rstd_out, int n_frames, int ntok, int64_t H, float eps, void* stream);
+int vgpt_ln_mod_bwd(const void* dv, const float* xhat, const float* rstd, const void* mod, const int32_t* dst_row,
+                    void* dhidden, float* dmod, int n_frames, int ntok, int64_t H, void* stream);
+/* embed_tokens backward: dtable[ids[r]] += dseq[r] for rows with keep[r] != 0 (fp32 atomics). */
+int vgpt_embed_bwd(const int64_t* ids, const uint8_t* keep, const void* dseq, float* dtable, int64_t rows, int64_t H,
+                   int64_t vocab, void* stream);
+/* (n_frames, C, h, w) -> (n_frames*ntok, 16) patch vectors; gradient of unpatchify; row-segment gather. */
+int vgpt_patchify(const void* x, void* patches, int n_frames, int C, int h, int w, void* stream);
+int vgpt_unpatchify_bwd(const void* dpred, void* dy16, int n_frames, int C, int h, int w, void* stream);
+int vgpt_gather_rows(const void* in, const int32_t* row0, void* out, int n_seg, int per, int64_t H, void* stream);
+/* *out += sum g^2;  coef = min(1, max_norm/(sqrt(sumsq)+1e-6)) * extra_scale;  AdamW on fp32 master weights
+ * (torch.optim.AdamW update; bf16 model copy refreshed; *grad_scale multiplies the gradient). */
+int vgpt_sumsq(const void* g, int g_f32, float* out, int64_t n, void* stream);
+int vgpt_clip_coef(const float* sumsq, float* coef, float* norm_out, float max_norm, float extra_scale, void* stream);
+int vgpt_adamw_step(float* master, void* param, const void* grad, int grad_f32, float* m, float* v, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_scale,
+                    void* stream);
+
 /* ---- hipGraph helpers (sampler loop under graph capture) ----------------- */
 int vgpt_graph_begin_capture(void* stream);
 int vgpt_graph_end_capture(void* stream, void** graph_exec_out);

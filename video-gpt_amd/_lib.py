@@ -54,6 +54,31 @@ SIGNATURES = {
     "vgpt_vae_sample": (c_int, [_P, _P, _P, c_int, _I64, c_float, c_float, _P]),
     "vgpt_vae_postprocess_u8": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vgpt_affine_to_f32": (c_int, [_P, c_int, _P, _I64, c_float, c_float, _P]),
+    "vgpt_attn_blockmask_fwd_lse": (
+        c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
+    "vgpt_attn_blockmask_bwd": (
+        c_int, [_P] * 12 + [_I64, _I64, c_int, c_int, c_int, _P, c_float, _P]),
+    "vgpt_transpose_pad_bf16": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _P]),
+    "vgpt_silu_mul_fwd": (c_int, [_P, _P, _I64, _I64, c_int, _P]),
+    "vgpt_silu_mul_bwd": (c_int, [_P, _P, _P, _I64, _I64, c_int, _P]),
+    "vgpt_act_fwd": (c_int, [_P, _P, _I64, c_int, _P]),
+    "vgpt_act_bwd": (c_int, [_P, _P, _P, _I64, c_int, _P]),
+    "vgpt_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, c_float, _P]),
+    "vgpt_matmul_generic": (c_int, [_P, c_int, _I64, _I64, _P, c_int, _I64, _I64, _P, c_int, _I64, _I64, _I64, _I64,
+                                    _I64, c_float, c_int, _P]),
+    "vgpt_colsum": (c_int, [_P, c_int, _P, _I64, _I64, _I64, c_int, _P]),
+    "vgpt_lerp_frames": (c_int, [_P, _P, _P, _P, c_int, _I64, _P]),
+    "vgpt_mse_frames": (c_int, [_P, _P, _P, _P, c_int, _I64, _P]),
+    "vgpt_ln_mod_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _I64, c_float, _P]),
+    "vgpt_ln_mod_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I64, _P]),
+    "vgpt_embed_bwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "vgpt_patchify": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vgpt_unpatchify_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vgpt_gather_rows": (c_int, [_P, _P, _P, c_int, c_int, _I64, _P]),
+    "vgpt_sumsq": (c_int, [_P, c_int, _P, _I64, _P]),
+    "vgpt_clip_coef": (c_int, [_P, _P, _P, c_float, c_float, _P]),
+    "vgpt_adamw_step": (c_int, [_P, _P, _P, c_int, _P, _P, _I64, c_float, c_float, c_float, c_float, c_float, c_int,
+                                _P, _P]),
     "vgpt_graph_begin_capture": (c_int, [_P]),
     "vgpt_graph_end_capture": (c_int, [_P, POINTER(c_void_p)]),
     "vgpt_graph_launch": (c_int, [_P, _P]),

@@ -1,0 +1,478 @@
+// Block-masked flash attention BACKWARD for gfx950 (head_dim 96, bf16 in/out, fp32 softmax math).
+//
+// The reference obtains these gradients from torch.autograd through F.scaled_dot_product_attention
+// (LVM/transform/sdpa_transform.py:78-86,152 inside accelerator.backward, train_x1_stage1_noiseinput.py:380).
+//
+// With P = exp2(c*S - LSE) (c = scale*log2 e, LSE from the forward), delta_q = sum_d dO[q][d] O[q][d]:
+//     dV = P^T dO            dP = dO V^T           dS = P o (dP - delta) * scale
+//     dQ = dS K              dK = dS^T Q
+// Two kernels, both recomputing S and dP (no atomics, deterministic):
+//   attn_bwd_dq_kernel  — a wave owns 32 QUERY rows and walks the key tiles exactly like the forward:
+//                         S^T = K Q^T, dP^T = V dO^T (keys on accumulator rows, the query on the lane, so
+//                         LSE/delta are per-lane scalars), dQ^T += K^T dS^T with K^T from ds_read_b64_tr_b16.
+//   attn_bwd_dkv_kernel — a wave owns 32 KEYS and walks the query tiles: S = Q K^T, dP = dO V^T (queries on
+//                         accumulator rows, the key on the lane), dV^T += dO^T P, dK^T += Q^T dS with the
+//                         transposed operands again from ds_read_b64_tr_b16 on the [row][d] LDS images.
+// Every LDS image is a contiguous [row][192 B] tile filled by LDS-DMA with the chunk XOR-swizzle
+// (chunk ^= (row>>2)&3) that makes ds_read_b128 row reads conflict-free and leaves the 64-byte windows of
+// the transposed reads intact (the XOR is constant over the 4 rows of a transposed-read block).
+#include "common.h"
+
+namespace {
+
+constexpr int D = 96, KS = D / 16, DT = D / 32, CHUNKS = D / 8, ROWB = D * 2;
+constexpr int TILE_BYTES = 64 * ROWB;  // 12 KiB image of 64 rows
+constexpr int PIECES = TILE_BYTES / 1024 / 4;
+
+struct BwdArgs {
+    const bf16 *q, *k, *v, *o, *dout;
+    bf16 *dq, *dk, *dv;
+    const float* lse;    // (B, n_heads, L) base-2
+    const float* delta;  // (B, n_heads, L)
+    const uint32_t* bits;
+    const uint8_t* summary;
+    int B, L, n_heads, n_kv_heads, kv_group, W, nqb, nkt;
+    int64_t q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, do_sb, do_sh, do_ss;
+    int64_t dq_sb, dq_sh, dq_ss, dk_sb, dk_sh, dk_ss, dv_sb, dv_sh, dv_ss;
+    float scale, scale_log2e;
+};
+
+__device__ __forceinline__ void dma4(const void* src, char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds, 4, 0, 0);
+}
+__device__ __forceinline__ void dma16(const bf16* src, char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// row read of a swizzled [row][192 B] image: lane (r = row, h) gets elements [16s + 8h, +8)
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int row, int s, int h) {
+    const int kc = (2 * s + h) ^ ((row >> 2) & 3);
+    return *reinterpret_cast<const bf16x8*>(img + row * ROWB + kc * 16);
+}
+
+// transposed read: A operand of a 32x32x16 MFMA whose rows are d (32-wide tile dt) and whose k index runs
+// over 16 image rows starting at row16 (+4h, +8 for the upper half): element j <-> row row16 + 8(j>>2) + 4h + (j&3)
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int row16, int dt, int lane) {
+    const int h = lane >> 5, li = lane & 15;
+    const int row = row16 + 4 * h + (li >> 2);
+    const int dcol = dt * 32 + ((lane >> 4) & 1) * 16 + 4 * (li & 3);  // first of 4 consecutive d
+    const int f0 = (row >> 2) & 3, f1 = ((row + 8) >> 2) & 3;
+    const char* p0 = img + row * ROWB + (((dcol >> 3) ^ f0) * 16) + (dcol & 4) * 2;
+    const char* p1 = img + (row + 8) * ROWB + (((dcol >> 3) ^ f1) * 16) + (dcol & 4) * 2;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int half) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = f2bf(x[8 * half + j]);
+    return r;
+}
+
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int L, int n_heads,
+                                                         int64_t o_sb, int64_t o_sh, int64_t o_ss, int64_t do_sb,
+                                                         int64_t do_sh, int64_t do_ss) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * n_heads * L) return;
+    const int q = (int)(idx % L);
+    const int hd = (int)((idx / L) % n_heads);
+    const int b = (int)(idx / ((int64_t)L * n_heads));
+    const bf16* op = o + b * o_sb + hd * o_sh + (int64_t)q * o_ss;
+    const bf16* dp = dout + b * do_sb + hd * do_sh + (int64_t)q * do_ss;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(op + c * 8);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dp + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += bf2f(a[j]) * bf2f(d[j]);
+    }
+    delta[idx] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// dQ: block = 4 waves = 128 query rows of one (batch, head); K/V tiles of 64 keys double-buffered in LDS
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs a) {
+    constexpr int STAGE = 2 * TILE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int total = a.nqb * a.n_heads * a.B;
+    int wid = blockIdx.x;
+    {
+        const int xcd = wid & 7, qn = total >> 3, rn = total & 7;
+        wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (wid >> 3);
+    }
+    const int qb = wid % a.nqb, head = (wid / a.nqb) % a.n_heads, b = wid / (a.nqb * a.n_heads);
+    const int kvh = head / a.kv_group;
+    const uint8_t* sum_row = a.summary + ((int64_t)b * a.nqb + qb) * a.nkt;
+    const bf16* kbase = a.k + (int64_t)b * a.k_sb + (int64_t)kvh * a.k_sh;
+    const bf16* vbase = a.v + (int64_t)b * a.v_sb + (int64_t)kvh * a.v_sh;
+
+    const int q_row = qb * 128 + wave * 32 + r;
+    const int q_ld = min(q_row, a.L - 1);
+    const bf16* qp = a.q + (int64_t)b * a.q_sb + (int64_t)head * a.q_sh + (int64_t)q_ld * a.q_ss;
+    const bf16* dop = a.dout + (int64_t)b * a.do_sb + (int64_t)head * a.do_sh + (int64_t)q_ld * a.do_ss;
+    bf16x8 Qf[KS], dOf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        Qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s + 8 * h);
+        dOf[s] = *reinterpret_cast<const bf16x8*>(dop + 16 * s + 8 * h);
+    }
+    const int64_t stat = ((int64_t)b * a.n_heads + head) * a.L + q_ld;
+    const float lse = a.lse[stat], dlt = a.delta[stat];
+    const uint32_t* bits_row = a.bits + ((int64_t)b * a.L + q_ld) * a.W;
+
+    f32x16 dQ[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dQ[dt][i] = 0.f;
+
+    int g_key[PIECES], g_chunk[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+        const int unit = (wave * PIECES + j) * 64 + lane;
+        g_key[j] = unit / CHUNKS;
+        g_chunk[j] = (unit % CHUNKS) ^ ((g_key[j] >> 2) & 3);
+    }
+    auto stage = [&](int buf, int kt) {
+        char* sk = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int key = min(kt * 64 + g_key[j], a.L - 1);
+            const int off = (wave * PIECES + j) * 1024;
+            dma16(kbase + (int64_t)key * a.k_ss + g_chunk[j] * 8, sk + off);
+            dma16(vbase + (int64_t)key * a.v_ss + g_chunk[j] * 8, sk + TILE_BYTES + off);
+        }
+    };
+    auto next_active = [&](int kt) {
+        for (int k2 = kt + 1; k2 < a.nkt; ++k2)
+            if (sum_row[k2]) return k2;
+        return -1;
+    };
+    auto mask_words = [&](int t, uint32_t& w0, uint32_t& w1) {
+        w0 = w1 = 0xffffffffu;
+        if (((sum_row[t] >> (2 * wave)) & 3) == 2) {
+            w0 = (2 * t < a.W) ? bits_row[2 * t] : 0u;
+            w1 = (2 * t + 1 < a.W) ? bits_row[2 * t + 1] : 0u;
+        }
+    };
+
+    int kt = next_active(-1), buf = 0;
+    uint32_t mw0 = 0xffffffffu, mw1 = 0xffffffffu;
+    if (kt >= 0) {
+        mask_words(kt, mw0, mw1);
+        stage(0, kt);
+    }
+    while (kt >= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nxt = next_active(kt);
+        uint32_t nw0 = 0xffffffffu, nw1 = 0xffffffffu;
+        if (nxt >= 0) {
+            mask_words(nxt, nw0, nw1);
+            stage(buf ^ 1, nxt);
+        }
+        const int code = (sum_row[kt] >> (2 * wave)) & 3;
+        if (code) {
+            const char* sk = smem + buf * STAGE;
+            const char* sv = sk + TILE_BYTES;
+            bf16x8 Kf[2][KS], Vf[2][KS];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    Kf[kb][s] = row_frag(sk, kb * 32 + r, s, h);
+                    Vf[kb][s] = row_frag(sv, kb * 32 + r, s, h);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 S[2], dP[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { S[kb][i] = 0.f; dP[kb][i] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[kb][s], Qf[s], S[kb], 0, 0, 0);
+                    dP[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vf[kb][s], dOf[s], dP[kb], 0, 0, 0);
+                }
+            }
+            // K^T fragments for dQ^T += K^T dS^T (independent of the element-wise math below)
+            bf16x8 Kt[DT][4];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Kt[dt][t] = tr_frag(sk, (t >> 1) * 32 + (t & 1) * 16, dt, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            // dS^T = P^T o (dP^T - delta) * scale, P^T = exp2(c S^T - LSE); masked keys -> 0
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const uint32_t w = (kb ? mw1 : mw0) >> (4 * h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int bit = (i & 3) + 8 * (i >> 2);
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kb][i], a.scale_log2e, -lse));
+                    if (code == 2) p = ((w >> bit) & 1u) ? p : 0.f;
+                    S[kb][i] = p * (dP[kb][i] - dlt) * a.scale;
+                }
+            }
+            bf16x8 dSf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dSf[t] = pack8(S[t >> 1], t & 1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kt[dt][t], dSf[t], dQ[dt], 0, 0, 0);
+        }
+        kt = nxt;
+        buf ^= 1;
+        mw0 = nw0;
+        mw1 = nw1;
+    }
+    if (q_row < a.L) {
+        bf16* op = a.dq + (int64_t)b * a.dq_sb + (int64_t)head * a.dq_sh + (int64_t)q_row * a.dq_ss;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = f2bf(dQ[dt][4 * g4 + t]);
+                *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g4 + 4 * h) = o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// dK, dV: block = 4 waves = 128 keys of one (batch, kv head); Q/dO tiles of 64 query rows in LDS
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs a) {
+    // stage: Q image | dO image | lse[64] | delta[64] | mask words [64][4]
+    constexpr int STAT_OFF = 2 * TILE_BYTES, MASK_OFF = STAT_OFF + 512, STAGE = MASK_OFF + 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int nkb = (a.L + 127) / 128;  // 128-key blocks
+    const int total = nkb * a.n_kv_heads * a.B;
+    int wid = blockIdx.x;
+    {
+        const int xcd = wid & 7, qn = total >> 3, rn = total & 7;
+        wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (wid >> 3);
+    }
+    const int kblk = wid % nkb, kvh = (wid / nkb) % a.n_kv_heads, b = wid / (nkb * a.n_kv_heads);
+    const int key_row = kblk * 128 + wave * 32 + r;
+    const int key_ld = min(key_row, a.L - 1);
+    const int ktile = kblk * 2 + (wave >> 1);  // 64-key tile of this wave (summary column)
+    const bf16* kp = a.k + (int64_t)b * a.k_sb + (int64_t)kvh * a.k_sh + (int64_t)key_ld * a.k_ss;
+    const bf16* vp = a.v + (int64_t)b * a.v_sb + (int64_t)kvh * a.v_sh + (int64_t)key_ld * a.v_ss;
+    bf16x8 Kf[KS], Vf[KS];  // B operands: lane holds K[key r][16s + 8h .. +8)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        Kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s + 8 * h);
+        Vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s + 8 * h);
+    }
+    f32x16 dK[DT], dV[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dK[dt][i] = 0.f; dV[dt][i] = 0.f; }
+
+    int g_row[PIECES], g_chunk[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+        const int unit = (wave * PIECES + j) * 64 + lane;
+        g_row[j] = unit / CHUNKS;
+        g_chunk[j] = (unit % CHUNKS) ^ ((g_row[j] >> 2) & 3);
+    }
+    const int nqt = (a.L + 63) / 64;
+
+    for (int gh = 0; gh < a.kv_group; ++gh) {
+        const int head = kvh * a.kv_group + gh;
+        const bf16* qbase = a.q + (int64_t)b * a.q_sb + (int64_t)head * a.q_sh;
+        const bf16* dobase = a.dout + (int64_t)b * a.do_sb + (int64_t)head * a.do_sh;
+        const float* lse_b = a.lse + ((int64_t)b * a.n_heads + head) * a.L;
+        const float* dlt_b = a.delta + ((int64_t)b * a.n_heads + head) * a.L;
+        // activity of query tile qt for this block: any code bit in the two summary bytes of its 128-row block
+        auto tile_bits = [&](int qt, int kt) -> int {
+            if (kt >= a.nkt) return 0;
+            const uint8_t sbyte = a.summary[((int64_t)b * a.nqb + (qt >> 1)) * a.nkt + kt];
+            return (sbyte >> (4 * (qt & 1))) & 15;  // 2 x 2-bit codes of the two 32-row halves of this 64-row tile
+        };
+        auto next_active = [&](int qt) {
+            for (int q2 = qt + 1; q2 < nqt; ++q2)
+                if (tile_bits(q2, kblk * 2) | tile_bits(q2, kblk * 2 + 1)) return q2;
+            return -1;
+        };
+        auto stage = [&](int buf, int qt) {
+            char* sq = smem + buf * STAGE;
+#pragma unroll
+            for (int j = 0; j < PIECES; ++j) {
+                const int row = min(qt * 64 + g_row[j], a.L - 1);
+                const int off = (wave * PIECES + j) * 1024;
+                dma16(qbase + (int64_t)row * a.q_ss + g_chunk[j] * 8, sq + off);
+                dma16(dobase + (int64_t)row * a.do_ss + g_chunk[j] * 8, sq + TILE_BYTES + off);
+            }
+            // row statistics and mask words also arrive by LDS-DMA (4-byte form), so that no ordinary
+            // global load sits behind the tile DMA in the in-order vmcnt queue
+            if (wave == 0) {
+                const int row = min(qt * 64 + lane, a.L - 1);
+                dma4(lse_b + row, sq + STAT_OFF);
+                dma4(dlt_b + row, sq + STAT_OFF + 256);
+            } else if (wave == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = i * 64 + lane;
+                    const int row = min(qt * 64 + (idx >> 2), a.L - 1);
+                    const int wi = min(kblk * 4 + (idx & 3), a.W - 1);
+                    dma4(a.bits + ((int64_t)b * a.L + row) * a.W + wi, sq + MASK_OFF + i * 256);
+                }
+            }
+        };
+
+        int qt = next_active(-1), buf = 0;
+        if (qt >= 0) stage(0, qt);
+        while (qt >= 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int nxt = next_active(qt);
+            if (nxt >= 0) stage(buf ^ 1, nxt);
+            const char* sq = smem + buf * STAGE;
+            const char* sdo = sq + TILE_BYTES;
+            const float* st = reinterpret_cast<const float*>(sq + STAT_OFF);
+            const uint32_t* mw = reinterpret_cast<const uint32_t*>(sq + MASK_OFF);
+            const int codes = tile_bits(qt, ktile);
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {  // two 32-row halves of the query tile
+                const int code = (codes >> (2 * qh)) & 3;
+                if (!code) continue;
+                bf16x8 Qr[KS], dOr[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    Qr[s] = row_frag(sq, qh * 32 + r, s, h);
+                    dOr[s] = row_frag(sdo, qh * 32 + r, s, h);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 S, dP;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qr[s], Kf[s], S, 0, 0, 0);    // S[q][key]
+                    dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dOr[s], Vf[s], dP, 0, 0, 0);  // dP[q][key]
+                }
+                // transposed operands for dV^T += dO^T P and dK^T += Q^T dS (k index = query row)
+                bf16x8 dOt[DT][2], Qt[DT][2];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        dOt[dt][t] = tr_frag(sdo, qh * 32 + t * 16, dt, lane);
+                        Qt[dt][t] = tr_frag(sq, qh * 32 + t * 16, dt, lane);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 P;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int qrow = qh * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;  // accumulator row -> query row
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], a.scale_log2e, -st[qrow]));
+                    if (code == 2) p = ((mw[qrow * 4 + wave] >> r) & 1u) ? p : 0.f;
+                    if (key_row >= a.L || qt * 64 + qrow >= a.L) p = 0.f;
+                    P[i] = p;
+                    S[i] = p * (dP[i] - st[64 + qrow]) * a.scale;  // dS
+                }
+                bf16x8 Pf[2], dSf[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    Pf[t] = pack8(P, t);
+                    dSf[t] = pack8(S, t);
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dOt[dt][t], Pf[t], dV[dt], 0, 0, 0);
+                        dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qt[dt][t], dSf[t], dK[dt], 0, 0, 0);
+                    }
+            }
+            qt = nxt;
+            buf ^= 1;
+        }
+        __syncthreads();  // the next head's prologue DMA reuses buffer 0
+    }
+    if (key_row < a.L) {
+        bf16* kp_o = a.dk + (int64_t)b * a.dk_sb + (int64_t)kvh * a.dk_sh + (int64_t)key_row * a.dk_ss;
+        bf16* vp_o = a.dv + (int64_t)b * a.dv_sb + (int64_t)kvh * a.dv_sh + (int64_t)key_row * a.dv_ss;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 ok, ov;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    ok[t] = f2bf(dK[dt][4 * g4 + t]);
+                    ov[t] = f2bf(dV[dt][4 * g4 + t]);
+                }
+                *reinterpret_cast<bf16x4*>(kp_o + dt * 32 + 8 * g4 + 4 * h) = ok;
+                *reinterpret_cast<bf16x4*>(vp_o + dt * 32 + 8 * g4 + 4 * h) = ov;
+            }
+    }
+}
+
+}  // namespace
+
+VGPT_EXPORT int vgpt_attn_blockmask_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                                        const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
+                                        const uint32_t* bits, const uint8_t* summary, int64_t B, int64_t L, int n_heads,
+                                        int n_kv_heads, int head_dim, const int64_t* strides, float scale, void* stream) {
+    VGPT_REQUIRE(q && k && v && o && dout && lse && delta_ws && dq && dk && dv && bits && summary && strides,
+                 VGPT_ERR_INVALID, "vgpt_attn_blockmask_bwd: null pointer");
+    VGPT_REQUIRE(head_dim == 96, VGPT_ERR_UNSUPPORTED, "vgpt_attn_blockmask_bwd: head_dim %d unsupported (96)", head_dim);
+    VGPT_REQUIRE(B >= 0 && L >= 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0 && scale > 0.f,
+                 VGPT_ERR_INVALID, "vgpt_attn_blockmask_bwd: bad shape");
+    for (int i = 0; i < 24; ++i)
+        VGPT_REQUIRE(strides[i] % (i < 15 ? 8 : 4) == 0, VGPT_ERR_UNSUPPORTED,
+                     "vgpt_attn_blockmask_bwd: strides must be multiples of 8 (inputs) / 4 (outputs) elements");
+    if (B == 0 || L == 0) return VGPT_OK;
+    BwdArgs a;
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)o; a.dout = (const bf16*)dout;
+    a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.lse = lse; a.delta = delta_ws; a.bits = bits;
+    a.summary = summary;
+    a.B = (int)B; a.L = (int)L; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.kv_group = n_heads / n_kv_heads;
+    a.W = (int)cdiv(L, 32); a.nqb = (int)cdiv(L, 128); a.nkt = (int)cdiv(L, 64);
+    const int64_t* s = strides;
+    a.q_sb = s[0]; a.q_sh = s[1]; a.q_ss = s[2]; a.k_sb = s[3]; a.k_sh = s[4]; a.k_ss = s[5];
+    a.v_sb = s[6]; a.v_sh = s[7]; a.v_ss = s[8]; a.o_sb = s[9]; a.o_sh = s[10]; a.o_ss = s[11];
+    a.do_sb = s[12]; a.do_sh = s[13]; a.do_ss = s[14]; a.dq_sb = s[15]; a.dq_sh = s[16]; a.dq_ss = s[17];
+    a.dk_sb = s[18]; a.dk_sh = s[19]; a.dk_ss = s[20]; a.dv_sb = s[21]; a.dv_sh = s[22]; a.dv_ss = s[23];
+    a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    constexpr int lds_dq = 2 * 2 * TILE_BYTES, lds_dkv = 2 * (2 * TILE_BYTES + 512 + 1024);
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
+        hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            vgpt_set_error("vgpt_attn_blockmask_bwd: hipFuncSetAttribute failed");
+            return VGPT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const int64_t nstat = B * n_heads * L;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(nstat, 256)), dim3(256), 0, st, a.o, a.dout, delta_ws, a.B,
+                       a.L, n_heads, a.o_sb, a.o_sh, a.o_ss, a.do_sb, a.do_sh, a.do_ss);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(a.nqb * n_heads * a.B), dim3(256), lds_dq, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(cdiv(L, 128) * n_kv_heads * B)), dim3(256), lds_dkv, st, a);
+    VGPT_CHECK_LAUNCH("vgpt_attn_blockmask_bwd");
+    return VGPT_OK;
+}

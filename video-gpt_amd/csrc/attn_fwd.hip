@@ -27,6 +27,7 @@ struct AttnArgs {
     bf16* o;
     const uint32_t* bits;
     const uint8_t* summary;
+    float* lse;  // optional (B, n_heads, L): base-2 log-sum-exp of the scaled scores, for the backward
     int B, L, n_heads, kv_group;  // kv_group = n_heads / n_kv_heads
     int W;                        // mask words per row
     int nqb, nkt;                 // 128-row q blocks, 64-key tiles
@@ -304,6 +305,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     }
 
     // ---- epilogue: lane holds O^T[d = 32dt + (i&3) + 8(i>>2) + 4h][q = r] ----
+    if (a.lse && q_row < a.L && h == 0)
+        a.lse[((int64_t)b * a.n_heads + head) * a.L + q_row] = l_i > 0.f ? m_i + __builtin_amdgcn_logf(l_i) : INFINITY;
     if (q_row < a.L) {
         const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
         bf16* op = a.o + (int64_t)b * a.o_sb + (int64_t)head * a.o_sh + (int64_t)q_row * a.o_ss;
@@ -344,13 +347,13 @@ VGPT_EXPORT int vgpt_attn_supported(int head_dim) {
     return head_dim == 64 || head_dim == 96 || head_dim == 128;
 }
 
-VGPT_EXPORT int vgpt_attn_blockmask_fwd(const void* q, const void* k, const void* v, void* o,
-                                        const uint32_t* bits, const uint8_t* summary, int64_t B,
-                                        int64_t L, int n_heads, int n_kv_heads, int head_dim,
-                                        int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
-                                        int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
-                                        int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
-                                        float scale, int variant, void* stream) {
+static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse,
+                         const uint32_t* bits, const uint8_t* summary, int64_t B,
+                         int64_t L, int n_heads, int n_kv_heads, int head_dim,
+                         int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
+                         int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
+                         int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
+                         float scale, int variant, void* stream) {
     VGPT_REQUIRE(q && k && v && o && bits && summary, VGPT_ERR_INVALID,
                  "vgpt_attn_blockmask_fwd: null pointer");
     VGPT_REQUIRE(B >= 0 && L >= 0 && n_heads > 0 && n_kv_heads > 0, VGPT_ERR_INVALID,
@@ -375,7 +378,7 @@ VGPT_EXPORT int vgpt_attn_blockmask_fwd(const void* q, const void* k, const void
     if (B == 0 || L == 0) return VGPT_OK;
     AttnArgs a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o;
-    a.bits = bits; a.summary = summary;
+    a.bits = bits; a.summary = summary; a.lse = lse;
     a.B = (int)B; a.L = (int)L; a.n_heads = n_heads; a.kv_group = n_heads / n_kv_heads;
     a.W = (int)cdiv(L, 32); a.nqb = (int)cdiv(L, 128); a.nkt = (int)cdiv(L, 64);
     a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
@@ -390,4 +393,30 @@ VGPT_EXPORT int vgpt_attn_blockmask_fwd(const void* q, const void* k, const void
     }
 #undef ATTN_CASE
     return VGPT_ERR_UNSUPPORTED;
+}
+
+VGPT_EXPORT int vgpt_attn_blockmask_fwd(const void* q, const void* k, const void* v, void* o,
+                                        const uint32_t* bits, const uint8_t* summary, int64_t B,
+                                        int64_t L, int n_heads, int n_kv_heads, int head_dim,
+                                        int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
+                                        int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
+                                        int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
+                                        float scale, int variant, void* stream) {
+    return attn_fwd_impl(q, k, v, o, nullptr, bits, summary, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
+                         k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, scale, variant, stream);
+}
+
+VGPT_EXPORT int vgpt_attn_blockmask_fwd_lse(const void* q, const void* k, const void* v, void* o, float* lse,
+                                            const uint32_t* bits, const uint8_t* summary, int64_t B,
+                                            int64_t L, int n_heads, int n_kv_heads, int head_dim,
+                                            int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
+                                            int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
+                                            int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
+                                            float scale, void* stream) {
+    if (!lse) {
+        vgpt_set_error("vgpt_attn_blockmask_fwd_lse: null lse");
+        return VGPT_ERR_INVALID;
+    }
+    return attn_fwd_impl(q, k, v, o, lse, bits, summary, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
+                         k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, scale, 0, stream);
 }

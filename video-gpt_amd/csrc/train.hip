@@ -1,0 +1,685 @@
+// Stage-1 pre-training step kernels: loss, element-wise backward passes, generic small matmul for the
+// heads, transposes that let every large backward GEMM run on the NT MFMA kernel, AdamW, gradient
+// norm / clipping.
+//
+// Reference: LVM/train_helper/loss.py:128-243 (xt mix, per-frame MSE), LVM/train/train_x1_stage1_noiseinput.py
+// :351-405 (backward, grad-norm, clip 1.0, AdamW step) — the reference gets every backward pass from
+// torch.autograd and the optimizer from DeepSpeed; here each is an explicit HIP kernel.
+//
+// Large backward GEMMs (dX = dY W, dW = dY^T X) reuse vgpt_gemm_bf16 (NT form) after a padded transpose:
+//   dX[M,K] = dY[M,N] (W^T)[K,N]^T            (transpose W once per use)
+//   dW[N,K] = (dY^T)[N,Mp] (X^T)[K,Mp]^T      (M zero-padded to a multiple of 64 inside the transposes)
+#include "common.h"
+
+namespace {
+
+// ---- (R, C) bf16 -> (C, Rp) bf16, zero columns for r >= R ---------------------------------------
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16* __restrict__ in, bf16* __restrict__ out,
+                                                            int R, int C, int Rp, int64_t ld_in) {
+    __shared__ bf16 tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty * 16 + i, c = c0 + tx;
+        tile[ty * 16 + i][tx] = (r < R && c < C) ? in[(int64_t)r * ld_in + c] : (bf16)0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty * 16 + i, r = r0 + tx;
+        if (c < C && r < Rp) out[(int64_t)c * Rp + r] = tile[tx][ty * 16 + i];
+    }
+}
+
+// ---- gated MLP activation, un-fused (training keeps gate/up for the backward) ---------------------
+__global__ __launch_bounds__(256) void silu_mul_fwd_kernel(const bf16* __restrict__ gu, bf16* __restrict__ act,
+                                                           int64_t M, int I, int actk) {
+    const int cpr = I >> 3;
+    const int64_t total = M * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / cpr;
+        const int c = (int)(i % cpr) * 8;
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + m * 2 * I + c);
+        const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + m * 2 * I + I + c);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(act_apply(bf2f(g[j]), actk) * bf2f(u[j]));
+        *reinterpret_cast<bf16x8*>(act + m * I + c) = o;
+    }
+}
+
+__device__ __forceinline__ float act_grad(float x, int actk) {
+    switch (actk) {
+        case VGPT_ACT_SILU: {
+            const float s = 1.0f / (1.0f + __expf(-x));
+            return s * (1.0f + x * (1.0f - s));
+        }
+        case VGPT_ACT_GELU: {
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+            return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+        }
+        case VGPT_ACT_GELU_TANH: {
+            const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+            const float t = tanhf(u);
+            return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+        }
+        default: return 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16* __restrict__ gu, const bf16* __restrict__ dact,
+                                                           bf16* __restrict__ dgu, int64_t M, int I, int actk) {
+    const int cpr = I >> 3;
+    const int64_t total = M * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / cpr;
+        const int c = (int)(i % cpr) * 8;
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + m * 2 * I + c);
+        const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + m * 2 * I + I + c);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dact + m * I + c);
+        bf16x8 dg, du;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gf = bf2f(g[j]), df = bf2f(d[j]);
+            dg[j] = f2bf(df * bf2f(u[j]) * act_grad(gf, actk));
+            du[j] = f2bf(df * act_apply(gf, actk));
+        }
+        *reinterpret_cast<bf16x8*>(dgu + m * 2 * I + c) = dg;
+        *reinterpret_cast<bf16x8*>(dgu + m * 2 * I + I + c) = du;
+    }
+}
+
+// y = act'(pre) * dy   (small MLP heads)
+__global__ void act_bwd_kernel(const bf16* __restrict__ pre, const bf16* __restrict__ dy, bf16* __restrict__ dx,
+                               int64_t n, int actk) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[i] = f2bf(bf2f(dy[i]) * act_grad(bf2f(pre[i]), actk));
+}
+__global__ void act_fwd_kernel(const bf16* __restrict__ pre, bf16* __restrict__ y, int64_t n, int actk) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = f2bf(act_apply(bf2f(pre[i]), actk));
+}
+
+// ---- RMSNorm backward: dx (+= dres), dw (fp32 atomics, one partial per block) ----------------------
+// y = w * (x * rstd):  g = w*dy ; dx = rstd*g - x*rstd^3/H * sum(g*x) ;  dw += dy * x*rstd
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                          const bf16* __restrict__ dy, const bf16* __restrict__ dres,
+                                                          bf16* __restrict__ dx, float* __restrict__ dw, int64_t rows,
+                                                          int H, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dwacc[NCH][8], wv[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int off = (c * 64 + lane) * 8;
+        bf16x8 wb;
+        if (off < H) wb = *reinterpret_cast<const bf16x8*>(w + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dwacc[c][j] = 0.f;
+            wv[c][j] = off < H ? bf2f(wb[j]) : 0.f;
+        }
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        float xv[NCH][8], dv[NCH][8];
+        float ss = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int off = (c * 64 + lane) * 8;
+            if (off < H) {
+                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(x + row * H + off);
+                const bf16x8 db = *reinterpret_cast<const bf16x8*>(dy + row * H + off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xv[c][j] = bf2f(xb[j]);
+                    dv[c][j] = bf2f(db[j]);
+                    ss += xv[c][j] * xv[c][j];
+                    sgx += dv[c][j] * wv[c][j] * xv[c][j];
+                }
+            }
+        }
+        ss = wave_sum(ss);
+        sgx = wave_sum(sgx);
+        const float rstd = rsqrtf(ss / (float)H + eps);
+        const float k = sgx * rstd * rstd * rstd / (float)H;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int off = (c * 64 + lane) * 8;
+            if (off < H) {
+                bf16x8 o, rb;
+                if (dres) rb = *reinterpret_cast<const bf16x8*>(dres + row * H + off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = rstd * dv[c][j] * wv[c][j] - xv[c][j] * k;
+                    if (dres) v += bf2f(rb[j]);
+                    o[j] = f2bf(v);
+                    dwacc[c][j] += dv[c][j] * xv[c][j] * rstd;
+                }
+                *reinterpret_cast<bf16x8*>(dx + row * H + off) = o;
+            }
+        }
+    }
+    // block reduction of dw over the 4 waves, then one atomic per column per block
+    __shared__ float red[4][64 * 8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int off = (c * 64 + lane) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = dwacc[c][j];
+        __syncthreads();
+        if (wave == 0 && off < H) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float s = red[0][lane * 8 + j] + red[1][lane * 8 + j] + red[2][lane * 8 + j] + red[3][lane * 8 + j];
+                atomicAdd(dw + off + j, s);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- generic strided matmul for the small heads: C = alpha * A B (+ C), one thread per output ------
+template <typename TA, typename TB, typename TC>
+__global__ __launch_bounds__(256) void matmul_generic_kernel(const TA* __restrict__ A, int64_t sa_m, int64_t sa_k,
+                                                             const TB* __restrict__ B, int64_t sb_k, int64_t sb_n,
+                                                             TC* __restrict__ C, int64_t sc_m, int64_t sc_n, int M, int N,
+                                                             int K, float alpha, int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx % N);  // n fastest: coalesced when sb_n == 1 / sc_n == 1
+    float acc = 0.f;
+    const TA* a = A + m * sa_m;
+    const TB* b = B + n * sb_n;
+    for (int k = 0; k < K; ++k) acc += (float)a[k * sa_k] * (float)b[k * sb_k];
+    acc *= alpha;
+    TC* c = C + m * sc_m + n * sc_n;
+    if (accumulate) acc += (float)*c;
+    *c = (TC)acc;
+}
+
+// ---- column sums: out[c] (+)= sum_r X[r][c] -------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ out, int64_t R, int C,
+                                                     int64_t ld, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int64_t r = 0; r < R; ++r) s += (float)X[r * ld + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---- loss -------------------------------------------------------------------------------------------
+// out[f] = t[f]*x1[f] + (1-t[f])*x0[f]   (LVM/train_helper/loss.py:175,186), fp32 in, bf16 out
+__global__ void lerp_frames_kernel(const float* __restrict__ x1, const float* __restrict__ x0,
+                                   const float* __restrict__ t, bf16* __restrict__ out, int64_t elems, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float tf = t[i / elems];
+    out[i] = f2bf(tf * x1[i] + (1.0f - tf) * x0[i]);
+}
+
+// loss[f] = mean((x1[f]-pred[f])^2) ; dpred = 2*(pred-x1)/(elems*n_frames)   (loss.py:209-218 + .mean())
+__global__ __launch_bounds__(256) void mse_frames_kernel(const bf16* __restrict__ pred, const float* __restrict__ x1,
+                                                         float* __restrict__ loss, bf16* __restrict__ dpred,
+                                                         int64_t elems, int n_frames) {
+    __shared__ float red[4];
+    const int f = blockIdx.x;
+    float s = 0.f;
+    const float gscale = 2.0f / ((float)elems * (float)n_frames);
+    for (int64_t i = threadIdx.x; i < elems; i += 256) {
+        const float d = bf2f(pred[f * elems + i]) - x1[f * elems + i];
+        s += d * d;
+        if (dpred) dpred[f * elems + i] = f2bf(d * gscale);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[f] = (red[0] + red[1] + red[2] + red[3]) / (float)elems;
+}
+
+// ---- final layer pieces (training): v = LN(x)*(1+scale)+shift with xhat saved ------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const bf16* __restrict__ hidden, const int32_t* __restrict__ src_row,
+                                                         const bf16* __restrict__ mod, bf16* __restrict__ v_out,
+                                                         float* __restrict__ xhat_out, float* __restrict__ rstd_out,
+                                                         int ntok, int H, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.y, t = blockIdx.x * 4 + wave;
+    if (t >= ntok) return;
+    const bf16* xr = hidden + ((int64_t)src_row[f] + t) * H;
+    const bf16* shift = mod + (int64_t)f * 2 * H;
+    const bf16* scale = shift + H;
+    const int64_t orow = ((int64_t)f * ntok + t);
+    float v[NCH][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int off = (c * 64 + lane) * 8;
+        if (off < H) {
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[c][j] = bf2f(xv[j]); s1 += v[c][j]; }
+        }
+    }
+    const float mean = wave_sum(s1) / (float)H;
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int off = (c * 64 + lane) * 8;
+        if (off < H) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; s2 += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)H + eps);
+    if (lane == 0) rstd_out[orow] = rstd;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int off = (c * 64 + lane) * 8;
+        if (off < H) {
+            const bf16x8 sh = *reinterpret_cast<const bf16x8*>(shift + off);
+            const bf16x8 sc = *reinterpret_cast<const bf16x8*>(scale + off);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (v[c][j] - mean) * rstd;
+                xhat_out[orow * H + off + j] = xh;
+                o[j] = f2bf(xh * (1.0f + bf2f(sc[j])) + bf2f(sh[j]));
+            }
+            *reinterpret_cast<bf16x8*>(v_out + orow * H + off) = o;
+        }
+    }
+}
+
+// backward of v = xhat*(1+scale)+shift, xhat = LN(x):
+//   dxhat = dv*(1+scale); dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)), scattered (added) into dhidden rows
+//   dshift[f] += dv ; dscale[f] += dv*xhat   (fp32 atomics, per frame)
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict__ dv, const float* __restrict__ xhat,
+                                                         const float* __restrict__ rstd_in, const bf16* __restrict__ mod,
+                                                         const int32_t* __restrict__ dst_row, bf16* __restrict__ dhidden,
+                                                         float* __restrict__ dmod, int ntok, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.y, t = blockIdx.x * 4 + wave;
+    if (t >= ntok) return;
+    const int64_t irow = ((int64_t)f * ntok + t);
+    const bf16* scale = mod + (int64_t)f * 2 * H + H;
+    float g[NCH][8], xh[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int off = (c * 64 + lane) * 8;
+        if (off < H) {
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dv + irow * H + off);
+            const bf16x8 sc = *reinterpret_cast<const bf16x8*>(scale + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float df = bf2f(d[j]);
+                xh[c][j] = xhat[irow * H + off + j];
+                g[c][j] = df * (1.0f + bf2f(sc[j]));
+                s1 += g[c][j];
+                s2 += g[c][j] * xh[c][j];
+                atomicAdd(dmod + (int64_t)f * 2 * H + off + j, df);               // dshift
+                atomicAdd(dmod + (int64_t)f * 2 * H + H + off + j, df * xh[c][j]);  // dscale
+            }
+        }
+    }
+    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+    const float rstd = rstd_in[irow];
+    bf16* o = dhidden + ((int64_t)dst_row[f] + t) * H;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int off = (c * 64 + lane) * 8;
+        if (off < H) {
+            bf16x8 ob;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ob[j] = f2bf(rstd * (g[c][j] - m1 - xh[c][j] * m2));
+            *reinterpret_cast<bf16x8*>(o + off) = ob;
+        }
+    }
+}
+
+// ---- embedding backward: dtable[ids[r]] += dseq[r] for rows flagged keep[r] != 0 (fp32 atomics) -------
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const uint8_t* __restrict__ keep,
+                                                        const bf16* __restrict__ dseq, float* __restrict__ dtable,
+                                                        int64_t rows, int H, int64_t vocab) {
+    const int64_t total = rows * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / H;
+        if (!keep[r]) continue;
+        const int64_t id = ids[r];
+        if (id < 0 || id >= vocab) continue;
+        atomicAdd(dtable + id * H + (i % H), bf2f(dseq[i]));
+    }
+}
+
+// ---- gather the 16-wide patch vectors of a frame stack: patches[f*ntok+t][e] (bf16) ------------------
+__global__ void patchify_kernel(const bf16* __restrict__ x, bf16* __restrict__ patches, int n_frames, int C, int h,
+                                int w) {
+    const int h2 = h >> 1, w2 = w >> 1, ntok = h2 * w2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n_frames * ntok * 16) return;
+    const int e = idx & 15;
+    const int64_t tt = idx >> 4;
+    const int t = (int)(tt % ntok), f = (int)(tt / ntok);
+    const int ci = e >> 2, p = (e >> 1) & 1, q = e & 1;
+    const int i = t / w2, j = t % w2;
+    patches[idx] = x[(((int64_t)f * C + ci) * h + 2 * i + p) * w + 2 * j + q];
+}
+
+// inverse of unpatchify on the gradient: dy16[f*ntok+t][(p*2+q)*C + c] = dpred[f][c][2i+p][2j+q]
+__global__ void unpatchify_bwd_kernel(const bf16* __restrict__ dpred, bf16* __restrict__ dy16, int n_frames, int C,
+                                      int h, int w) {
+    const int h2 = h >> 1, w2 = w >> 1, ntok = h2 * w2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n_frames * ntok * 16) return;
+    const int o = idx & 15;
+    const int64_t tt = idx >> 4;
+    const int t = (int)(tt % ntok), f = (int)(tt / ntok);
+    const int c = o % C, pq = o / C, p = pq >> 1, q = pq & 1;
+    const int i = t / w2, j = t % w2;
+    dy16[idx] = dpred[(((int64_t)f * C + c) * h + 2 * i + p) * w + 2 * j + q];
+}
+
+// gather rows: out[i] = in[row[i] + (i % per) ... ] — copies `per` consecutive rows per entry
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ in, const int32_t* __restrict__ row0,
+                                                          bf16* __restrict__ out, int n_seg, int per, int H) {
+    const int cpr = H >> 3;
+    const int64_t total = (int64_t)n_seg * per * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr);
+        const int64_t r = i / cpr;
+        const int seg = (int)(r / per), k = (int)(r % per);
+        *reinterpret_cast<bf16x8*>(out + r * H + c * 8) =
+            *reinterpret_cast<const bf16x8*>(in + ((int64_t)row0[seg] + k) * H + c * 8);
+    }
+}
+
+// ---- optimizer -----------------------------------------------------------------------------------------
+// sum of squares of a bf16 / fp32 gradient buffer into *out (fp32 atomic per block)
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ g, float* __restrict__ out, int64_t n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = (float)g[i];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// AdamW (torch.optim.AdamW semantics) on fp32 master weights; bf16 model copy refreshed.
+// grad_scale_ptr: device scalar multiplied into the gradient (clip coefficient / 1/world), may be NULL.
+template <typename TG>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, bf16* __restrict__ param,
+                                                    const TG* __restrict__ grad, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2,
+                                                    const float* __restrict__ grad_scale_ptr) {
+    const float gs = grad_scale_ptr ? *grad_scale_ptr : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = (float)grad[i] * gs;
+        float p = master[i];
+        p *= 1.0f - lr * wd;
+        const float mi = b1 * m[i] + (1.0f - b1) * g;
+        const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        p -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+        master[i] = p;
+        param[i] = f2bf(p);
+    }
+}
+
+// clip coefficient: coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)) * extra_scale
+__global__ void clip_coef_kernel(const float* sumsq, float* coef, float* norm_out, float max_norm, float extra) {
+    const float nrm = sqrtf(*sumsq);
+    if (norm_out) *norm_out = nrm;
+    float c = max_norm > 0.f ? max_norm / (nrm + 1e-6f) : 1.0f;
+    *coef = fminf(c, 1.0f) * extra;
+}
+
+template <int MAXN>
+int dispatch_nch(int nch) { return nch >= 1 && nch <= MAXN; }
+
+}  // namespace
+
+#define LAUNCH_OK(name) VGPT_CHECK_LAUNCH(name); return VGPT_OK
+
+VGPT_EXPORT int vgpt_transpose_pad_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t Rp, int64_t ld_in,
+                                        void* stream) {
+    VGPT_REQUIRE(in && out, VGPT_ERR_INVALID, "vgpt_transpose_pad_bf16: null pointer");
+    VGPT_REQUIRE(R > 0 && C > 0 && Rp >= R && ld_in >= C, VGPT_ERR_INVALID, "vgpt_transpose_pad_bf16: bad shape");
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)cdiv(Rp, 64)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16*)in, (bf16*)out, (int)R, (int)C, (int)Rp, ld_in);
+    LAUNCH_OK("vgpt_transpose_pad_bf16");
+}
+
+VGPT_EXPORT int vgpt_silu_mul_fwd(const void* gate_up, void* act_out, int64_t M, int64_t I, int act, void* stream) {
+    VGPT_REQUIRE(gate_up && act_out, VGPT_ERR_INVALID, "vgpt_silu_mul_fwd: null pointer");
+    VGPT_REQUIRE(M >= 0 && I > 0 && I % 8 == 0, VGPT_ERR_INVALID, "vgpt_silu_mul_fwd: bad shape");
+    if (M == 0) return VGPT_OK;
+    int grid = (int)std::min<int64_t>(cdiv(M * (I / 8), 256), 256 * 16);
+    hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)gate_up,
+                       (bf16*)act_out, M, (int)I, act);
+    LAUNCH_OK("vgpt_silu_mul_fwd");
+}
+
+VGPT_EXPORT int vgpt_silu_mul_bwd(const void* gate_up, const void* dact, void* dgate_up, int64_t M, int64_t I, int act,
+                                  void* stream) {
+    VGPT_REQUIRE(gate_up && dact && dgate_up, VGPT_ERR_INVALID, "vgpt_silu_mul_bwd: null pointer");
+    VGPT_REQUIRE(M >= 0 && I > 0 && I % 8 == 0, VGPT_ERR_INVALID, "vgpt_silu_mul_bwd: bad shape");
+    if (M == 0) return VGPT_OK;
+    int grid = (int)std::min<int64_t>(cdiv(M * (I / 8), 256), 256 * 16);
+    hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)gate_up,
+                       (const bf16*)dact, (bf16*)dgate_up, M, (int)I, act);
+    LAUNCH_OK("vgpt_silu_mul_bwd");
+}
+
+VGPT_EXPORT int vgpt_act_fwd(const void* pre, void* y, int64_t n, int act, void* stream) {
+    VGPT_REQUIRE(pre && y && n >= 0, VGPT_ERR_INVALID, "vgpt_act_fwd: bad argument");
+    if (n == 0) return VGPT_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)pre, (bf16*)y, n, act);
+    LAUNCH_OK("vgpt_act_fwd");
+}
+
+VGPT_EXPORT int vgpt_act_bwd(const void* pre, const void* dy, void* dx, int64_t n, int act, void* stream) {
+    VGPT_REQUIRE(pre && dy && dx && n >= 0, VGPT_ERR_INVALID, "vgpt_act_bwd: bad argument");
+    if (n == 0) return VGPT_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)pre, (const bf16*)dy, (bf16*)dx, n, act);
+    LAUNCH_OK("vgpt_act_bwd");
+}
+
+VGPT_EXPORT int vgpt_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dres, void* dx, float* dw,
+                                 int64_t rows, int64_t H, float eps, void* stream) {
+    VGPT_REQUIRE(x && w && dy && dx && dw, VGPT_ERR_INVALID, "vgpt_rmsnorm_bwd: null pointer");
+    VGPT_REQUIRE(rows >= 0 && H > 0 && H % 8 == 0 && H <= 4096, VGPT_ERR_UNSUPPORTED,
+                 "vgpt_rmsnorm_bwd: H must be a multiple of 8 and <= 4096");
+    if (rows == 0) return VGPT_OK;
+    int grid = (int)std::min<int64_t>(cdiv(rows, 4), 256 * 4);
+    hipStream_t s = (hipStream_t)stream;
+#define RB_CASE(N)                                                                                                \
+    case N:                                                                                                       \
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(grid), dim3(256), 0, s, (const bf16*)x, (const bf16*)w,    \
+                           (const bf16*)dy, (const bf16*)dres, (bf16*)dx, dw, rows, (int)H, eps);                 \
+        break;
+    switch ((int)cdiv(H, 512)) { RB_CASE(1) RB_CASE(2) RB_CASE(3) RB_CASE(4) RB_CASE(5) RB_CASE(6) RB_CASE(7) RB_CASE(8) }
+#undef RB_CASE
+    LAUNCH_OK("vgpt_rmsnorm_bwd");
+}
+
+VGPT_EXPORT int vgpt_matmul_generic(const void* A, int a_f32, int64_t sa_m, int64_t sa_k, const void* B, int b_f32,
+                                    int64_t sb_k, int64_t sb_n, void* C, int c_f32, int64_t sc_m, int64_t sc_n,
+                                    int64_t M, int64_t N, int64_t K, float alpha, int accumulate, void* stream) {
+    VGPT_REQUIRE(A && B && C, VGPT_ERR_INVALID, "vgpt_matmul_generic: null pointer");
+    VGPT_REQUIRE(M >= 0 && N >= 0 && K >= 0 && M * N < (1ll << 40), VGPT_ERR_INVALID, "vgpt_matmul_generic: bad shape");
+    if (M == 0 || N == 0) return VGPT_OK;
+    dim3 grid((unsigned)cdiv(M * N, 256));
+    hipStream_t s = (hipStream_t)stream;
+#define MG(TA, TB, TC)                                                                                              \
+    hipLaunchKernelGGL((matmul_generic_kernel<TA, TB, TC>), grid, dim3(256), 0, s, (const TA*)A, sa_m, sa_k,        \
+                       (const TB*)B, sb_k, sb_n, (TC*)C, sc_m, sc_n, (int)M, (int)N, (int)K, alpha, accumulate)
+    const int key = (a_f32 ? 4 : 0) | (b_f32 ? 2 : 0) | (c_f32 ? 1 : 0);
+    switch (key) {
+        case 0: MG(bf16, bf16, bf16); break;
+        case 1: MG(bf16, bf16, float); break;
+        case 2: MG(bf16, float, bf16); break;
+        case 3: MG(bf16, float, float); break;
+        case 4: MG(float, bf16, bf16); break;
+        case 5: MG(float, bf16, float); break;
+        case 6: MG(float, float, bf16); break;
+        default: MG(float, float, float); break;
+    }
+#undef MG
+    LAUNCH_OK("vgpt_matmul_generic");
+}
+
+VGPT_EXPORT int vgpt_colsum(const void* X, int x_f32, float* out, int64_t R, int64_t C, int64_t ld, int accumulate,
+                            void* stream) {
+    VGPT_REQUIRE(X && out && R >= 0 && C > 0, VGPT_ERR_INVALID, "vgpt_colsum: bad argument");
+    dim3 grid((unsigned)cdiv(C, 256));
+    if (x_f32)
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, out, R,
+                           (int)C, ld, accumulate);
+    else
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)X, out, R, (int)C,
+                           ld, accumulate);
+    LAUNCH_OK("vgpt_colsum");
+}
+
+VGPT_EXPORT int vgpt_lerp_frames(const float* x1, const float* x0, const float* t, void* out, int n_frames,
+                                 int64_t elems, void* stream) {
+    VGPT_REQUIRE(x1 && x0 && t && out && n_frames >= 0 && elems > 0, VGPT_ERR_INVALID, "vgpt_lerp_frames: bad argument");
+    if (n_frames == 0) return VGPT_OK;
+    const int64_t total = n_frames * elems;
+    hipLaunchKernelGGL(lerp_frames_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x1, x0, t,
+                       (bf16*)out, elems, total);
+    LAUNCH_OK("vgpt_lerp_frames");
+}
+
+VGPT_EXPORT int vgpt_mse_frames(const void* pred, const float* x1, float* loss, void* dpred, int n_frames,
+                                int64_t elems, void* stream) {
+    VGPT_REQUIRE(pred && x1 && loss && n_frames >= 0 && elems > 0, VGPT_ERR_INVALID, "vgpt_mse_frames: bad argument");
+    if (n_frames == 0) return VGPT_OK;
+    hipLaunchKernelGGL(mse_frames_kernel, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, (const bf16*)pred, x1, loss,
+                       (bf16*)dpred, elems, n_frames);
+    LAUNCH_OK("vgpt_mse_frames");
+}
+
+VGPT_EXPORT int vgpt_ln_mod_fwd(const void* hidden, const int32_t* src_row, const void* mod, void* v_out,
+                                float* xhat_out, float* rstd_out, int n_frames, int ntok, int64_t H, float eps,
+                                void* stream) {
+    VGPT_REQUIRE(hidden && src_row && mod && v_out && xhat_out && rstd_out, VGPT_ERR_INVALID, "vgpt_ln_mod_fwd: null pointer");
+    VGPT_REQUIRE(n_frames >= 0 && ntok > 0 && H % 8 == 0 && H <= 4096, VGPT_ERR_UNSUPPORTED, "vgpt_ln_mod_fwd: bad shape");
+    if (n_frames == 0) return VGPT_OK;
+    dim3 grid((unsigned)cdiv(ntok, 4), n_frames);
+    hipStream_t s = (hipStream_t)stream;
+#define LF_CASE(N)                                                                                              \
+    case N:                                                                                                     \
+        hipLaunchKernelGGL(ln_mod_fwd_kernel<N>, grid, dim3(256), 0, s, (const bf16*)hidden, src_row,           \
+                           (const bf16*)mod, (bf16*)v_out, xhat_out, rstd_out, ntok, (int)H, eps);              \
+        break;
+    switch ((int)cdiv(H, 512)) { LF_CASE(1) LF_CASE(2) LF_CASE(3) LF_CASE(4) LF_CASE(5) LF_CASE(6) LF_CASE(7) LF_CASE(8) }
+#undef LF_CASE
+    LAUNCH_OK("vgpt_ln_mod_fwd");
+}
+
+VGPT_EXPORT int vgpt_ln_mod_bwd(const void* dv, const float* xhat, const float* rstd, const void* mod,
+                                const int32_t* dst_row, void* dhidden, float* dmod, int n_frames, int ntok, int64_t H,
+                                void* stream) {
+    VGPT_REQUIRE(dv && xhat && rstd && mod && dst_row && dhidden && dmod, VGPT_ERR_INVALID, "vgpt_ln_mod_bwd: null pointer");
+    VGPT_REQUIRE(n_frames >= 0 && ntok > 0 && H % 8 == 0 && H <= 4096, VGPT_ERR_UNSUPPORTED, "vgpt_ln_mod_bwd: bad shape");
+    if (n_frames == 0) return VGPT_OK;
+    dim3 grid((unsigned)cdiv(ntok, 4), n_frames);
+    hipStream_t s = (hipStream_t)stream;
+#define LB_CASE(N)                                                                                              \
+    case N:                                                                                                     \
+        hipLaunchKernelGGL(ln_mod_bwd_kernel<N>, grid, dim3(256), 0, s, (const bf16*)dv, xhat, rstd,            \
+                           (const bf16*)mod, dst_row, (bf16*)dhidden, dmod, ntok, (int)H);                      \
+        break;
+    switch ((int)cdiv(H, 512)) { LB_CASE(1) LB_CASE(2) LB_CASE(3) LB_CASE(4) LB_CASE(5) LB_CASE(6) LB_CASE(7) LB_CASE(8) }
+#undef LB_CASE
+    LAUNCH_OK("vgpt_ln_mod_bwd");
+}
+
+VGPT_EXPORT int vgpt_embed_bwd(const int64_t* ids, const uint8_t* keep, const void* dseq, float* dtable, int64_t rows,
+                               int64_t H, int64_t vocab, void* stream) {
+    VGPT_REQUIRE(ids && keep && dseq && dtable && rows >= 0 && H > 0, VGPT_ERR_INVALID, "vgpt_embed_bwd: bad argument");
+    if (rows == 0) return VGPT_OK;
+    int grid = (int)std::min<int64_t>(cdiv(rows * H, 256), 256 * 16);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, keep, (const bf16*)dseq,
+                       dtable, rows, (int)H, vocab);
+    LAUNCH_OK("vgpt_embed_bwd");
+}
+
+VGPT_EXPORT int vgpt_patchify(const void* x, void* patches, int n_frames, int C, int h, int w, void* stream) {
+    VGPT_REQUIRE(x && patches && n_frames >= 0 && C * 4 == 16 && h % 2 == 0 && w % 2 == 0, VGPT_ERR_INVALID,
+                 "vgpt_patchify: bad argument");
+    if (n_frames == 0) return VGPT_OK;
+    const int64_t total = (int64_t)n_frames * (h / 2) * (w / 2) * 16;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, (bf16*)patches, n_frames, C, h, w);
+    LAUNCH_OK("vgpt_patchify");
+}
+
+VGPT_EXPORT int vgpt_unpatchify_bwd(const void* dpred, void* dy16, int n_frames, int C, int h, int w, void* stream) {
+    VGPT_REQUIRE(dpred && dy16 && n_frames >= 0 && C * 4 == 16 && h % 2 == 0 && w % 2 == 0, VGPT_ERR_INVALID,
+                 "vgpt_unpatchify_bwd: bad argument");
+    if (n_frames == 0) return VGPT_OK;
+    const int64_t total = (int64_t)n_frames * (h / 2) * (w / 2) * 16;
+    hipLaunchKernelGGL(unpatchify_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)dpred, (bf16*)dy16, n_frames, C, h, w);
+    LAUNCH_OK("vgpt_unpatchify_bwd");
+}
+
+VGPT_EXPORT int vgpt_gather_rows(const void* in, const int32_t* row0, void* out, int n_seg, int per, int64_t H,
+                                 void* stream) {
+    VGPT_REQUIRE(in && row0 && out && n_seg >= 0 && per > 0 && H % 8 == 0, VGPT_ERR_INVALID, "vgpt_gather_rows: bad argument");
+    if (n_seg == 0) return VGPT_OK;
+    int grid = (int)std::min<int64_t>(cdiv((int64_t)n_seg * per * (H / 8), 256), 256 * 16);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, row0,
+                       (bf16*)out, n_seg, per, (int)H);
+    LAUNCH_OK("vgpt_gather_rows");
+}
+
+VGPT_EXPORT int vgpt_sumsq(const void* g, int g_f32, float* out, int64_t n, void* stream) {
+    VGPT_REQUIRE(g && out && n >= 0, VGPT_ERR_INVALID, "vgpt_sumsq: bad argument");
+    if (n == 0) return VGPT_OK;
+    int grid = (int)std::min<int64_t>(cdiv(n, 256 * 8), 1024);
+    if (g_f32)
+        hipLaunchKernelGGL(sumsq_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)g, out, n);
+    else
+        hipLaunchKernelGGL(sumsq_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, out, n);
+    LAUNCH_OK("vgpt_sumsq");
+}
+
+VGPT_EXPORT int vgpt_clip_coef(const float* sumsq, float* coef, float* norm_out, float max_norm, float extra_scale,
+                               void* stream) {
+    VGPT_REQUIRE(sumsq && coef, VGPT_ERR_INVALID, "vgpt_clip_coef: null pointer");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, coef, norm_out, max_norm,
+                       extra_scale);
+    LAUNCH_OK("vgpt_clip_coef");
+}
+
+VGPT_EXPORT int vgpt_adamw_step(float* master, void* param, const void* grad, int grad_f32, float* m, float* v,
+                                int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                const float* grad_scale, void* stream) {
+    VGPT_REQUIRE(master && param && grad && m && v, VGPT_ERR_INVALID, "vgpt_adamw_step: null pointer");
+    VGPT_REQUIRE(n >= 0 && step >= 1, VGPT_ERR_INVALID, "vgpt_adamw_step: bad argument");
+    if (n == 0) return VGPT_OK;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    int grid = (int)std::min<int64_t>(cdiv(n, 256), 256 * 16);
+    if (grad_f32)
+        hipLaunchKernelGGL(adamw_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, master, (bf16*)param,
+                           (const float*)grad, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    else
+        hipLaunchKernelGGL(adamw_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, master, (bf16*)param,
+                           (const bf16*)grad, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    LAUNCH_OK("vgpt_adamw_step");
+}

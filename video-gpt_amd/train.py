@@ -1,0 +1,320 @@
+"""Stage-1 pre-training step on the HIP path: forward with saved activations, per-frame MSE on x1,
+explicit backward, gradient all-reduce (RCCL) overlapped with the backward, global-norm clipping and AdamW.
+
+Mirrors the reference's hot loop (LVM/train/train_x1_stage1_noiseinput.py:351-405) and loss
+(LVM/train_helper/loss.py:128-243, `training_losses_x1_noise_input`):
+    xt = t*x1 + (1-t)*x0 per frame, clean inputs noised with t_in in [input_noise, 1]; pred = model(xt, t, ...);
+    loss_i = mean((x1_i - pred_i)^2); loss.mean().backward(); clip_grad_norm_(1.0); AdamW(lr, weight_decay).step()
+The reference delegates backward to torch.autograd, the gradient reduction to DeepSpeed ZeRO-2 and the
+optimizer to DeepSpeed's bf16 AdamW (fp32 master weights).  Here:
+  * every backward pass is a HIP kernel (ops_train.py); the big dX / dW products reuse the MFMA NT GEMM
+    through padded transposes, attention has its own dQ / dKdV kernels;
+  * data parallelism replicates the model (288 GB HBM holds params + fp32 master + Adam moments, ~60 GB
+    at Phi-3-mini size; no ZeRO sharding) and all-reduces one flat bf16 gradient bucket per decoder
+    layer (226 MB at full size) as soon as that layer's backward has produced it, on RCCL's stream,
+    while the next layer's backward runs; the small fp32 gradients go in one last bucket;
+  * clipping uses the norm of the averaged gradient; the 1/world factor and the clip coefficient are
+    folded into the AdamW kernel's gradient scale (no separate pass over the gradients).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from . import ops_train as T
+from .engine import _rows, count_left_pads, pack_left_padded
+from .ops import BF16, VgptError
+
+F32 = torch.float32
+
+
+class Stage1Trainer:
+    def __init__(self, model, lr: float = 1e-4, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
+                 max_grad_norm: Optional[float] = 1.0, input_noise: float = 0.9, pack_padding: bool = True):
+        model._check_ready()
+        self.model = model
+        self.cfg = model.llm.config
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.max_grad_norm = max_grad_norm
+        self.input_noise = input_noise
+        self.pack_padding = pack_padding
+        self.dev = model.llm.norm.weight.device
+        self.step_count = 0
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.params = {n: p for n, p in model.named_parameters()}
+        L = self.cfg.num_hidden_layers
+        # ---- gradient storage: one flat bf16 bucket per decoder layer + one fp32 bucket for the rest ----
+        self.layer_names = [[f"llm.layers.{i}.self_attn.qkv_proj.weight", f"llm.layers.{i}.self_attn.o_proj.weight",
+                             f"llm.layers.{i}.mlp.gate_up_proj.weight", f"llm.layers.{i}.mlp.down_proj.weight"]
+                            for i in range(L)]
+        self.grads: Dict[str, torch.Tensor] = {}
+        self.layer_buckets = []
+        for names in self.layer_names:
+            n = sum(self.params[k].numel() for k in names)
+            flat = torch.zeros(n, dtype=BF16, device=self.dev)
+            o = 0
+            for k in names:
+                sz = self.params[k].numel()
+                self.grads[k] = flat[o:o + sz].view(self.params[k].shape)
+                o += sz
+            self.layer_buckets.append(flat)
+        big = {k for names in self.layer_names for k in names}
+        small = [k for k in self.params if k not in big]
+        n_small = sum(self.params[k].numel() for k in small)
+        self.small_bucket = torch.zeros(n_small, dtype=F32, device=self.dev)
+        o = 0
+        for k in small:
+            sz = self.params[k].numel()
+            self.grads[k] = self.small_bucket[o:o + sz].view(self.params[k].shape)
+            o += sz
+        # ---- optimizer state (fp32 master + moments), flat per bucket so AdamW is one launch per bucket ----
+        def flat_params(names):
+            return torch.cat([self.params[k].detach().reshape(-1).to(F32) for k in names])
+        self.master_layers = [flat_params(names) for names in self.layer_names]
+        self.master_small = flat_params(small)
+        self.small_names = small
+        z = lambda t: torch.zeros_like(t)
+        self.m_layers = [z(t) for t in self.master_layers]
+        self.v_layers = [z(t) for t in self.master_layers]
+        self.m_small, self.v_small = z(self.master_small), z(self.master_small)
+        # model parameters become views of flat bf16 buffers so the optimizer writes them in one launch
+        self.param_layers = []
+        for names in self.layer_names:
+            flat = torch.cat([self.params[k].detach().reshape(-1) for k in names]).contiguous()
+            o = 0
+            for k in names:
+                sz = self.params[k].numel()
+                self.params[k].data = flat[o:o + sz].view(self.params[k].shape)
+                o += sz
+            self.param_layers.append(flat)
+        flat = torch.cat([self.params[k].detach().reshape(-1) for k in small]).contiguous()
+        o = 0
+        for k in small:
+            sz = self.params[k].numel()
+            self.params[k].data = flat[o:o + sz].view(self.params[k].shape)
+            o += sz
+        self.param_small = flat
+        self.sumsq = torch.zeros(1, dtype=F32, device=self.dev)
+        self.coef = torch.ones(1, dtype=F32, device=self.dev)
+        self.grad_norm = torch.zeros(1, dtype=F32, device=self.dev)
+        self._ws = {}
+        self.last = {}
+
+    # ------------------------------------------------------------------------------------------------
+    def _buf(self, name, shape, dtype=BF16):
+        t = self._ws.get(name)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = torch.empty(*shape, dtype=dtype, device=self.dev)
+            self._ws[name] = t
+        return t
+
+    def _prepare(self, batch):
+        cfg = self.cfg
+        ids, pos, mask = batch["input_ids"], batch["position_ids"], batch["attention_mask"]
+        B, L = ids.shape
+        row_of = lambda b, s: b * L + s
+        pads = count_left_pads(mask) if self.pack_padding else []
+        if any(pads):
+            ids, pos, mask, offs = pack_left_padded(ids, pos, mask, pads)
+            row_of = lambda b, s: offs[b] + s - pads[b]
+            B, L = ids.shape
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=self.dev)
+        x_rows = _rows(batch["denoise_image_sizes"], row_of, True)
+        t_rows = _rows(batch["time_emb_inx"], row_of, False)
+        c_rows = _rows(batch["input_image_sizes"], row_of, True)
+        ntok_x = batch_ntok(batch["denoise_image_sizes"])
+        keep = torch.ones(B * L, dtype=torch.uint8)
+        for r0 in x_rows + c_rows:
+            keep[r0:r0 + ntok_x] = 0
+        for r0 in t_rows:
+            keep[r0] = 0
+        return dict(ids=ids.contiguous(), B=B, L=L, pm=ops.pack_mask(mask), rope=self.model.llm.rope_tables(pos),
+                    x_rows=i32(x_rows), t_rows=i32(t_rows), c_rows=i32(c_rows) if c_rows else None,
+                    keep=keep.to(self.dev), ntok=ntok_x)
+
+    # ------------------------------------------------------------------------------------------------
+    def step(self, batch, x1: torch.Tensor, x0: torch.Tensor, t: torch.Tensor, clean: Optional[torch.Tensor],
+             x0_in: Optional[torch.Tensor], t_in: Optional[torch.Tensor], update: bool = True):
+        """One optimisation step.  x1/x0: (F, C, h, w) fp32 target latents / noise, t: (F,) fp32;
+        clean/x0_in/t_in: the clean-frame latents and their noise (loss.py:166-192).  Returns the per-frame losses."""
+        m, cfg = self.model, self.cfg
+        prep = self._prepare(batch)
+        B, L, M, H, I = prep["B"], prep["L"], prep["B"] * prep["L"], cfg.hidden_size, cfg.intermediate_size
+        nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        nl = cfg.num_hidden_layers
+        nf, C, h, w = x1.shape
+        ntok = prep["ntok"]
+        Tn = nf * ntok
+        x1 = x1.to(self.dev, F32).contiguous(); x0 = x0.to(self.dev, F32).contiguous()
+        t = t.to(self.dev, F32).contiguous()
+        # ---------------- forward ----------------
+        xt = T.lerp_frames(x1, x0, t, self._buf("xt", (nf, C, h, w)))
+        cl = None
+        if clean is not None and clean.shape[0] > 0:
+            cl = T.lerp_frames(clean.to(self.dev, F32).contiguous(), x0_in.to(self.dev, F32).contiguous(),
+                               t_in.to(self.dev, F32).contiguous(), self._buf("cl", tuple(clean.shape)))
+        hbuf = self._buf("h", (nl + 1, M, H))          # layer inputs (h[l]) and the last output
+        seq = hbuf[0]
+        ops.embed_gather(prep["ids"], m.llm.embed_tokens.weight, out=seq.view(B, L, H))
+        pos = m.pos_embed[0]
+        if cl is not None:
+            ops.patch_embed(cl, m.input_x_embedder.proj.weight, m.input_x_embedder.proj.bias, pos, prep["c_rows"], seq,
+                            m.pos_embed_max_size)
+        sin = ops.timestep_sinusoid(t, m.time_token.freqs(self.dev))
+        tt, te, ada = m.time_token.mlp, m.t_embedder.mlp, m.final_layer.adaLN_modulation[1]
+        tt_pre = ops.linear_small(sin, tt[0].weight, tt[0].bias)
+        tt_act = T.act_fwd(tt_pre, ops.ACT_SILU)
+        ops.linear_small(tt_act, tt[2].weight, tt[2].bias, out=seq, out_row=prep["t_rows"], ldo=H)
+        ops.patch_embed(xt, m.x_embedder.proj.weight, m.x_embedder.proj.bias, pos, prep["x_rows"], seq,
+                        m.pos_embed_max_size)
+        n1 = self._buf("n1", (nl, M, H)); qkv = self._buf("qkv", (nl, M, (nq + 2 * nk) * hd))
+        ctx = self._buf("ctx", (nl, M, nq * hd)); h2 = self._buf("h2", (nl, M, H)); n2 = self._buf("n2", (nl, M, H))
+        gu = self._buf("gu", (nl, M, 2 * I)); act = self._buf("act", (nl, M, I))
+        lse = self._buf("lse", (nl, B, nq, L), F32)
+        for li, layer in enumerate(m.llm.layers):
+            at, mlp = layer.self_attn, layer.mlp
+            ops.rmsnorm(hbuf[li], layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=n1[li])
+            ops.linear(n1[li], at.qkv_proj.weight, out=qkv[li])
+            ops.rope_qk_inplace(qkv[li], prep["rope"][0], prep["rope"][1], nq, nk, hd)
+            T.attention_qkv_train(qkv[li].view(B, L, -1), prep["pm"], nq, nk, hd, ctx[li].view(B, L, -1), lse[li])
+            ops.linear(ctx[li], at.o_proj.weight, residual=hbuf[li], out=h2[li])
+            ops.rmsnorm(h2[li], layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon,
+                        out=n2[li])
+            ops.linear(n2[li], mlp.gate_up_proj.weight, out=gu[li])
+            T.silu_mul_fwd(gu[li], act[li], mlp.act)
+            ops.linear(act[li], mlp.down_proj.weight, residual=h2[li], out=hbuf[li + 1])
+        nrm = ops.rmsnorm(hbuf[nl], m.llm.norm.weight, m.llm.norm.variance_epsilon, out=self._buf("nrm", (M, H)))
+        te_pre = ops.linear_small(sin, te[0].weight, te[0].bias)
+        te_act = T.act_fwd(te_pre, ops.ACT_SILU)
+        temb = ops.linear_small(te_act, te[2].weight, te[2].bias)
+        st = T.act_fwd(temb, ops.ACT_SILU)
+        mod = ops.linear_small(st, ada.weight, ada.bias)
+        v = self._buf("v", (Tn, H)); xhat = self._buf("xhat", (Tn, H), F32); rstd = self._buf("rstd", (Tn,), F32)
+        T.ln_mod_fwd(nrm, prep["x_rows"], mod, v, xhat, rstd, ntok)
+        fl = m.final_layer.linear
+        y16 = ops.linear(v, fl.weight, bias=fl.bias)                       # (Tn, 16)
+        p2 = m.patch_size
+        pred = y16.view(nf, h // p2, w // p2, p2, p2, C).permute(0, 5, 1, 3, 2, 4).reshape(nf, C, h, w).contiguous()
+        loss = torch.empty(nf, dtype=F32, device=self.dev)
+        dpred = self._buf("dpred", (nf, C, h, w))
+        T.mse_frames(pred, x1, loss, dpred)
+        self.last = dict(pred=pred, loss=loss, xt=xt)
+        if not update and not self._want_grads:
+            return loss
+        # ---------------- backward ----------------
+        g = self.grads
+        self.small_bucket.zero_()
+        dy16 = T.unpatchify_bwd(dpred)                                      # (Tn, 16)
+        T.matmul(dy16, v, out=g["final_layer.linear.weight"], ta=True)     # dWf = dy16^T v
+        T.colsum(dy16, g["final_layer.linear.bias"])
+        dv = T.matmul(dy16, fl.weight)                                      # (Tn, H)
+        dnrm = self._buf("dnrm", (M, H)); dnrm.zero_()
+        dmod = torch.zeros(nf, 2 * H, dtype=F32, device=self.dev)
+        T.ln_mod_bwd(dv, xhat, rstd, mod, prep["x_rows"], dnrm, dmod, ntok)
+        dh = self._buf("dh", (M, H)); dh_b = self._buf("dh_b", (M, H))
+        T.rmsnorm_bwd(hbuf[nl], m.llm.norm.weight, dnrm, dh, g["llm.norm.weight"], m.llm.norm.variance_epsilon)
+        # adaLN + t_embedder
+        T.matmul(dmod, st, out=g["final_layer.adaLN_modulation.1.weight"], ta=True)
+        T.colsum(dmod, g["final_layer.adaLN_modulation.1.bias"])
+        dtemb = T.act_bwd(temb, T.matmul(dmod, ada.weight), ops.ACT_SILU)
+        self._mlp_bwd("t_embedder", te, dtemb, te_act, te_pre, sin)
+        # decoder layers, last to first
+        sw = self._buf("sw", (max(2 * I, (nq + 2 * nk) * hd) * max(H, I),))           # W^T scratch
+        Mp = (M + 63) // 64 * 64
+        sa = self._buf("sa", (max(2 * I, (nq + 2 * nk) * hd) * Mp,))                    # dY^T scratch
+        sb = self._buf("sb", (max(H, I) * Mp,))                                         # X^T scratch
+        dact = self._buf("dact", (M, I)); dgu = self._buf("dgu", (M, 2 * I)); dn = self._buf("dn", (M, H))
+        dctx = self._buf("dctx", (M, nq * hd)); dqkv = self._buf("dqkv", (M, (nq + 2 * nk) * hd))
+        delta = self._buf("delta", (B, nq, L), F32)
+        nsin = self._neg_sin(prep)
+        handles = []
+        for li in range(nl - 1, -1, -1):
+            layer = m.llm.layers[li]
+            at, mlp = layer.self_attn, layer.mlp
+            names = self.layer_names[li]
+            T.linear_dw(dh, act[li], sa, sb, g[names[3]])                               # dW_down
+            T.linear_dx(dh, mlp.down_proj.weight, sw, out=dact)
+            T.silu_mul_bwd(gu[li], dact, dgu, mlp.act)
+            T.linear_dw(dgu, n2[li], sa, sb, g[names[2]])                               # dW_gate_up
+            T.linear_dx(dgu, mlp.gate_up_proj.weight, sw, out=dn)
+            T.rmsnorm_bwd(h2[li], layer.post_attention_layernorm.weight, dn, dh_b,
+                          g[f"llm.layers.{li}.post_attention_layernorm.weight"],
+                          layer.post_attention_layernorm.variance_epsilon, dres=dh)       # dh2
+            T.linear_dw(dh_b, ctx[li], sa, sb, g[names[1]])                             # dW_o
+            T.linear_dx(dh_b, at.o_proj.weight, sw, out=dctx)
+            T.attention_qkv_bwd(qkv[li].view(B, L, -1), ctx[li].view(B, L, -1), dctx.view(B, L, -1), lse[li], delta,
+                                dqkv.view(B, L, -1), prep["pm"], nq, nk, hd)
+            ops.rope_qk_inplace(dqkv, prep["rope"][0], nsin, nq, nk, hd)                 # inverse rotation
+            T.linear_dw(dqkv, n1[li], sa, sb, g[names[0]])                              # dW_qkv
+            T.linear_dx(dqkv, at.qkv_proj.weight, sw, out=dn)
+            T.rmsnorm_bwd(hbuf[li], layer.input_layernorm.weight, dn, dh,
+                          g[f"llm.layers.{li}.input_layernorm.weight"], layer.input_layernorm.variance_epsilon,
+                          dres=dh_b)                                                     # dh (layer input)
+            if self.world > 1:
+                handles.append(dist.all_reduce(self.layer_buckets[li], async_op=True))
+        # heads fed by dseq = dh
+        dseq = dh
+        dtt = T.gather_rows(dseq, prep["t_rows"], 1)
+        self._mlp_bwd("time_token", tt, dtt, tt_act, tt_pre, sin)
+        self._patch_bwd("x_embedder", T.gather_rows(dseq, prep["x_rows"], ntok), xt)
+        if cl is not None:
+            self._patch_bwd("input_x_embedder", T.gather_rows(dseq, prep["c_rows"], ntok), cl)
+        T.embed_bwd(prep["ids"].view(-1), prep["keep"], dseq, g["llm.embed_tokens.weight"])
+        if self.world > 1:
+            handles.append(dist.all_reduce(self.small_bucket, async_op=True))
+            for hd_ in handles:
+                hd_.wait()
+        if update:
+            self.optimizer_step()
+        return loss
+
+    _want_grads = True
+
+    def _neg_sin(self, prep):
+        key = ("nsin", prep["rope"][1].data_ptr())
+        if self._ws.get("nsin_key") != key:
+            self._ws["nsin"] = (-prep["rope"][1]).contiguous()   # sign flip of a table: data prep, once per layout
+            self._ws["nsin_key"] = key
+        return self._ws["nsin"]
+
+    def _mlp_bwd(self, prefix, mlp, dout, act_saved, pre_saved, x_in):
+        """2-layer MLP (Linear, SiLU, Linear) backward: LVM/model.py:32-36."""
+        g = self.grads
+        T.matmul(dout, act_saved, out=g[f"{prefix}.mlp.2.weight"], ta=True)
+        T.colsum(dout, g[f"{prefix}.mlp.2.bias"])
+        dpre = T.act_bwd(pre_saved, T.matmul(dout, mlp[2].weight), ops.ACT_SILU)
+        T.matmul(dpre, x_in, out=g[f"{prefix}.mlp.0.weight"], ta=True)
+        T.colsum(dpre, g[f"{prefix}.mlp.0.bias"])
+
+    def _patch_bwd(self, prefix, dtok, latents):
+        g = self.grads
+        patches = T.patchify(latents)
+        T.matmul(dtok, patches, out=g[f"{prefix}.proj.weight"].view(-1, 16), ta=True)
+        T.colsum(dtok, g[f"{prefix}.proj.bias"])
+
+    # ------------------------------------------------------------------------------------------------
+    def optimizer_step(self):
+        self.step_count += 1
+        self.sumsq.zero_()
+        for b in self.layer_buckets:
+            T.sumsq(b, self.sumsq)
+        T.sumsq(self.small_bucket, self.sumsq)
+        w = float(self.world)
+        # norm of the AVERAGED gradient = norm(sum)/world; coefficient already carries the 1/world factor
+        T.clip_coef(self.sumsq, self.coef, self.grad_norm, (self.max_grad_norm or 0.0) * w, 1.0 / w)
+        b1, b2 = self.betas
+        for i in range(len(self.layer_buckets)):
+            T.adamw_step(self.master_layers[i], self.param_layers[i], self.layer_buckets[i], self.m_layers[i],
+                         self.v_layers[i], self.lr, b1, b2, self.eps, self.wd, self.step_count, self.coef)
+        T.adamw_step(self.master_small, self.param_small, self.small_bucket, self.m_small, self.v_small, self.lr, b1, b2,
+                     self.eps, self.wd, self.step_count, self.coef)
+
+
+def batch_ntok(sizes) -> int:
+    ns = {e - s for v in sizes.values() for s, e in v}
+    if len(ns) != 1:
+        raise VgptError("Stage1Trainer needs frames of one resolution")
+    return ns.pop()
