@@ -83,6 +83,63 @@ def cpu_baseline(cfg_full, batch, layers_sample=2):
                       "to one denoise step (embedders/final layer/Euler update are <0.1% and omitted)"}
 
 
+def bench_stage1(args, rank, world, device, M, P, D, ops):
+    """cfg-3: stage-1 pre-training, bs 2 clips/GPU of F=8 frames at 256^2 (2 x 3870 tokens), bf16 params with fp32
+    master AdamW, gradient all-reduce over RCCL (one bucket per decoder layer, overlapped with backward).
+    One step = forward + backward + all-reduce + clip + AdamW.  samples/sec = 2*world*steps/time."""
+    TR = importlib.import_module("video-gpt_amd.train")
+    F, N, hw, bs = 8, 256, (32, 32), 2
+    cfg = full_config(M, args.layers)
+    model = build_model(M, cfg, device, seed=0)
+    proc = P.LVMProcessor(P.SpecialTokenizer(10, 11, 12))
+    rows = []
+    for _ in range(bs):
+        prompt = "".join(f"<|diffusion|><|image_{i + 1}|><img><|image_{i + 1}|></img>" if i < F - 1
+                         else f"<|diffusion|><|image_{i + 1}|>" for i in range(F))
+        rows.append(proc.process_multi_modal_prompt_training(prompt, [torch.zeros(3, hw[0] * 8, hw[1] * 8) for _ in range(F)]))
+    batch = proc.collator.collate_stage1(rows, F)
+    batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items() if k not in ("input_pixel_values", "output_images")}
+    g = torch.Generator("cpu").manual_seed(100 + rank)
+    nd, nc = bs * F, bs * (F - 1)
+    mk = lambda n: torch.randn(n, 4, *hw, generator=g).to(device)
+    x1, x0, clean, x0i = mk(nd), mk(nd), mk(nc), mk(nc)
+    t = torch.rand(nd, generator=g).to(device)
+    ti = (0.9 + 0.1 * torch.rand(nc, generator=g)).to(device)
+    trainer = TR.Stage1Trainer(model, lr=1e-4, weight_decay=0.1, max_grad_norm=1.0)
+    for _ in range(args.warmup):
+        loss = trainer.step(batch, x1, x0, t, clean, x0i, ti)
+    losses = []
+
+    def run():
+        for _ in range(args.steps):
+            losses.append(trainer.step(batch, x1, x0, t, clean, x0i, ti))
+    elapsed = D.timed_region(run, torch.cuda.synchronize, device)
+    ms = elapsed / max(args.steps, 1) * 1e3
+    valid = int((batch["attention_mask"].all(-1) == 0).sum()) if False else None
+    H, I, nl = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    real = bs * (2 * F - 1) * (N + 2)
+    mask = batch["attention_mask"]
+    pairs = int(mask.sum().item())  # no pad rows at equal lengths
+    fwd = (2 * (4 * H * H + 3 * H * I) * real + 4 * H * pairs) * nl
+    if rank == 0:
+        loss_v = [float(l.mean()) for l in (losses[0], losses[-1])]
+        line = {"metric": "stage-1 train samples/sec (256^2, 8-frame clips, bs 2/GPU, DP)", "value": round(world * bs * args.steps / elapsed, 3),
+                "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"cfg-3 stage-1 pretrain: bs {bs}/GPU x F={F} frames 256^2 ({real} tokens/GPU), "
+                                       f"Phi-3-mini-class denoiser {nl} layers, bf16 + fp32-master AdamW, clip 1.0"
+                                       + ("" if nl == 32 else " [DEBUG layer count: INVALID]"),
+                           "global_batch": world * bs, "parallelism": f"dp{world}", "loss_first_last": loss_v},
+                "roofline": {"bound": "mfma", "kernel": "whole step (fwd + bwd ~ 3 x fwd FLOPs)", "achieved": round(3 * fwd / (ms * 1e-3) / 1e12, 1),
+                             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(3 * fwd / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                             "traffic": None, "alg_tflop_per_step": round(3 * fwd / 1e12, 1)}}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        D.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +148,9 @@ def main():
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers => INVALID as a benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--workload", choices=["infer", "stage1"], default="infer",
+                    help="infer = cfg-2 next-clip denoise (default, BASELINE metric part 1); "
+                         "stage1 = cfg-3 stage-1 pre-training step, bs 2/GPU, data-parallel (metric part 2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,6 +170,9 @@ def main():
     E = importlib.import_module("video-gpt_amd.engine")
     S = importlib.import_module("video-gpt_amd.scheduler")
     ops = importlib.import_module("video-gpt_amd.ops")
+
+    if args.workload == "stage1":
+        return bench_stage1(args, rank, world, device, M, P, D, ops)
 
     # ---- workload: cfg-2 ----
     C, G, hw = 4, 8, (32, 32)

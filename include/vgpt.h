@@ -259,9 +259,9 @@ int vgpt_embed_bwd(const int64_t* ids, const uint8_t* keep, const void* dseq, fl
 int vgpt_patchify(const void* x, void* patches, int n_frames, int C, int h, int w, void* stream);
 int vgpt_unpatchify_bwd(const void* dpred, void* dy16, int n_frames, int C, int h, int w, void* stream);
 int vgpt_gather_rows(const void* in, const int32_t* row0, void* out, int n_seg, int per, int64_t H, void* stream);
-/* *out += sum g^2;  coef = min(1, max_norm/(sqrt(sumsq)+1e-6)) * extra_scale;  AdamW on fp32 master weights
+/* *out += sum g^2 (deterministic two-stage reduction: replicas must agree bit for bit);  coef = min(1, max_norm/(sqrt(sumsq)+1e-6)) * extra_scale;  AdamW on fp32 master weights
  * (torch.optim.AdamW update; bf16 model copy refreshed; *grad_scale multiplies the gradient). */
-int vgpt_sumsq(const void* g, int g_f32, float* out, int64_t n, void* stream);
+int vgpt_sumsq(const void* g, int g_f32, float* out, int64_t n, float* partial_ws /* >= 1024 floats */, void* stream);
 int vgpt_clip_coef(const float* sumsq, float* coef, float* norm_out, float max_norm, float extra_scale, void* stream);
 int vgpt_adamw_step(float* master, void* param, const void* grad, int grad_f32, float* m, float* v, int64_t n, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_scale,

@@ -192,3 +192,48 @@ def test_stage1_loss_and_gradients_match_autograd():
     for _ in range(5):
         l1 = float(tr.step(dbatch, x1, x0, t, clean, x0i, ti).mean())
     assert l1 < l0
+
+
+# ---- data-parallel step: 2 ranks on the one GPU of the test box, gloo transport (RCCL refuses two ranks on
+#      one device); the trainer code path (per-layer bucket all-reduce, 1/world folded into the clip) is the
+#      same one `bench.py --workload stage1 --gpus N` runs over RCCL ----
+def _dp_worker(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = R.TINY
+    p, batch, x1, x0, t, clean, x0i, ti = _stage1_case(cfg)
+    gen = torch.Generator("cpu").manual_seed(500 + rank)          # different data on every rank
+    x1 = torch.randn(x1.shape, generator=gen)
+    model = SC.build_product_model(cfg, p, DEV, cls_name="LVMTraining")
+    TR = importlib.import_module("video-gpt_amd.train")
+    tr = TR.Stage1Trainer(model, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    for _ in range(2):
+        tr.step(dbatch, x1, x0, t, clean, x0i, ti)
+    torch.cuda.synchronize()
+    w = model.llm.layers[1].mlp.down_proj.weight.detach().float().cpu().numpy()   # numpy: pickled by value
+    e = model.llm.embed_tokens.weight.detach().float().cpu().numpy()
+    q.put((rank, w, e, float(tr.grad_norm)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_stay_in_sync():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    (_, w0, e0, n0), (_, w1, e1, n1) = res
+    assert n0 == n1 and n0 > 0, (n0, n1)                          # same all-reduced gradient norm on both ranks
+    assert np.array_equal(w0, w1), float(np.abs(w0 - w1).max())   # replicas identical after all-reduced updates
+    assert np.array_equal(e0, e1), float(np.abs(e0 - e1).max())

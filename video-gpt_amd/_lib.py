@@ -75,7 +75,7 @@ SIGNATURES = {
     "vgpt_patchify": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vgpt_unpatchify_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vgpt_gather_rows": (c_int, [_P, _P, _P, c_int, c_int, _I64, _P]),
-    "vgpt_sumsq": (c_int, [_P, c_int, _P, _I64, _P]),
+    "vgpt_sumsq": (c_int, [_P, c_int, _P, _I64, _P, _P]),
     "vgpt_clip_coef": (c_int, [_P, _P, _P, c_float, c_float, _P]),
     "vgpt_adamw_step": (c_int, [_P, _P, _P, c_int, _P, _P, _I64, c_float, c_float, c_float, c_float, c_float, c_int,
                                 _P, _P]),

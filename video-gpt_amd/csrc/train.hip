@@ -397,9 +397,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict
 }
 
 // ---- optimizer -----------------------------------------------------------------------------------------
-// sum of squares of a bf16 / fp32 gradient buffer into *out (fp32 atomic per block)
+// sum of squares of a bf16 / fp32 gradient buffer, DETERMINISTIC (replicas must compute bit-identical clip
+// coefficients): per-block partials in a fixed grid, then one thread adds them to *out in index order
 template <typename T>
-__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ g, float* __restrict__ out, int64_t n) {
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const T* __restrict__ g, float* __restrict__ partial, int64_t n) {
     __shared__ float red[4];
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -409,7 +410,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ g, flo
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sumsq_final_kernel(const float* __restrict__ partial, int n_partial, float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = 0; i < n_partial; ++i) s += partial[i];
+    *out += s;
 }
 
 // AdamW (torch.optim.AdamW semantics) on fp32 master weights; bf16 model copy refreshed.
@@ -648,14 +654,17 @@ VGPT_EXPORT int vgpt_gather_rows(const void* in, const int32_t* row0, void* out,
     LAUNCH_OK("vgpt_gather_rows");
 }
 
-VGPT_EXPORT int vgpt_sumsq(const void* g, int g_f32, float* out, int64_t n, void* stream) {
-    VGPT_REQUIRE(g && out && n >= 0, VGPT_ERR_INVALID, "vgpt_sumsq: bad argument");
+VGPT_EXPORT int vgpt_sumsq(const void* g, int g_f32, float* out, int64_t n, float* partial_ws, void* stream) {
+    VGPT_REQUIRE(g && out && partial_ws && n >= 0, VGPT_ERR_INVALID, "vgpt_sumsq: bad argument");
     if (n == 0) return VGPT_OK;
     int grid = (int)std::min<int64_t>(cdiv(n, 256 * 8), 1024);
     if (g_f32)
-        hipLaunchKernelGGL(sumsq_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)g, out, n);
+        hipLaunchKernelGGL(sumsq_partial_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)g,
+                           partial_ws, n);
     else
-        hipLaunchKernelGGL(sumsq_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, out, n);
+        hipLaunchKernelGGL(sumsq_partial_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)g,
+                           partial_ws, n);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, partial_ws, grid, out);
     LAUNCH_OK("vgpt_sumsq");
 }
 

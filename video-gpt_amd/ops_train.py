@@ -172,8 +172,14 @@ def gather_rows(x2d, row0, per):
     return out
 
 
+_partials = {}
+
+
 def sumsq(g, out):
-    call("vgpt_sumsq", g.data_ptr(), _f32flag(g), out.data_ptr(), g.numel(), _stream())
+    ws = _partials.get(g.device)
+    if ws is None:
+        ws = _partials[g.device] = torch.empty(1024, dtype=F32, device=g.device)
+    call("vgpt_sumsq", g.data_ptr(), _f32flag(g), out.data_ptr(), g.numel(), ws.data_ptr(), _stream())
 
 
 def clip_coef(sumsq_t, coef, norm_out, max_norm, extra_scale=1.0):
