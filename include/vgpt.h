@@ -232,7 +232,7 @@ int vgpt_act_fwd(const void* pre, void* y, int64_t n, int act, void* stream);
 int vgpt_act_bwd(const void* pre, const void* dy, void* dx, int64_t n, int act, void* stream);
 /* Phi3RMSNorm backward: dx = d(norm)/dx (+ dres if not NULL), dw += sum_rows dy * xhat (fp32, caller zeroes). */
 int vgpt_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dres, void* dx, float* dw,
-                     int64_t rows, int64_t H, float eps, void* stream);
+                     float* rstd_ws /* rows floats */, int64_t rows, int64_t H, float eps, void* stream);
 /* C[m][n] = alpha * sum_k A[m*sa_m + k*sa_k] * B[k*sb_k + n*sb_n] (+ C); *_f32: 0 = bf16, 1 = fp32.  For the
  * small heads (patch embeds, timestep MLPs, adaLN, final Linear) whose backward is not worth an MFMA kernel. */
 int vgpt_matmul_generic(const void* A, int a_f32, int64_t sa_m, int64_t sa_k, const void* B, int b_f32, int64_t sb_k,

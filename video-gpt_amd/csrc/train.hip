@@ -101,41 +101,33 @@ __global__ void act_fwd_kernel(const bf16* __restrict__ pre, bf16* __restrict__ 
     if (i < n) y[i] = f2bf(act_apply(bf2f(pre[i]), actk));
 }
 
-// ---- RMSNorm backward: dx (+= dres), dw (fp32 atomics, one partial per block) ----------------------
-// y = w * (x * rstd):  g = w*dy ; dx = rstd*g - x*rstd^3/H * sum(g*x) ;  dw += dy * x*rstd
+// ---- RMSNorm backward -------------------------------------------------------------------------------
+// y = w * (x * rstd):  g = w*dy ; dx = rstd*g - x*rstd^3/H * sum(g*x) (+ dres) ;  dw += sum_rows dy * x * rstd
+// Two kernels: a row kernel (one wave per row, like the forward) that also stores rstd[row], and a column
+// kernel that reduces dw over row strips (fp32 atomics, one per column per strip).
 template <int NCH>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
-                                                          const bf16* __restrict__ dy, const bf16* __restrict__ dres,
-                                                          bf16* __restrict__ dx, float* __restrict__ dw, int64_t rows,
-                                                          int H, float eps) {
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dx_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                             const bf16* __restrict__ dy, const bf16* __restrict__ dres,
+                                                             bf16* __restrict__ dx, float* __restrict__ rstd_out,
+                                                             int64_t rows, int H, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float dwacc[NCH][8], wv[NCH][8];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int off = (c * 64 + lane) * 8;
-        bf16x8 wb;
-        if (off < H) wb = *reinterpret_cast<const bf16x8*>(w + off);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            dwacc[c][j] = 0.f;
-            wv[c][j] = off < H ? bf2f(wb[j]) : 0.f;
-        }
-    }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-        float xv[NCH][8], dv[NCH][8];
+        bf16x8 xb[NCH], gb[NCH];
         float ss = 0.f, sgx = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int off = (c * 64 + lane) * 8;
             if (off < H) {
-                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(x + row * H + off);
+                xb[c] = *reinterpret_cast<const bf16x8*>(x + row * H + off);
                 const bf16x8 db = *reinterpret_cast<const bf16x8*>(dy + row * H + off);
+                const bf16x8 wb = *reinterpret_cast<const bf16x8*>(w + off);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    xv[c][j] = bf2f(xb[j]);
-                    dv[c][j] = bf2f(db[j]);
-                    ss += xv[c][j] * xv[c][j];
-                    sgx += dv[c][j] * wv[c][j] * xv[c][j];
+                    const float xf = bf2f(xb[c][j]);
+                    const float gf = bf2f(db[j]) * bf2f(wb[j]);
+                    gb[c][j] = f2bf(gf);  // w*dy, kept in bf16 registers (re-rounded once; error << bf16 output)
+                    ss += xf * xf;
+                    sgx += gf * xf;
                 }
             }
         }
@@ -143,6 +135,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
         sgx = wave_sum(sgx);
         const float rstd = rsqrtf(ss / (float)H + eps);
         const float k = sgx * rstd * rstd * rstd / (float)H;
+        if (lane == 0) rstd_out[row] = rstd;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int off = (c * 64 + lane) * 8;
@@ -151,32 +144,36 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
                 if (dres) rb = *reinterpret_cast<const bf16x8*>(dres + row * H + off);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float v = rstd * dv[c][j] * wv[c][j] - xv[c][j] * k;
+                    float v = rstd * bf2f(gb[c][j]) - bf2f(xb[c][j]) * k;
                     if (dres) v += bf2f(rb[j]);
                     o[j] = f2bf(v);
-                    dwacc[c][j] += dv[c][j] * xv[c][j] * rstd;
                 }
                 *reinterpret_cast<bf16x8*>(dx + row * H + off) = o;
             }
         }
     }
-    // block reduction of dw over the 4 waves, then one atomic per column per block
-    __shared__ float red[4][64 * 8];
+}
+
+// grid (ceil(H/8/256), strips): thread = 8 columns, loops over its strip of rows
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                             const float* __restrict__ rstd, float* __restrict__ dw,
+                                                             int64_t rows, int H, int rows_per_strip) {
+    const int off = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (off >= H) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_strip;
+    const int64_t r1 = r0 + rows_per_strip < rows ? r0 + rows_per_strip : rows;
+    float acc[8];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int off = (c * 64 + lane) * 8;
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(x + r * H + off);
+        const bf16x8 db = *reinterpret_cast<const bf16x8*>(dy + r * H + off);
+        const float rs = rstd[r];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = dwacc[c][j];
-        __syncthreads();
-        if (wave == 0 && off < H) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float s = red[0][lane * 8 + j] + red[1][lane * 8 + j] + red[2][lane * 8 + j] + red[3][lane * 8 + j];
-                atomicAdd(dw + off + j, s);
-            }
-        }
-        __syncthreads();
+        for (int j = 0; j < 8; ++j) acc[j] += bf2f(db[j]) * bf2f(xb[j]) * rs;
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(dw + off + j, acc[j]);
 }
 
 // ---- generic strided matmul for the small heads: C = alpha * A B (+ C), one thread per output ------
@@ -403,10 +400,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const T* __restrict__ g, float* __restrict__ partial, int64_t n) {
     __shared__ float red[4];
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = (float)g[i];
-        s += v * v;
+    constexpr int V = 16 / sizeof(T);  // 16-byte loads
+    const int64_t nv = n / V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        if constexpr (sizeof(T) == 2) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(g + i * V);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); s += f * f; }
+        } else {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(g + i * V);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += v[j] * v[j];
+        }
     }
+    if (blockIdx.x == 0)
+        for (int64_t i = nv * V + threadIdx.x; i < n; i += blockDim.x) { const float f = (float)g[i]; s += f * f; }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -503,20 +511,24 @@ VGPT_EXPORT int vgpt_act_bwd(const void* pre, const void* dy, void* dx, int64_t 
 }
 
 VGPT_EXPORT int vgpt_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dres, void* dx, float* dw,
-                                 int64_t rows, int64_t H, float eps, void* stream) {
-    VGPT_REQUIRE(x && w && dy && dx && dw, VGPT_ERR_INVALID, "vgpt_rmsnorm_bwd: null pointer");
+                                 float* rstd_ws, int64_t rows, int64_t H, float eps, void* stream) {
+    VGPT_REQUIRE(x && w && dy && dx && dw && rstd_ws, VGPT_ERR_INVALID, "vgpt_rmsnorm_bwd: null pointer");
     VGPT_REQUIRE(rows >= 0 && H > 0 && H % 8 == 0 && H <= 4096, VGPT_ERR_UNSUPPORTED,
                  "vgpt_rmsnorm_bwd: H must be a multiple of 8 and <= 4096");
     if (rows == 0) return VGPT_OK;
-    int grid = (int)std::min<int64_t>(cdiv(rows, 4), 256 * 4);
+    int grid = (int)std::min<int64_t>(cdiv(rows, 4), 256 * 8);
     hipStream_t s = (hipStream_t)stream;
 #define RB_CASE(N)                                                                                                \
     case N:                                                                                                       \
-        hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(grid), dim3(256), 0, s, (const bf16*)x, (const bf16*)w,    \
-                           (const bf16*)dy, (const bf16*)dres, (bf16*)dx, dw, rows, (int)H, eps);                 \
+        hipLaunchKernelGGL(rmsnorm_bwd_dx_kernel<N>, dim3(grid), dim3(256), 0, s, (const bf16*)x, (const bf16*)w, \
+                           (const bf16*)dy, (const bf16*)dres, (bf16*)dx, rstd_ws, rows, (int)H, eps);            \
         break;
     switch ((int)cdiv(H, 512)) { RB_CASE(1) RB_CASE(2) RB_CASE(3) RB_CASE(4) RB_CASE(5) RB_CASE(6) RB_CASE(7) RB_CASE(8) }
 #undef RB_CASE
+    const int strips = (int)std::min<int64_t>(rows, 256);
+    const int rps = (int)cdiv(rows, strips);
+    hipLaunchKernelGGL(rmsnorm_bwd_dw_kernel, dim3((unsigned)cdiv(H / 8, 256), (unsigned)cdiv(rows, rps)), dim3(256), 0, s,
+                       (const bf16*)x, (const bf16*)dy, rstd_ws, dw, rows, (int)H, rps);
     LAUNCH_OK("vgpt_rmsnorm_bwd");
 }
 

@@ -90,12 +90,19 @@ def act_bwd(pre, dy, act):
     return dx
 
 
+_rstd_ws = {}
+
+
 def rmsnorm_bwd(x, w, dy, dx, dw, eps, dres=None):
     _chk(x, BF16, "rmsnorm_bwd.x"); _chk(dy, BF16, "rmsnorm_bwd.dy"); _chk(dx, BF16, "rmsnorm_bwd.dx")
     _chk(dw, F32, "rmsnorm_bwd.dw")
     H = x.shape[-1]
+    rows = x.numel() // H
+    ws = _rstd_ws.get(x.device)
+    if ws is None or ws.numel() < rows:
+        ws = _rstd_ws[x.device] = torch.empty(max(rows, 1), dtype=F32, device=x.device)
     call("vgpt_rmsnorm_bwd", x.data_ptr(), w.data_ptr(), dy.data_ptr(), _ptr(dres), dx.data_ptr(), dw.data_ptr(),
-         x.numel() // H, H, float(eps), _stream())
+         ws.data_ptr(), rows, H, float(eps), _stream())
     return dx
 
 
