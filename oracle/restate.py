@@ -256,6 +256,32 @@ def frame_block_forward(p, cfg: Phi3Cfg, x: List[torch.Tensor], timestep: torch.
     return (latents, out) if return_hidden else latents
 
 
+def lvm_forward(p, cfg: Phi3Cfg, x: torch.Tensor, timestep, input_ids, input_img_latents, input_image_sizes,
+                attention_mask, position_ids):
+    """LVM.forward (LVM/model.py:330-397), tensor branch at world_size 1: [condition | time_token | x] -> last N tokens."""
+    pos_embed = p["pos_embed"]
+    h, w = x.shape[-2:]
+    tok = patch_embed(x, p["x_embedder.proj.weight"], p["x_embedder.proj.bias"], cfg.patch_size)
+    tok = tok + cropped_pos_embed(pos_embed, cfg, h, w).to(tok.dtype)
+    n_tok = tok.size(1)
+    time_token = timestep_embedder(p, "time_token", timestep, tok.dtype).unsqueeze(1)
+    if input_ids is not None:
+        cond = F.embedding(input_ids, p["llm.embed_tokens.weight"]).clone()
+        if input_img_latents is not None:
+            lat, _, _ = patch_multiple_resolutions(p, cfg, pos_embed, input_img_latents, True)
+            n = 0
+            for b in input_image_sizes.keys():
+                for s, e in input_image_sizes[b]:
+                    cond[b, s:e] = lat[n]
+                    n += 1
+        emb = torch.cat([cond, time_token, tok], dim=1)
+    else:
+        emb = torch.cat([time_token, tok], dim=1)
+    out = transformer(p, cfg, emb, attention_mask, position_ids)
+    y = final_layer(p, out[:, -n_tok:], timestep_embedder(p, "t_embedder", timestep, tok.dtype))
+    return unpatchify(y, h, w, cfg.patch_size, cfg.in_channels)
+
+
 def frame_block_forward_with_cfg(p, cfg, x, timestep, use_img_cfg, img_cfg_scale, prediction_type="v", **kw):
     """LVM/model.py:519-566 — CFG on the model output only for prediction_type 'v'."""
     out = frame_block_forward(p, cfg, x, timestep, **kw)

@@ -131,3 +131,34 @@ def test_shift_and_sigma_table():
 
 def test_smoke_entry():
     assert SC.run_smoke(verbose=False) < TOL
+
+
+def test_single_target_forward(case):
+    """LVM.forward / forward_with_cfg (LVM/model.py:330-397,504-516): [condition | time token | x], any 3-D mask."""
+    cfg, p, batch, z, cond, model = case
+    g = torch.Generator("cpu").manual_seed(11)
+    B, Lc, hw = 2, 21, (8, 8)
+    N = 16
+    L = Lc + 1 + N
+    ids = torch.randint(3, cfg.vocab_size, (B, Lc), generator=g)
+    x = torch.randn(B, 4, *hw, generator=g).to(BF).float()
+    t = torch.tensor([0.2, 0.9])
+    lat = [torch.randn(1, 4, *hw, generator=g).to(BF).float()]
+    sizes = {0: [[2, 2 + N]]}
+    mask = torch.tril(torch.ones(L, L)).bool()[None].repeat(B, 1, 1)
+    mask[:, -N:, -N:] = True                      # image tokens see each other (OmniGen-style)
+    pos = torch.arange(L)[None].repeat(B, 1)
+    ref = R.lvm_forward(p, cfg, x, t, ids, lat, sizes, mask, pos)
+    out, cache = model.forward(x.to(DEV, BF), t.to(DEV), ids.to(DEV), [lat[0].to(DEV, BF)], sizes, mask.to(DEV), pos.to(DEV))
+    assert cache is None and out.shape == x.shape
+    assert SC.rel_l2(out, ref) < TOL
+    # 'v' CFG on the batch halves
+    o2, _ = model.forward_with_cfg(x.to(DEV, BF), t.to(DEV), ids.to(DEV), [lat[0].to(DEV, BF)], sizes, mask.to(DEV),
+                                   pos.to(DEV), True, 1.6, None, False, False, prediction_type="v")
+    c = ref[1:2] + 1.6 * (ref[0:1] - ref[1:2])
+    assert SC.rel_l2(o2, torch.cat([c, c])) < TOL
+    # no condition tokens
+    out3 = model.forward(x.to(DEV, BF), t.to(DEV), None, None, None, mask[:, Lc:, Lc:].contiguous().to(DEV),
+                         pos[:, : N + 1].contiguous().to(DEV), return_past_key_values=False)
+    ref3 = R.lvm_forward(p, cfg, x, t, None, None, None, mask[:, Lc:, Lc:], pos[:, : N + 1])
+    assert SC.rel_l2(out3, ref3) < TOL

@@ -510,9 +510,54 @@ class LVM(nn.Module):
 
     def forward(self, x, timestep, input_ids, input_img_latents, input_image_sizes, attention_mask, position_ids,
                 padding_latent=None, past_key_values=None, return_past_key_values=True, offload_model: bool = False):
-        """Single-target variant (LVM/model.py:330-397): sequence = [condition | time_token | x]."""
-        raise VgptError("LVM.forward (single-image OmniGen-style sequence) is outside the next-clip hot path; "
-                        "use frame_block_forward")
+        """Single-target variant (LVM/model.py:330-397): sequence = [condition tokens | time token | x tokens],
+        prediction read from the last N positions.  Same kernels as the frame-block path: the sequence is the
+        frame-block layout with one noisy block per batch row at the end.  (The reference's unconditional
+        `dist.all_gather` at world size 1 is the identity and is not issued.)"""
+        self._check_ready()
+        if padding_latent is not None or isinstance(x, (list, tuple)):
+            raise VgptError("LVM.forward: mixed-resolution lists / padding latents are not supported on the HIP path")
+        B, C, h, w = x.shape
+        N = (h // self.patch_size) * (w // self.patch_size)
+        dev = x.device
+        Lc = 0 if input_ids is None else input_ids.shape[1]
+        L = Lc + 1 + N
+        pad = self.llm.config.pad_token_id if self.llm.config.pad_token_id is not None else 0
+        pad = min(max(int(pad), 0), self.llm.vocab_size - 1)
+        ids = torch.full((B, L), pad, dtype=torch.int64, device=dev)
+        if input_ids is not None:
+            ids[:, :Lc] = input_ids
+        denoise = {b: [[Lc + 1, L]] for b in range(B)}
+        time_inx = {b: [Lc] for b in range(B)}
+        sizes = input_image_sizes if input_img_latents is not None else {}
+        lat = input_img_latents if input_img_latents is not None and len(input_img_latents) > 0 else None
+        seq, rows, shapes = self.assemble_sequence(x, timestep, ids, lat, sizes, denoise, time_inx)
+        output = self.llm(inputs_embeds=seq, attention_mask=attention_mask, position_ids=position_ids,
+                          past_key_values=past_key_values, offload_model=offload_model)
+        frames = self.decode_frames(output.last_hidden_state, timestep, rows, shapes)
+        latents = torch.cat(frames, dim=0)
+        if return_past_key_values:
+            return latents, None
+        return latents
+
+    @torch.no_grad()
+    def forward_with_cfg(self, x, timestep, input_ids, input_img_latents, input_image_sizes, attention_mask, position_ids,
+                         use_img_cfg, img_cfg_scale, past_key_values, use_kv_cache, offload_model,
+                         prediction_type: str = "v"):
+        """LVM/model.py:504-516: batch = [cond ; uncond]; CFG applied here only for 'v' predictions."""
+        model_out, past_key_values = self.forward(x, timestep, input_ids, input_img_latents, input_image_sizes,
+                                                  attention_mask, position_ids, past_key_values=past_key_values,
+                                                  return_past_key_values=True, offload_model=offload_model)
+        if use_img_cfg and prediction_type == "v":
+            n = model_out.shape[0]
+            v = torch.zeros(model_out.shape, dtype=torch.float32, device=model_out.device)
+            sig = self._plan(("sig01", model_out.device), lambda: torch.tensor([0.0, 1.0], device=model_out.device))
+            st = self._plan(("step0", model_out.device), lambda: torch.zeros(1, dtype=torch.int32, device=model_out.device))
+            vm = torch.empty_like(model_out)
+            ops.euler_cfg_update(v.view(n, -1), vm.view(n, -1), model_out.contiguous().view(n, -1), sig, st, ops.PRED_V,
+                                 True, img_cfg_scale)
+            model_out = torch.cat([vm[: n // 2], vm[: n // 2]], dim=0)
+        return model_out, past_key_values
 
 
 class LVMTraining(LVM):
