@@ -248,9 +248,17 @@ def main():
         n_launch = len(ev)
         alg = 2 * (4 * H * H + H * I) * real_tokens * nl  # qkv (3H^2) + o (H^2) + down (HI), real tokens
         achieved = alg / t_gemm / 1e12
+        traffic = None  # per-launch bytes beyond L2 from the committed PMC passes (profiles/r01_pmc_traffic.json)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                for name, rec in json.load(f)["kernels"].items():
+                    if "gemm_bf16_kernel<0" in name:
+                        traffic = rec["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<MODE_PLAIN> (qkv_proj/o_proj/down_proj)",
                 "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "launches": n_launch, "avg_launch_us": round(t_gemm / max(n_launch, 1) * 1e6, 1),
                 "alg_flops_per_launch": alg / max(n_launch, 1),
                 "whole_step": {"alg_tflop": round(flops_step / 1e12, 2),
