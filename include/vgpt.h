@@ -116,6 +116,15 @@ int vgpt_attn_blockmask_fwd(const void* q, const void* k, const void* v, void* o
                             int64_t v_sh, int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
                             float scale, int variant, void* stream);
 int vgpt_attn_supported(int head_dim);
+/* Same, computing only query rows [q_start, L) (q_start % 128 == 0) against ALL L keys: rows before q_start are a
+ * cached, step-invariant key/value prefix (condition frames never see the clip being denoised, LVM/processor.py:
+ * 682-731, so their K/V need not be recomputed every denoise step as LVM/scheduler.py:174 does).  q, o and the mask
+ * are indexed by absolute row. */
+int vgpt_attn_blockmask_fwd_qrange(const void* q, const void* k, const void* v, void* o, int64_t q_start,
+                                   const uint32_t* bits, const uint8_t* summary, int64_t B, int64_t L, int n_heads,
+                                   int n_kv_heads, int head_dim, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
+                                   int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb,
+                                   int64_t o_sh, int64_t o_ss, float scale, void* stream);
 
 /* ---- model glue ---------------------------------------------------------- */
 

@@ -162,3 +162,25 @@ def test_single_target_forward(case):
                          pos[:, : N + 1].contiguous().to(DEV), return_past_key_values=False)
     ref3 = R.lvm_forward(p, cfg, x, t, None, None, None, mask[:, Lc:, Lc:], pos[:, : N + 1])
     assert SC.rel_l2(out3, ref3) < TOL
+
+
+def test_condition_prefix_reuse_matches_full_recompute():
+    """The clean condition rows are step-invariant: computing them once (prefill) and running only the remaining
+    rows per step must give the reference's result (which recomputes everything every step, LVM/scheduler.py:174)."""
+    cfg = R.TINY
+    p, batch, z, cond = SC.build_case(cfg, C=2, G=2, hw=(16, 16))       # block = 66 tokens -> 132-token prefix
+    model = SC.build_product_model(cfg, p, DEV)
+    S = importlib.import_module("video-gpt_amd.scheduler")
+    outs = {}
+    for reuse in (True, False):
+        sched = S.LVMScheduler(num_steps=3)
+        sched.reuse_condition_prefix = reuse
+        outs[reuse] = torch.cat(sched([x.to(DEV, BF) for x in z], model.frame_block_forward_with_cfg,
+                                      SC.model_kwargs(batch, cond, DEV), prediction_type="x1"))
+        assert (sched.last_engine.S > 0) == reuse
+        if reuse:
+            eng = sched.last_engine
+            assert eng.S == 256 and eng.Ma == eng.L - 256      # 132-row prefix padded to 2 x 128
+    ref = torch.cat(SC.oracle_sample(cfg, p, batch, z, cond, 3, "x1"))
+    assert SC.rel_l2(outs[True], ref) < TOL
+    assert SC.rel_l2(outs[True], outs[False]) < 5e-3

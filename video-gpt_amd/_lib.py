@@ -39,6 +39,8 @@ SIGNATURES = {
         [_P, _P, _P, _P, _P, _P, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, c_int, _P],
     ),
     "vgpt_attn_supported": (c_int, [c_int]),
+    "vgpt_attn_blockmask_fwd_qrange": (
+        c_int, [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
     "vgpt_embed_gather": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "vgpt_patch_embed_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64, c_int, _P]),
     "vgpt_timestep_sinusoid": (c_int, [_P, _P, _P, c_int, c_int, _P]),

@@ -31,6 +31,7 @@ struct AttnArgs {
     int B, L, n_heads, kv_group;  // kv_group = n_heads / n_kv_heads
     int W;                        // mask words per row
     int nqb, nkt;                 // 128-row q blocks, 64-key tiles
+    int qb0;                      // first q block computed (rows before qb0*128 are keys only: cached prefix)
     int64_t q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss;
     float scale_log2e;
 };
@@ -69,15 +70,16 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     const int r = lane & 31, h = lane >> 5;
 
     // ---- work item: keep all q blocks of a (batch, head) on one XCD (shared K/V in its L2) ----
-    const int total = a.nqb * a.n_heads * a.B;
+    const int nqa = a.nqb - a.qb0;  // q blocks actually computed
+    const int total = nqa * a.n_heads * a.B;
     int wid = blockIdx.x;
     {
         const int xcd = wid & 7, qn = total >> 3, rn = total & 7;
         wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (wid >> 3);
     }
-    const int qb = wid % a.nqb;
-    const int head = (wid / a.nqb) % a.n_heads;
-    const int b = wid / (a.nqb * a.n_heads);
+    const int qb = a.qb0 + wid % nqa;
+    const int head = (wid / nqa) % a.n_heads;
+    const int b = wid / (nqa * a.n_heads);
     const int kvh = head / a.kv_group;
 
     const uint8_t* sum_row = a.summary + ((int64_t)b * a.nqb + qb) * a.nkt;
@@ -335,7 +337,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
         }
         attr_set = true;
     }
-    const int total = a.nqb * a.n_heads * a.B;
+    const int total = (a.nqb - a.qb0) * a.n_heads * a.B;
     hipLaunchKernelGGL((attn_fwd_kernel<D, TR>), dim3(total), dim3(256), lds, s, a);
     VGPT_CHECK_LAUNCH("vgpt_attn_blockmask_fwd");
     return VGPT_OK;
@@ -347,7 +349,7 @@ VGPT_EXPORT int vgpt_attn_supported(int head_dim) {
     return head_dim == 64 || head_dim == 96 || head_dim == 128;
 }
 
-static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse,
+static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, int64_t q_start,
                          const uint32_t* bits, const uint8_t* summary, int64_t B,
                          int64_t L, int n_heads, int n_kv_heads, int head_dim,
                          int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
@@ -375,12 +377,14 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
                  VGPT_ERR_UNSUPPORTED, "vgpt_attn_blockmask_fwd: q/k/v must be 16-byte aligned");
     VGPT_REQUIRE(L < (1 << 24) && B * n_heads * cdiv(L, 128) < (1ll << 31), VGPT_ERR_UNSUPPORTED,
                  "vgpt_attn_blockmask_fwd: problem too large");
-    if (B == 0 || L == 0) return VGPT_OK;
+    VGPT_REQUIRE(q_start >= 0 && q_start % 128 == 0 && q_start <= L, VGPT_ERR_INVALID,
+                 "vgpt_attn_blockmask_fwd: q_start must be a multiple of 128 in [0, L]");
+    if (B == 0 || L == 0 || q_start >= L) return VGPT_OK;
     AttnArgs a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o;
     a.bits = bits; a.summary = summary; a.lse = lse;
     a.B = (int)B; a.L = (int)L; a.n_heads = n_heads; a.kv_group = n_heads / n_kv_heads;
-    a.W = (int)cdiv(L, 32); a.nqb = (int)cdiv(L, 128); a.nkt = (int)cdiv(L, 64);
+    a.W = (int)cdiv(L, 32); a.nqb = (int)cdiv(L, 128); a.nkt = (int)cdiv(L, 64); a.qb0 = (int)(q_start / 128);
     a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
     a.v_sb = v_sb; a.v_sh = v_sh; a.v_ss = v_ss; a.o_sb = o_sb; a.o_sh = o_sh; a.o_ss = o_ss;
     a.scale_log2e = scale * 1.4426950408889634f;
@@ -402,7 +406,7 @@ VGPT_EXPORT int vgpt_attn_blockmask_fwd(const void* q, const void* k, const void
                                         int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
                                         int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
                                         float scale, int variant, void* stream) {
-    return attn_fwd_impl(q, k, v, o, nullptr, bits, summary, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
+    return attn_fwd_impl(q, k, v, o, nullptr, 0, bits, summary, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
                          k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, scale, variant, stream);
 }
 
@@ -417,6 +421,17 @@ VGPT_EXPORT int vgpt_attn_blockmask_fwd_lse(const void* q, const void* k, const 
         vgpt_set_error("vgpt_attn_blockmask_fwd_lse: null lse");
         return VGPT_ERR_INVALID;
     }
-    return attn_fwd_impl(q, k, v, o, lse, bits, summary, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
+    return attn_fwd_impl(q, k, v, o, lse, 0, bits, summary, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
                          k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, scale, 0, stream);
+}
+
+VGPT_EXPORT int vgpt_attn_blockmask_fwd_qrange(const void* q, const void* k, const void* v, void* o, int64_t q_start,
+                                               const uint32_t* bits, const uint8_t* summary, int64_t B,
+                                               int64_t L, int n_heads, int n_kv_heads, int head_dim,
+                                               int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
+                                               int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
+                                               int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
+                                               float scale, void* stream) {
+    return attn_fwd_impl(q, k, v, o, nullptr, q_start, bits, summary, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh,
+                         q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, scale, 0, stream);
 }

@@ -329,10 +329,32 @@ template <int MODE>
 int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const int f = forced_tile();
     // the 256-tile pays off once the grid fills the chip (>= ~half of the 256 CUs with 256x256 tiles)
-    const int64_t big_tiles = cdiv(g.M, 256) * cdiv(n_out, MODE == MODE_GATED ? 128 : 256);
+    const int64_t tiles_n = cdiv(n_out, MODE == MODE_GATED ? 128 : 256);
+    const int64_t tiles_m = cdiv(g.M, 256);
+    const int64_t big_tiles = tiles_m * tiles_n;
     const bool use256 = f == 256 || f == 257 || (f != 128 && big_tiles >= 128);
     if (!use256) return launch_cfg<MODE, Cfg128, false>(g, n_out, s, name);
     if (f == 257) return launch_cfg<MODE, Cfg256, false>(g, n_out, s, name);
+    // Wave quantisation: the 256-tile kernel runs one block per CU, so a grid of T tiles takes ceil(T/256) rounds.
+    // When the last round would be badly filled, give the big-tile kernel only the m-tile rows that make full
+    // rounds and run the remaining rows with the 128x128 kernel (2 blocks/CU, 4x smaller tiles) behind it.
+    constexpr int CUS = 256;
+    const int64_t full_rounds = big_tiles / CUS, rem = big_tiles % CUS;
+    if (f == 0 && full_rounds >= 1 && rem > 0 && rem < (CUS * 85) / 100) {
+        const int64_t rows_big = (full_rounds * CUS) / tiles_n;  // m-tile rows that fit in the full rounds
+        if (rows_big >= 1 && rows_big < tiles_m) {
+            GemmArgs g1 = g, g2 = g;
+            const int64_t m1 = rows_big * 256;
+            g1.M = (int)m1;
+            g2.M = g.M - (int)m1;
+            g2.A = g.A + m1 * g.lda;
+            g2.C = g.C + m1 * g.ldc;
+            if (g.epi == VGPT_EPI_RESID) g2.extra = g.extra + m1 * g.ldr;
+            int rc = launch_cfg<MODE, Cfg256, true>(g1, n_out, s, name);
+            if (rc != VGPT_OK) return rc;
+            return launch_cfg<MODE, Cfg128, false>(g2, n_out, s, name);
+        }
+    }
     return launch_cfg<MODE, Cfg256, true>(g, n_out, s, name);
 }
 

@@ -64,7 +64,8 @@ def pack_left_padded(input_ids, position_ids, attention_mask, pads: List[int]):
 class StaticDenoiser:
     def __init__(self, model, input_ids, position_ids, attention_mask, input_img_latents, input_image_sizes,
                  denoise_image_sizes, time_emb_inx, n_frames: int, latent_hw, use_img_cfg: bool, img_cfg_scale: float,
-                 prediction_type: str = "v", sigma: Optional[torch.Tensor] = None, pack_padding: bool = True):
+                 prediction_type: str = "v", sigma: Optional[torch.Tensor] = None, pack_padding: bool = True,
+                 reuse_condition_prefix: bool = False):
         model._check_ready()
         self.model = model
         cfg = model.llm.config
@@ -80,6 +81,33 @@ class StaticDenoiser:
             row_of = lambda b, s: offs[b] + s - pads[b]
             B, L = input_ids.shape
             self.packed = True
+        # ---- condition-prefix reuse: rows before the first <|diffusion|> token never see a
+        #      noisy / time token (LVM/processor.py:682-731), so their activations are identical at every denoise
+        #      step; the reference recomputes them 50x (LVM/scheduler.py:174).  They are computed ONCE (prefill),
+        #      their per-layer K/V stay in a full-length qkv buffer, and a step only runs the remaining rows. ----
+        self.S = 0          # static prefix length in the (padded) layout == first computed row, multiple of 128
+        if reuse_condition_prefix and B == 1 and not isinstance(attention_mask, ops.PackedMask):
+            t_first = min(row_of(b, t) for b in time_emb_inx.keys() for t in time_emb_inx[b]) - 1
+            m2 = attention_mask[0].to(torch.bool)
+            if t_first >= 128 and not bool(m2[:t_first, t_first:].any()):
+                S0 = t_first
+                S = (S0 + 127) // 128 * 128
+                npad = S - S0
+                dev0 = input_ids.device
+                pad_ids = torch.full((1, npad), int(input_ids[0, 0]), dtype=input_ids.dtype, device=dev0)
+                input_ids = torch.cat([input_ids[:, :S0], pad_ids, input_ids[:, S0:]], dim=1)
+                position_ids = torch.cat([position_ids[:, :S0], torch.zeros(1, npad, dtype=position_ids.dtype, device=dev0),
+                                          position_ids[:, S0:]], dim=1)
+                L2 = L + npad
+                mask2 = torch.zeros(1, L2, L2, dtype=torch.bool, device=m2.device)
+                mask2[0, :S0, :S0] = m2[:S0, :S0]
+                mask2[0, S:, :S0] = m2[S0:, :S0]
+                mask2[0, S:, S:] = m2[S0:, S0:]
+                attention_mask = mask2
+                prev = row_of
+                row_of = lambda b, s, prev=prev, S0=S0, npad=npad: (lambda r: r if r < S0 else r + npad)(prev(b, s))
+                L = L2
+                self.S = S
         H, I = cfg.hidden_size, cfg.intermediate_size
         self.B, self.L, self.H = B, L, H
         self.nf = n_frames
@@ -113,6 +141,12 @@ class StaticDenoiser:
         if len(x_rows) != n_frames or len(t_rows) != n_frames:
             raise AssertionError("denoise_image_sizes / time_emb_inx disagree with the number of latents")
         self.x_rows, self.t_rows = i32(x_rows), i32(t_rows)
+        S = self.S
+        self.Ma = B * L - S   # rows computed per step
+        if S:
+            self.x_rows_a, self.t_rows_a = i32([r - S for r in x_rows]), i32([r - S for r in t_rows])
+            self.ids_a = self.input_ids[:, S:].contiguous()
+            self.rope_a = (self.rope[0][S:].contiguous(), self.rope[1][S:].contiguous())
 
         # per-step state
         M = B * L
@@ -127,17 +161,48 @@ class StaticDenoiser:
             self.set_sigma(sigma)
         # workspaces
         nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        self.hid = e(B, L, H)
-        self.nrm = e(B, L, H)
-        self.qkv = e(B, L, (nq + 2 * nk) * hd)
-        self.ctx = e(B, L, nq * hd)
-        self.act = e(B, L, I)
+        if S:
+            Ma = self.Ma
+            self.hid, self.nrm, self.ctx, self.act = e(1, Ma, H), e(1, Ma, H), e(1, Ma, nq * hd), e(1, Ma, I)
+            self.qkv_full = torch.zeros(cfg.num_hidden_layers, L, (nq + 2 * nk) * hd, dtype=BF16, device=dev)
+        else:
+            self.hid = e(B, L, H)
+            self.nrm = e(B, L, H)
+            self.qkv = e(B, L, (nq + 2 * nk) * hd)
+            self.ctx = e(B, L, nq * hd)
+            self.act = e(B, L, I)
         self.temb_sin = e(n_frames, 256)
         self.tt_h = e(n_frames, H)
         self.te_h = e(n_frames, H)
         self.temb = e(n_frames, H)
         self.mod = e(n_frames, 2 * H)
         self.graph = None
+        if S:
+            self.prefill()
+
+    def prefill(self):
+        """One full-length forward that leaves every layer's (post-RoPE) q/k/v of the static prefix in
+        qkv_full[l][:S]; the rows >= S written here are overwritten by every step."""
+        m, cfg, H, L = self.model, self.cfg, self.H, self.L
+        nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        e = lambda *s: torch.empty(*s, dtype=BF16, device=self.dev)
+        hid, nrm, ctx, act = e(1, L, H), e(1, L, H), e(1, L, nq * hd), e(1, L, cfg.intermediate_size)
+        ops.embed_gather(self.input_ids, m.llm.embed_tokens.weight, out=hid)
+        if self.cond is not None:
+            ops.patch_embed(self.cond, m.input_x_embedder.proj.weight, m.input_x_embedder.proj.bias, m.pos_embed[0],
+                            self.cond_rows, hid.view(-1, H), m.pos_embed_max_size)
+        for li, layer in enumerate(m.llm.layers):
+            at, mlp = layer.self_attn, layer.mlp
+            qkv = self.qkv_full[li].view(1, L, -1)
+            ops.rmsnorm(hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=nrm)
+            ops.linear(nrm, at.qkv_proj.weight, out=qkv)
+            ops.rope_qk_inplace(qkv, self.rope[0], self.rope[1], nq, nk, hd)
+            ops.attention_qkv(qkv, self.pm, nq, nk, hd, out=ctx)
+            ops.linear(ctx, at.o_proj.weight, residual=hid, out=hid)
+            ops.rmsnorm(hid, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon, out=nrm)
+            ops.gated_mlp_act(nrm, mlp.gate_up_proj.weight, mlp.act, out=act)
+            ops.linear(act, mlp.down_proj.weight, residual=hid, out=hid)
+        torch.cuda.current_stream().synchronize()
 
     def set_sigma(self, sigma: torch.Tensor):
         self.sigma = sigma.to(self.dev, torch.float32).contiguous()
@@ -154,23 +219,33 @@ class StaticDenoiser:
         m, cfg, H = self.model, self.cfg, self.H
         seq2d = self.hid.view(-1, H)
         pos = m.pos_embed[0]
-        ops.embed_gather(self.input_ids, m.llm.embed_tokens.weight, out=self.hid)
-        if self.cond is not None:
+        S = self.S
+        x_rows, t_rows = (self.x_rows_a, self.t_rows_a) if S else (self.x_rows, self.t_rows)
+        rope = self.rope_a if S else self.rope
+        ops.embed_gather(self.ids_a if S else self.input_ids, m.llm.embed_tokens.weight, out=self.hid)
+        if self.cond is not None and not S:
             ops.patch_embed(self.cond, m.input_x_embedder.proj.weight, m.input_x_embedder.proj.bias, pos,
                             self.cond_rows, seq2d, m.pos_embed_max_size)
         ops.timestep_sinusoid(self.ts, m.time_token.freqs(self.dev), out=self.temb_sin)
         tt = m.time_token.mlp
         ops.linear_small(self.temb_sin, tt[0].weight, tt[0].bias, post_act=ops.ACT_SILU, out=self.tt_h)
-        ops.linear_small(self.tt_h, tt[2].weight, tt[2].bias, out=seq2d, out_row=self.t_rows, ldo=H)
-        ops.patch_embed(self.z_model, m.x_embedder.proj.weight, m.x_embedder.proj.bias, pos, self.x_rows, seq2d,
+        ops.linear_small(self.tt_h, tt[2].weight, tt[2].bias, out=seq2d, out_row=t_rows, ldo=H)
+        ops.patch_embed(self.z_model, m.x_embedder.proj.weight, m.x_embedder.proj.bias, pos, x_rows, seq2d,
                         m.pos_embed_max_size)
         nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        for layer in m.llm.layers:
+        for li_, layer in enumerate(m.llm.layers):
             at, mlp = layer.self_attn, layer.mlp
             ops.rmsnorm(self.hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=self.nrm)
-            ops.linear(self.nrm, at.qkv_proj.weight, out=self.qkv)
-            ops.rope_qk_inplace(self.qkv, self.rope[0], self.rope[1], nq, nk, hd)
-            ops.attention_qkv(self.qkv, self.pm, nq, nk, hd, out=self.ctx)
+            if S:
+                full = self.qkv_full[li_]
+                live = full[S:]                                  # this step's q/k/v rows, behind the cached prefix
+                ops.linear(self.nrm, at.qkv_proj.weight, out=live)
+                ops.rope_qk_inplace(live, rope[0], rope[1], nq, nk, hd)
+                ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, S, self.ctx)
+            else:
+                ops.linear(self.nrm, at.qkv_proj.weight, out=self.qkv)
+                ops.rope_qk_inplace(self.qkv, rope[0], rope[1], nq, nk, hd)
+                ops.attention_qkv(self.qkv, self.pm, nq, nk, hd, out=self.ctx)
             ops.linear(self.ctx, at.o_proj.weight, residual=self.hid, out=self.hid)
             ops.rmsnorm(self.hid, layer.post_attention_layernorm.weight,
                         layer.post_attention_layernorm.variance_epsilon, out=self.nrm)
@@ -182,7 +257,7 @@ class StaticDenoiser:
         ops.linear_small(self.te_h, te[2].weight, te[2].bias, out=self.temb)
         ada = m.final_layer.adaLN_modulation[1]
         ops.linear_small(self.temb, ada.weight, ada.bias, pre_act=ops.ACT_SILU, out=self.mod)
-        ops.final_layer(self.nrm.view(-1, H), self.x_rows, self.mod, m.final_layer.linear.weight,
+        ops.final_layer(self.nrm.view(-1, H), x_rows, self.mod, m.final_layer.linear.weight,
                         m.final_layer.linear.bias, self.pred)
 
     def sampler_step(self):

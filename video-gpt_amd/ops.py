@@ -215,6 +215,26 @@ def attention_qkv(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: i
     return out
 
 
+def attention_qkv_range(qkv_full: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: int, head_dim: int,
+                        q_start: int, out_active: torch.Tensor, scale: Optional[float] = None):
+    """Attention of query rows [q_start, L) against all L rows of the fused (1, L, 3H-like) buffer; `out_active`
+    holds the L - q_start computed rows (condition-prefix reuse, see include/vgpt.h)."""
+    _chk(qkv_full, BF16, "attention.qkv"); _chk(out_active, BF16, "attention.out")
+    B, L, width = qkv_full.shape
+    if B != 1 or pm.B != 1 or pm.L != L:
+        raise VgptError("attention_qkv_range: needs the packed single-row layout")
+    if scale is None:
+        scale = 1.0 / math.sqrt(head_dim)
+    hq = n_heads * head_dim
+    kq = qkv_full.data_ptr() + hq * 2
+    vq = kq + n_kv_heads * head_dim * 2
+    o_base = out_active.data_ptr() - q_start * hq * 2   # absolute-row addressing of the active output buffer
+    call("vgpt_attn_blockmask_fwd_qrange", qkv_full.data_ptr(), kq, vq, o_base, q_start, pm.bits.data_ptr(),
+         pm.summary.data_ptr(), 1, L, n_heads, n_kv_heads, head_dim, L * width, head_dim, width, L * width, head_dim,
+         width, L * width, head_dim, width, L * hq, head_dim, hq, float(scale), _stream())
+    return out_active
+
+
 def sdpa(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attn_mask=None, dropout_p: float = 0.0,
          is_causal: bool = False, scale: Optional[float] = None, variant: int = 0):
     """Drop-in for the `local_attn` slot (F.scaled_dot_product_attention) on (B, heads, S, d) tensors.

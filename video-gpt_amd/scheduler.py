@@ -32,6 +32,7 @@ class LVMScheduler:
         self.sigma = t / (t + time_shifting_factor - time_shifting_factor * t)
         self.use_graph = True
         self.pack_padding = True
+        self.reuse_condition_prefix = True   # compute the step-invariant condition rows once per clip (engine.py)
         self.last_engine = None
 
     # ---- fast path ----
@@ -54,7 +55,8 @@ class LVMScheduler:
                               model_kwargs["attention_mask"], lat, model_kwargs["input_image_sizes"],
                               model_kwargs["denoise_image_sizes"], model_kwargs["time_emb_inx"], len(z),
                               tuple(z[0].shape[-2:]), model_kwargs["use_img_cfg"], model_kwargs["img_cfg_scale"],
-                              prediction_type, sigma=self.sigma, pack_padding=self.pack_padding)
+                              prediction_type, sigma=self.sigma, pack_padding=self.pack_padding,
+                              reuse_condition_prefix=self.reuse_condition_prefix)
 
     def __call__(self, z, func, model_kwargs, use_kv_cache: bool = True, offload_kv_cache: bool = True,
                  prediction_type: str = "v", vae=None, noise_level=None):
