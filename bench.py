@@ -132,13 +132,23 @@ def bench_vae(args, rank, world, device, D):
 
 
 def bench_stage1(args, rank, world, device, M, P, D, ops):
+    line = measure_stage1(args.steps, args.warmup, args.layers, rank, world, device, M, P, D)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        D.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=None):
     """cfg-3: stage-1 pre-training, bs 2 clips/GPU of F=8 frames at 256^2 (2 x 3870 tokens), bf16 params with fp32
     master AdamW, gradient all-reduce over RCCL (one bucket per decoder layer, overlapped with backward).
     One step = forward + backward + all-reduce + clip + AdamW.  samples/sec = 2*world*steps/time."""
     TR = importlib.import_module("video-gpt_amd.train")
     F, N, hw, bs = 8, 256, (32, 32), 2
-    cfg = full_config(M, args.layers)
-    model = build_model(M, cfg, device, seed=0)
+    cfg = full_config(M, layers)
+    if model is None:
+        model = build_model(M, cfg, device, seed=0)
     proc = P.LVMProcessor(P.SpecialTokenizer(10, 11, 12))
     rows = []
     for _ in range(bs):
@@ -154,25 +164,24 @@ def bench_stage1(args, rank, world, device, M, P, D, ops):
     t = torch.rand(nd, generator=g).to(device)
     ti = (0.9 + 0.1 * torch.rand(nc, generator=g)).to(device)
     trainer = TR.Stage1Trainer(model, lr=1e-4, weight_decay=0.1, max_grad_norm=1.0)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         loss = trainer.step(batch, x1, x0, t, clean, x0i, ti)
     losses = []
 
     def run():
-        for _ in range(args.steps):
+        for _ in range(steps):
             losses.append(trainer.step(batch, x1, x0, t, clean, x0i, ti))
     elapsed = D.timed_region(run, torch.cuda.synchronize, device)
-    ms = elapsed / max(args.steps, 1) * 1e3
-    valid = int((batch["attention_mask"].all(-1) == 0).sum()) if False else None
+    ms = elapsed / max(steps, 1) * 1e3
     H, I, nl = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
     real = bs * (2 * F - 1) * (N + 2)
     mask = batch["attention_mask"]
     pairs = int(mask.sum().item())  # no pad rows at equal lengths
     fwd = (2 * (4 * H * H + 3 * H * I) * real + 4 * H * pairs) * nl
-    if rank == 0:
-        loss_v = [float(l.mean()) for l in (losses[0], losses[-1])]
-        line = {"metric": "stage-1 train samples/sec (256^2, 8-frame clips, bs 2/GPU, DP)", "value": round(world * bs * args.steps / elapsed, 3),
-                "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+    loss_v = [float(l.mean()) for l in (losses[0], losses[-1])]
+    if True:
+        line = {"metric": "stage-1 train samples/sec (256^2, 8-frame clips, bs 2/GPU, DP)", "value": round(world * bs * steps / elapsed, 3),
+                "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
                 "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"cfg-3 stage-1 pretrain: bs {bs}/GPU x F={F} frames 256^2 ({real} tokens/GPU), "
@@ -182,10 +191,8 @@ def bench_stage1(args, rank, world, device, M, P, D, ops):
                 "roofline": {"bound": "mfma", "kernel": "whole step (fwd + bwd ~ 3 x fwd FLOPs)", "achieved": round(3 * fwd / (ms * 1e-3) / 1e12, 1),
                              "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(3 * fwd / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                              "traffic": None, "alg_tflop_per_step": round(3 * fwd / 1e12, 1)}}
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        D.barrier()
-        torch.distributed.destroy_process_group()
+    del trainer
+    return line
 
 
 def main():
@@ -196,6 +203,8 @@ def main():
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers => INVALID as a benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-stage1", action="store_true",
+                    help="skip the short stage-1 data-parallel training measurement appended to the default line")
     ap.add_argument("--no-prefix-reuse", action="store_true",
                     help="recompute the condition frames at every step exactly as the reference does")
     ap.add_argument("--workload", choices=["infer", "stage1", "vae"], default="infer",
@@ -331,6 +340,19 @@ def main():
                                "achieved": round((flops_step * args.steps + flops_prefill) / elapsed / 1e12, 1),
                                "frac": round((flops_step * args.steps + flops_prefill) / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4)}}
 
+    # ---- second half of the BASELINE metric: stage-1 train samples/sec at this GPU count (data parallel over RCCL),
+    #      a short run (1 warm-up + 3 steps) on the same model; reported inside the same JSON line ----
+    stage1 = None
+    if not args.no_stage1 and args.layers == 32:
+        del eng
+        torch.cuda.empty_cache()
+        try:
+            s1 = measure_stage1(3, 1, args.layers, rank, world, device, M, P, D, model=model)
+            stage1 = {k: s1[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup")}
+            stage1["config"] = s1["config"]
+            stage1["roofline"] = s1["roofline"]
+        except Exception as e:  # keep the headline line even if the training leg fails
+            stage1 = {"error": repr(e)[:300]}
     if rank == 0:
         line = {"metric": "denoised clip-tokens/sec (256^2, 8-frame next-clip, CFG, x1)", "value": round(value, 1),
                 "unit": "clip-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -342,7 +364,7 @@ def main():
                            "global_batch": world, "parallelism": f"replicas x{world}", "graph": use_graph,
                            "condition_prefix_reuse": reuse, "tokens_computed_per_step": real_tokens_step,
                            "finite": finite},
-                "roofline": roof}
+                "roofline": roof, "stage1_train": stage1}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, batch)
         print(json.dumps(line), flush=True)
