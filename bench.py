@@ -140,12 +140,12 @@ def bench_stage1(args, rank, world, device, M, P, D, ops):
         torch.distributed.destroy_process_group()
 
 
-def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=None):
+def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=None, F=8, hw=(32, 32), bs=2):
     """cfg-3: stage-1 pre-training, bs 2 clips/GPU of F=8 frames at 256^2 (2 x 3870 tokens), bf16 params with fp32
     master AdamW, gradient all-reduce over RCCL (one bucket per decoder layer, overlapped with backward).
     One step = forward + backward + all-reduce + clip + AdamW.  samples/sec = 2*world*steps/time."""
     TR = importlib.import_module("video-gpt_amd.train")
-    F, N, hw, bs = 8, 256, (32, 32), 2
+    N = (hw[0] // 2) * (hw[1] // 2)
     cfg = full_config(M, layers)
     if model is None:
         model = build_model(M, cfg, device, seed=0)
@@ -180,11 +180,11 @@ def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=No
     fwd = (2 * (4 * H * H + 3 * H * I) * real + 4 * H * pairs) * nl
     loss_v = [float(l.mean()) for l in (losses[0], losses[-1])]
     if True:
-        line = {"metric": "stage-1 train samples/sec (256^2, 8-frame clips, bs 2/GPU, DP)", "value": round(world * bs * steps / elapsed, 3),
+        line = {"metric": f"train samples/sec ({hw[0] * 8}^2, {F}-frame clips, bs {bs}/GPU, DP)", "value": round(world * bs * steps / elapsed, 3),
                 "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
                 "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": f"cfg-3 stage-1 pretrain: bs {bs}/GPU x F={F} frames 256^2 ({real} tokens/GPU), "
+                "config": {"workload": f"stage-1-layout pretrain step: bs {bs}/GPU x F={F} frames {hw[0] * 8}^2 ({real} tokens/GPU), "
                                        f"Phi-3-mini-class denoiser {nl} layers, bf16 + fp32-master AdamW, clip 1.0"
                                        + ("" if nl == 32 else " [DEBUG layer count: INVALID]"),
                            "global_batch": world * bs, "parallelism": f"dp{world}", "loss_first_last": loss_v},
@@ -207,7 +207,7 @@ def main():
                     help="skip the short stage-1 data-parallel training measurement appended to the default line")
     ap.add_argument("--no-prefix-reuse", action="store_true",
                     help="recompute the condition frames at every step exactly as the reference does")
-    ap.add_argument("--workload", choices=["infer", "stage1", "vae"], default="infer",
+    ap.add_argument("--workload", choices=["infer", "stage1", "stage4", "vae"], default="infer",
                     help="infer = cfg-2 next-clip denoise (default, BASELINE metric part 1); "
                          "stage1 = cfg-3 stage-1 pre-training step, bs 2/GPU, data-parallel (metric part 2)")
     args = ap.parse_args()
@@ -234,6 +234,11 @@ def main():
         return bench_stage1(args, rank, world, device, M, P, D, ops)
     if args.workload == "vae":
         return bench_vae(args, rank, world, device, D)
+    if args.workload == "stage4":   # cfg-4 shapes: 512^2, 16-frame clips (L = 31 806), bs 1/GPU, stage-1 interleaved layout
+        line = measure_stage1(args.steps, args.warmup, args.layers, rank, world, device, M, P, D, F=16, hw=(64, 64), bs=1)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        return
 
     # ---- workload: cfg-2 ----
     C, G, hw = 4, 8, (32, 32)

@@ -194,6 +194,56 @@ def test_stage1_loss_and_gradients_match_autograd():
     assert l1 < l0
 
 
+def test_stage2_frame_block_layout_gradients():
+    """Stage-2+ layout (LVMTraining_CP path: noisy clips of several frames + clean groups, LVM/processor.py:469-500,
+    618-680; frame-block-tied timesteps, loss.py:105-113) through the same trainer vs autograd on the oracle."""
+    cfg = R.TINY
+    P = importlib.import_module("video-gpt_amd.processor")
+    p = {k: v.to(BF).float() for k, v in R.make_params(cfg, 4).items()}
+    proc = P.LVMProcessor(P.SpecialTokenizer(10, 11, 12))
+    fbs = [2, 1, 2]
+    prompt, i, j, n = "", 0, 0, 0
+    for k, fb in enumerate(fbs):
+        for _ in range(fb):
+            prompt += f"<|diffusion|><|image_{i + 1}|>"; i += 1; n += 1
+        if k != len(fbs) - 1:
+            for _ in range(fb):
+                prompt += f"<img><|image_{j + 1}|></img>"; j += 1
+    row = proc.process_multi_modal_prompt_frame_block_training(prompt, [torch.zeros(3, 64, 64) for _ in range(n)], fbs)
+    row["frame_blocks"] = fbs
+    ids, pos, mask, pv, sizes, fb = proc.collator.process_mllm_input_frame_block_training([row])
+    den, inp, tix, idx = {0: []}, {0: []}, {0: []}, 0
+    for k, f in enumerate(fbs):                       # TrainDataCollator_FrameBlock (LVM/train_helper/data.py:503-523)
+        if k != len(fbs) - 1:
+            for _ in range(f):
+                den[0].append(sizes[0][idx]); inp[0].append(sizes[0][idx + f]); tix[0].append(sizes[0][idx][0] - 1); idx += 1
+            idx += f
+        else:
+            for _ in range(f):
+                den[0].append(sizes[0][idx]); tix[0].append(sizes[0][idx][0] - 1); idx += 1
+    batch = dict(input_ids=ids, position_ids=pos, attention_mask=mask, denoise_image_sizes=den, input_image_sizes=inp,
+                 time_emb_inx=tix)
+    gen = torch.Generator("cpu").manual_seed(9)
+    nd, nc = len(den[0]), len(inp[0])
+    mk = lambda m: torch.randn(m, 4, 8, 8, generator=gen)
+    x1, x0, clean, x0i = mk(nd), mk(nd), mk(nc), mk(nc)
+    tb = torch.rand(len(fbs), generator=gen)
+    t = torch.cat([tb[k].repeat(f) for k, f in enumerate(fbs)])          # one t per frame block
+    ti = 0.9 + 0.1 * torch.rand(nc, generator=gen)
+    pr = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in p.items()}
+    loss_ref, _ = R.stage1_loss(pr, cfg, list(x1.split(1)), list(x0.split(1)), t, list(clean.split(1)),
+                                list(x0i.split(1)), ti, batch)
+    loss_ref.mean().backward()
+    model = SC.build_product_model(cfg, p, DEV, cls_name="LVMTraining_CP")
+    TR = importlib.import_module("video-gpt_amd.train")
+    tr = TR.Stage1Trainer(model)
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    loss = tr.step(dbatch, x1, x0, t, clean, x0i, ti, update=False)
+    assert rel_l2(loss, loss_ref.detach()) < 2e-2
+    bad = {n_: rel_l2(tr.grads[n_], r.grad) for n_, r in pr.items() if n_ != "pos_embed" and not rel_l2(tr.grads[n_], r.grad) < 6e-2}
+    assert not bad, bad
+
+
 # ---- data-parallel step: 2 ranks on the one GPU of the test box, gloo transport (RCCL refuses two ranks on
 #      one device); the trainer code path (per-layer bucket all-reduce, 1/world folded into the clip) is the
 #      same one `bench.py --workload stage1 --gpus N` runs over RCCL ----

@@ -21,6 +21,10 @@
 
 #include "common.h"
 
+#ifndef VGPT_GEMM_SETPRIO
+#define VGPT_GEMM_SETPRIO 0
+#endif
+
 namespace {
 
 constexpr int BK = 64;
@@ -54,6 +58,7 @@ struct GemmArgs {
     int act;   // gated mode
     int I;     // gated mode: intermediate size
     int tiles_m, tiles_n;
+    int debug;  // diagnostics only (VGPT_GEMM_DEBUG): 1 = skip the LDS-DMA staging, 2 = skip the LDS fragment reads
 };
 
 __device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
@@ -71,6 +76,8 @@ __device__ __forceinline__ int w_row_of_slot(int n0, int s, int I) {
     }
     return n0 + s;
 }
+
+constexpr bool getenv_prio = VGPT_GEMM_SETPRIO;
 
 template <int MODE, typename C, bool PIPE>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
@@ -119,6 +126,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     char* sW = smem + 2 * C::A_BYTES;   // [2][W_BYTES]
 
     auto stage = [&](int buf, int kt) {
+        if (g.debug & 1) return;
         const int koff = kt * BK;
 #pragma unroll
         for (int i = 0; i < C::A_SLABS; ++i)
@@ -177,26 +185,40 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         // the LAST phase of a tile so the first fragments of tile kt+1 are prefetched under tile kt.
         static_assert(MI == 8 && NI == 4, "pipelined loop is written for the 256x256 / 2x4-wave tile");
         bf16x8 Wf[2][4], Af[2][4];
+        if (g.debug & 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    Wf[u][i] = bf16x8{(bf16)1.f, (bf16)0.5f, (bf16)-1.f, (bf16)2.f, (bf16)1.f, (bf16)0.5f, (bf16)-1.f, (bf16)2.f};
+                    Af[u][i] = Wf[u][i];
+                }
+        }
         auto ldW = [&](bf16x8(&dst)[4], int buf, int ks) {
+            if (g.debug & 2) return;
             const char* b = sW + buf * C::W_BYTES + w_base + ((ks * 4 + fk) ^ sw) * 16;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(b + i * 2048);
         };
         auto ldA = [&](bf16x8(&dst)[4], int buf, int ks, int mh) {
+            if (g.debug & 2) return;
             const char* b = sA + buf * C::A_BYTES + a_base + mh * 8192 + ((ks * 4 + fk) ^ sw) * 16;
 #pragma unroll
             for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(b + j * 2048);
         };
         auto mma = [&](const bf16x8(&wf)[4], const bf16x8(&af)[4], auto mh) {
             constexpr int MH = decltype(mh)::value;
+            if (getenv_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][MH * 4 + j] =
                         __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][MH * 4 + j], 0, 0, 0);
+            if (getenv_prio) __builtin_amdgcn_s_setprio(0);
         };
         auto stage_half = [&](int buf, int kt, int half) {
+            if (g.debug & 1) return;
             const int koff = kt * BK;
 #pragma unroll
             for (int i = 0; i < C::A_SLABS / 2; ++i) {
@@ -308,6 +330,11 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     }
     g.tiles_m = (int)cdiv(g.M, C::BM);
     g.tiles_n = (int)cdiv(n_out, MODE == MODE_GATED ? C::BN / 2 : C::BN);
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("VGPT_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+        g.debug = dbg;
+    }
     hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C, PIPE>), dim3(g.tiles_m * g.tiles_n), dim3(C::THREADS),
                        C::LDS_BYTES, s, g);
     VGPT_CHECK_LAUNCH(name);
