@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 // ------------------------------------------------------------------------------------------------------
 // dQ: block = 4 waves = 128 query rows of one (batch, head); K/V tiles of 64 keys double-buffered in LDS
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     constexpr int STAGE = 2 * TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -186,53 +186,48 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs a) {
         if (code) {
             const char* sk = smem + buf * STAGE;
             const char* sv = sk + TILE_BYTES;
-            bf16x8 Kf[2][KS], Vf[2][KS];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    Kf[kb][s] = row_frag(sk, kb * 32 + r, s, h);
-                    Vf[kb][s] = row_frag(sv, kb * 32 + r, s, h);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 S[2], dP[2];
+            // the two 32-key halves of the tile are processed one after the other (register budget: 2 waves/SIMD)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { S[kb][i] = 0.f; dP[kb][i] = 0.f; }
+                bf16x8 Kf[KS], Vf[KS];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[kb][s], Qf[s], S[kb], 0, 0, 0);
-                    dP[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vf[kb][s], dOf[s], dP[kb], 0, 0, 0);
+                    Kf[s] = row_frag(sk, kb * 32 + r, s, h);
+                    Vf[s] = row_frag(sv, kb * 32 + r, s, h);
                 }
-            }
-            // K^T fragments for dQ^T += K^T dS^T (independent of the element-wise math below)
-            bf16x8 Kt[DT][4];
+                // K^T fragments for dQ^T += K^T dS^T (independent of the element-wise math below)
+                bf16x8 Kt[DT][2];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) Kt[dt][t] = tr_frag(sk, (t >> 1) * 32 + (t & 1) * 16, dt, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            // dS^T = P^T o (dP^T - delta) * scale, P^T = exp2(c S^T - LSE); masked keys -> 0
+                    for (int t = 0; t < 2; ++t) Kt[dt][t] = tr_frag(sk, kb * 32 + t * 16, dt, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 S, dP;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+                for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[s], Qf[s], S, 0, 0, 0);
+                    dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vf[s], dOf[s], dP, 0, 0, 0);
+                }
+                // dS^T = P^T o (dP^T - delta) * scale, P^T = exp2(c S^T - LSE); masked keys -> 0
                 const uint32_t w = (kb ? mw1 : mw0) >> (4 * h);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int bit = (i & 3) + 8 * (i >> 2);
-                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kb][i], a.scale_log2e, -lse));
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], a.scale_log2e, -lse));
                     if (code == 2) p = ((w >> bit) & 1u) ? p : 0.f;
-                    S[kb][i] = p * (dP[kb][i] - dlt) * a.scale;
+                    S[i] = p * (dP[i] - dlt) * a.scale;
                 }
+                bf16x8 dSf[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) dSf[t] = pack8(S, t);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kt[dt][t], dSf[t], dQ[dt], 0, 0, 0);
             }
-            bf16x8 dSf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dSf[t] = pack8(S[t >> 1], t & 1);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kt[dt][t], dSf[t], dQ[dt], 0, 0, 0);
         }
         kt = nxt;
         buf ^= 1;
@@ -356,54 +351,60 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs a) {
             for (int qh = 0; qh < 2; ++qh) {  // two 32-row halves of the query tile
                 const int code = (codes >> (2 * qh)) & 3;
                 if (!code) continue;
-                bf16x8 Qr[KS], dOr[KS];
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    Qr[s] = row_frag(sq, qh * 32 + r, s, h);
-                    dOr[s] = row_frag(sdo, qh * 32 + r, s, h);
-                }
-                __builtin_amdgcn_sched_barrier(0);
                 f32x16 S, dP;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+                {   // S = Q K^T, then dP = dO V^T: one row-fragment set live at a time (register budget)
+                    bf16x8 Qr[KS];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qr[s], Kf[s], S, 0, 0, 0);    // S[q][key]
-                    dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dOr[s], Vf[s], dP, 0, 0, 0);  // dP[q][key]
+                    for (int s = 0; s < KS; ++s) Qr[s] = row_frag(sq, qh * 32 + r, s, h);
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qr[s], Kf[s], S, 0, 0, 0);
                 }
-                // transposed operands for dV^T += dO^T P and dK^T += Q^T dS (k index = query row)
-                bf16x8 dOt[DT][2], Qt[DT][2];
+                {
+                    bf16x8 dOr[KS];
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) dOr[s] = row_frag(sdo, qh * 32 + r, s, h);
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dOr[s], Vf[s], dP, 0, 0, 0);
+                }
+                // transposed operand for dV^T += dO^T P (k index = query row); requested before the element-wise math
+                bf16x8 dOt[DT][2];
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        dOt[dt][t] = tr_frag(sdo, qh * 32 + t * 16, dt, lane);
-                        Qt[dt][t] = tr_frag(sq, qh * 32 + t * 16, dt, lane);
-                    }
+                    for (int t = 0; t < 2; ++t) dOt[dt][t] = tr_frag(sdo, qh * 32 + t * 16, dt, lane);
                 __builtin_amdgcn_sched_barrier(0);
-                f32x16 P;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int qrow = qh * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;  // accumulator row -> query row
                     float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], a.scale_log2e, -st[qrow]));
                     if (code == 2) p = ((mw[qrow * 4 + wave] >> r) & 1u) ? p : 0.f;
                     if (key_row >= a.L || qt * 64 + qrow >= a.L) p = 0.f;
-                    P[i] = p;
-                    S[i] = p * (dP[i] - st[64 + qrow]) * a.scale;  // dS
+                    S[i] = p * (dP[i] - st[64 + qrow]) * a.scale;  // dS (in place)
+                    dP[i] = p;                                      // P  (in place)
                 }
                 bf16x8 Pf[2], dSf[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    Pf[t] = pack8(P, t);
+                    Pf[t] = pack8(dP, t);
                     dSf[t] = pack8(S, t);
                 }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
+                    for (int t = 0; t < 2; ++t)
                         dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dOt[dt][t], Pf[t], dV[dt], 0, 0, 0);
-                        dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qt[dt][t], dSf[t], dK[dt], 0, 0, 0);
-                    }
+                // dK^T += Q^T dS
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x8 Qt[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) Qt[t] = tr_frag(sq, qh * 32 + t * 16, dt, lane);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qt[t], dSf[t], dK[dt], 0, 0, 0);
+                }
             }
             qt = nxt;
             buf ^= 1;
