@@ -83,6 +83,56 @@ def cpu_baseline(cfg_full, batch, layers_sample=2):
                       "to one denoise step (embedders/final layer/Euler update are <0.1% and omitted)"}
 
 
+def synthetic_vae(device):
+    V = importlib.import_module("video-gpt_amd.vae")
+    vae = V.AutoencoderKL()
+    g = torch.Generator("cpu").manual_seed(0)
+    with torch.no_grad():
+        for n_, p_ in vae.named_parameters():
+            if p_.dim() > 1:
+                p_.copy_(torch.randn(p_.shape, generator=g) / p_[0].numel() ** 0.5)
+            elif "norm" in n_ and n_.endswith("weight"):
+                p_.copy_(1 + 0.1 * torch.randn(p_.shape, generator=g))
+            else:
+                p_.copy_(0.02 * torch.randn(p_.shape, generator=g))
+    return vae.to(device, torch.float32).eval()
+
+
+def bench_pipeline(args, rank, world, device, M, P, D):
+    """End-to-end LVMPipeline.prompt_condition_frame_block_autoregressive_inference (LVM/pipeline.py:347-595):
+    VAE-encode 4 condition frames (256^2), sample 8-frame clips with CFG (`--steps` Euler steps each, x1 prediction,
+    hipGraph sampler with condition-prefix reuse), VAE-decode, uint8 frames; `--rounds` chained clips with a
+    16-frame window (cfg-5: --rounds 8).  One "step" of this workload = one whole round."""
+    PL = importlib.import_module("video-gpt_amd.pipeline")
+    cfg = full_config(M, args.layers)
+    model = build_model(M, cfg, device, seed=0)
+    pipe = PL.LVMPipeline(synthetic_vae(device), model, P.LVMProcessor(P.SpecialTokenizer(10, 11, 12)), device=device)
+    g = torch.Generator("cpu").manual_seed(7 + rank)
+    frames = [torch.rand(3, 256, 256, generator=g) * 2 - 1 for _ in range(4)]
+    kw = dict(input_images=frames, height=256, width=256, num_inference_steps=args.steps, use_img_guidance=True,
+              img_guidance_scale=1.6, seed=42, output_type="pt", prediction_type="x1", clean_image_noise_level=0.05,
+              max_frame_window=16)
+    pipe.prompt_condition_frame_block_autoregressive_inference(gen_nums=[8], **dict(kw, num_inference_steps=2))  # warm-up
+    out = []
+
+    def run():
+        out.append(pipe.prompt_condition_frame_block_autoregressive_inference(gen_nums=[8] * args.rounds, **kw))
+    elapsed = D.timed_region(run, torch.cuda.synchronize, device)
+    n_gen = 8 * args.rounds
+    if rank == 0:
+        print(json.dumps({"metric": "end-to-end denoised clip-tokens/sec incl. VAE encode/decode (256^2, 8-frame next-clip, CFG, x1)",
+                          "value": round(world * n_gen * 256 * args.steps / elapsed, 1), "unit": "clip-tokens/s", "n_gpus": world,
+                          "steps": args.rounds, "warmup": 1, "ms_per_step": round(elapsed / args.rounds * 1e3, 1),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": f"LVMPipeline next-clip rollout: {args.rounds} round(s) x 8 frames, {args.steps} Euler steps, "
+                                                 "C=4 condition frames on round 0 then a 16-frame window, fp32 VAE, bf16 denoiser",
+                                     "frames_returned": len(out[0]), "generated_frames_per_s": round(world * n_gen / elapsed, 2)},
+                          "roofline": None}), flush=True)
+    if world > 1:
+        D.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def bench_vae(args, rank, world, device, D):
     """VAE decode / encode of 256^2 frames (sdxl-vae architecture, fp32 like the reference), 8 frames per step.
     Algorithmic work per 256^2 frame: decode 0.622 TFLOP / 1.68 GB fp32 ideal-fusion traffic,
@@ -207,7 +257,8 @@ def main():
                     help="skip the short stage-1 data-parallel training measurement appended to the default line")
     ap.add_argument("--no-prefix-reuse", action="store_true",
                     help="recompute the condition frames at every step exactly as the reference does")
-    ap.add_argument("--workload", choices=["infer", "stage1", "stage4", "vae"], default="infer",
+    ap.add_argument("--rounds", type=int, default=1, help="pipeline workload: chained next-clip rounds (cfg-5 uses 8)")
+    ap.add_argument("--workload", choices=["infer", "stage1", "stage4", "vae", "pipeline"], default="infer",
                     help="infer = cfg-2 next-clip denoise (default, BASELINE metric part 1); "
                          "stage1 = cfg-3 stage-1 pre-training step, bs 2/GPU, data-parallel (metric part 2)")
     args = ap.parse_args()
@@ -234,6 +285,8 @@ def main():
         return bench_stage1(args, rank, world, device, M, P, D, ops)
     if args.workload == "vae":
         return bench_vae(args, rank, world, device, D)
+    if args.workload == "pipeline":
+        return bench_pipeline(args, rank, world, device, M, P, D)
     if args.workload == "stage4":   # cfg-4 shapes: 512^2, 16-frame clips (L = 31 806), bs 1/GPU, stage-1 interleaved layout
         line = measure_stage1(args.steps, args.warmup, args.layers, rank, world, device, M, P, D, F=16, hw=(64, 64), bs=1)
         if rank == 0:
