@@ -36,6 +36,28 @@ struct AttnArgs {
     float scale_log2e;
 };
 
+// One 1-KiB LDS-DMA piece: lane i's 16 bytes at base + off land at lds_dst + 16 i.  Issued from inline asm so
+// the compiler does not know LDS is being written: it would otherwise drain vmcnt(0) before every later LDS read
+// of the OTHER buffer (and at __syncthreads), exposing the prefetch latency.  Completion is tracked by hand:
+// s_waitcnt vmcnt(0) + a raw s_barrier at the top of the tile loop.
+__device__ __forceinline__ void glds16(const char* base, uint32_t off, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(off), "s"(base), "s"(lds_dst)
+        : "memory");
+}
+
+// 4-byte variant (lane i's dword lands at lds_dst + 4 i): the mask words of a mixed tile.
+__device__ __forceinline__ void glds4(const uint32_t* src, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+
 template <int D>
 struct Cfg {
     // D == 96: K/V tiles are contiguous [key][192 B] images filled by LDS-DMA (global_load_lds); the K
@@ -62,6 +84,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     constexpr int KS = D / 16;  // k-steps of the QK^T product
     constexpr int DT = D / 32;  // 32-wide d tiles of the output
     constexpr int STAGE = C::KBYTES + vbytes<D, TR>();
+    constexpr int ACT_MAX = 1023;  // tiles per active-list chunk (list = 4 KiB behind the staging buffers)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -93,7 +116,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     bf16x8 Qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) Qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s + 8 * h);
-    const uint32_t* bits_row = a.bits + ((int64_t)b * a.L + q_ld) * a.W;
 
     f32x16 O[DT];
 #pragma unroll
@@ -106,29 +128,38 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     constexpr bool GLDS = TR && C::GLDS;
     constexpr int PIECES = (64 * D * 2) / 1024 / 4;  // 1-KiB LDS-DMA pieces per wave per operand
     // per-lane (key, source chunk) of each DMA piece this wave issues
-    int g_key[GLDS ? PIECES : 1], g_kchunk[GLDS ? PIECES : 1], g_vchunk[GLDS ? PIECES : 1];
+    // per-lane byte offset (inside a tile) of each 16-byte unit this wave moves; the tile base is wave-uniform
+    int g_key[GLDS ? PIECES : 1];
+    uint32_t g_koff[GLDS ? PIECES : 1], g_voff[GLDS ? PIECES : 1], g_kc[GLDS ? PIECES : 1], g_vc[GLDS ? PIECES : 1];
     if constexpr (GLDS) {
 #pragma unroll
         for (int j = 0; j < PIECES; ++j) {
             const int unit = (wave * PIECES + j) * 64 + lane;  // 16-byte unit inside the tile image
             g_key[j] = unit / C::CHUNKS;
-            g_vchunk[j] = unit % C::CHUNKS;
-            g_kchunk[j] = g_vchunk[j] ^ ((g_key[j] >> 2) & 3);
+            g_vc[j] = (unit % C::CHUNKS) * 16;
+            g_kc[j] = ((unit % C::CHUNKS) ^ ((g_key[j] >> 2) & 3)) * 16;
+            g_koff[j] = (uint32_t)g_key[j] * (uint32_t)a.k_ss * 2u + g_kc[j];
+            g_voff[j] = (uint32_t)g_key[j] * (uint32_t)a.v_ss * 2u + g_vc[j];
         }
     }
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
     auto glds_tile = [&](int buf, int kt) {
         if constexpr (GLDS) {
-            char* sk = smem + buf * STAGE;
+            const char* kt_base = reinterpret_cast<const char*>(kbase + (int64_t)kt * 64 * a.k_ss);
+            const char* vt_base = reinterpret_cast<const char*>(vbase + (int64_t)kt * 64 * a.v_ss);
+            const bool tail = kt * 64 + 64 > a.L;  // wave-uniform: clamp keys past the end onto the last row
 #pragma unroll
             for (int j = 0; j < PIECES; ++j) {
-                const int key = min(kt * 64 + g_key[j], a.L - 1);
-                const int piece_off = (wave * PIECES + j) * 1024;
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(kbase + (int64_t)key * a.k_ss + g_kchunk[j] * 8),
-                    (__attribute__((address_space(3))) void*)(sk + piece_off), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(vbase + (int64_t)key * a.v_ss + g_vchunk[j] * 8),
-                    (__attribute__((address_space(3))) void*)(sk + C::KBYTES + piece_off), 16, 0, 0);
+                uint32_t ko = g_koff[j], vo = g_voff[j];
+                if (tail) {
+                    const uint32_t key = (uint32_t)(min(kt * 64 + g_key[j], a.L - 1) - kt * 64);
+                    ko = key * (uint32_t)a.k_ss * 2u + g_kc[j];
+                    vo = key * (uint32_t)a.v_ss * 2u + g_vc[j];
+                }
+                const uint32_t dst = lds_base + (uint32_t)(buf * STAGE + (wave * PIECES + j) * 1024);
+                glds16(kt_base, ko, dst);
+                glds16(vt_base, vo, dst + C::KBYTES);
             }
         }
     };
@@ -160,42 +191,68 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             }
         }
     };
-    auto next_active = [&](int kt) {
-        for (int k2 = kt + 1; k2 < a.nkt; ++k2)
-            if (sum_row[k2]) return k2;
-        return -1;
-    };
-
-    // mask words of a mixed tile are fetched one tile ahead, BEFORE that tile's LDS-DMA is issued, so the
-    // ordinary loads never sit behind an in-flight DMA in the (in-order) vmcnt queue
-    auto mask_words = [&](int t, uint32_t& w0, uint32_t& w1) {
-        w0 = w1 = 0xffffffffu;
-        if (((sum_row[t] >> (2 * wave)) & 3) == 2) {
-            w0 = (2 * t < a.W) ? bits_row[2 * t] : 0u;
-            w1 = (2 * t + 1 < a.W) ? bits_row[2 * t + 1] : 0u;
+    // ---- active-tile list.  The per-tile summary bytes of this q block are compacted ONCE into LDS
+    //      (entry = tile << 8 | summary byte), ACT_MAX tiles at a time, so the tile loop never issues a global
+    //      load of its own: any such load would sit in the in-order vmcnt queue behind the next tile's LDS-DMA
+    //      and its wait would expose the whole DMA latency. ----
+    uint32_t* alist = reinterpret_cast<uint32_t*>(smem + 2 * STAGE);
+    // mask words of a mixed tile travel by LDS-DMA too (one dword per lane: row lane>>1, word lane&1), one tile
+    // ahead like K/V, into a per-wave 256-byte slot: the tile loop then holds no compiler-tracked global load.
+    constexpr int MASK_OFF = 2 * STAGE + 4096;
+    const uint32_t* mrow_src =
+        a.bits + ((int64_t)b * a.L + min(qb * 128 + wave * 32 + (lane >> 1), a.L - 1)) * a.W;
+    auto mask_dma = [&](int buf_, uint32_t e) {
+        if (((e >> (2 * wave)) & 3) == 2) {
+            const int t = (int)(e >> 8);
+            glds4(mrow_src + min(2 * t + (lane & 1), a.W - 1), lds_base + (uint32_t)(MASK_OFF + buf_ * 1024 + wave * 256));
         }
     };
-    int kt = next_active(-1);
-    int buf = 0;
-    uint32_t mw0 = 0xffffffffu, mw1 = 0xffffffffu;
-    if (kt >= 0) {
-        mask_words(kt, mw0, mw1);
-        if constexpr (GLDS) glds_tile(0, kt); else gload(kt);
+    auto stage = [&](int buf_, int kt_) {
+        if constexpr (GLDS) glds_tile(buf_, kt_); else gload(kt_);
+    };
+    // Pin the Q fragments: the compiler must retire their global loads HERE.  Left pending, their first use sits
+    // inside the tile loop and the vmcnt(0) emitted for it would also drain the (asm-issued) LDS-DMA in flight.
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(Qf[s]));
+    for (int chunk0 = 0; chunk0 < a.nkt; chunk0 += ACT_MAX) {
+    __syncthreads();  // every wave is done with the previous list and the staging buffers
+    if (wave == 0) {
+        const int lim = min(chunk0 + ACT_MAX, a.nkt);
+        int n = 0;
+        for (int base = chunk0; base < lim; base += 64) {
+            const int t = base + lane;
+            const uint32_t c = t < lim ? sum_row[t] : 0u;
+            const uint64_t bal = __ballot(c != 0);
+            if (c) alist[1 + n + __popcll(bal & ((1ull << lane) - 1))] = ((uint32_t)t << 8) | c;
+            n += __popcll(bal);
+        }
+        if (lane == 0) alist[0] = (uint32_t)n;
     }
-    while (kt >= 0) {
+    __syncthreads();
+    const int n_act = __builtin_amdgcn_readfirstlane((int)alist[0]);
+    if (n_act == 0) continue;
+    uint32_t e_cur = __builtin_amdgcn_readfirstlane(alist[1]);
+    uint32_t e_nxt = __builtin_amdgcn_readfirstlane(n_act > 1 ? alist[2] : 0u);
+    int buf = 0;
+    mask_dma(0, e_cur);
+    stage(0, (int)(e_cur >> 8));
+    for (int it = 0; it < n_act; ++it) {
         if constexpr (GLDS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed
+            // this wave's share of the current tile has landed; the raw barrier then (a) publishes every wave's
+            // share and (b) guarantees every wave is done reading the other buffer before it is refilled
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         } else {
             lds_store(buf);
+            __syncthreads();
         }
-        __syncthreads();
-        const int nxt = next_active(kt);
-        uint32_t nw0 = 0xffffffffu, nw1 = 0xffffffffu;
-        if (nxt >= 0) {
-            mask_words(nxt, nw0, nw1);
-            if constexpr (GLDS) glds_tile(buf ^ 1, nxt); else gload(nxt);
+        const uint32_t e_n2 = it + 2 < n_act ? alist[3 + it] : 0u;  // consumed at the end of the iteration
+        if (it + 1 < n_act) {
+            mask_dma(buf ^ 1, e_nxt);
+            stage(buf ^ 1, (int)(e_nxt >> 8));
         }
-        const int code = (sum_row[kt] >> (2 * wave)) & 3;
+        const int code = (e_cur >> (2 * wave)) & 3;
         if (code) {
             const char* sk = smem + buf * STAGE;
             const char* sv = sk + C::KBYTES;
@@ -249,6 +306,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             __builtin_amdgcn_sched_barrier(0);
             // ---- mask (mixed tiles only), row max on raw scores; scale folded into the exp2 FMA ----
             if (code == 2) {
+                const uint2 mw = *reinterpret_cast<const uint2*>(smem + MASK_OFF + buf * 1024 + wave * 256 + r * 8);
+                const uint32_t mw0 = mw.x, mw1 = (2 * (int)(e_cur >> 8) + 1 < a.W) ? mw.y : 0u;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     const uint32_t w = (kb ? mw1 : mw0) >> (4 * h);
@@ -300,10 +359,10 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
                 for (int t = 0; t < 4; ++t)
                     O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vf[dt][t], Pf[t], O[dt], 0, 0, 0);
         }
-        kt = nxt;
+        e_cur = e_nxt;
+        e_nxt = __builtin_amdgcn_readfirstlane(e_n2);
         buf ^= 1;
-        mw0 = nw0;
-        mw1 = nw1;
+    }
     }
 
     // ---- epilogue: lane holds O^T[d = 32dt + (i&3) + 8(i>>2) + 4h][q = r] ----
@@ -326,7 +385,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
 
 template <int D, bool TR>
 int launch(const AttnArgs& a, hipStream_t s) {
-    constexpr int lds = 2 * (Cfg<D>::KBYTES + vbytes<D, TR>());
+    constexpr int lds = 2 * (Cfg<D>::KBYTES + vbytes<D, TR>()) + 4096 + 2048;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, TR>,
@@ -377,6 +436,8 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
                  VGPT_ERR_UNSUPPORTED, "vgpt_attn_blockmask_fwd: q/k/v must be 16-byte aligned");
     VGPT_REQUIRE(L < (1 << 24) && B * n_heads * cdiv(L, 128) < (1ll << 31), VGPT_ERR_UNSUPPORTED,
                  "vgpt_attn_blockmask_fwd: problem too large");
+    VGPT_REQUIRE(k_ss > 0 && v_ss > 0 && k_ss < (1 << 24) && v_ss < (1 << 24), VGPT_ERR_UNSUPPORTED,
+                 "vgpt_attn_blockmask_fwd: key/value row strides must be in (0, 2^24) elements");
     VGPT_REQUIRE(q_start >= 0 && q_start % 128 == 0 && q_start <= L, VGPT_ERR_INVALID,
                  "vgpt_attn_blockmask_fwd: q_start must be a multiple of 128 in [0, L]");
     if (B == 0 || L == 0 || q_start >= L) return VGPT_OK;
