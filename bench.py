@@ -257,6 +257,7 @@ def main():
                     help="skip the short stage-1 data-parallel training measurement appended to the default line")
     ap.add_argument("--no-prefix-reuse", action="store_true",
                     help="recompute the condition frames at every step exactly as the reference does")
+    ap.add_argument("--breakdown", action="store_true", help="add per-operator HIP-event times of one eager denoise step")
     ap.add_argument("--rounds", type=int, default=1, help="pipeline workload: chained next-clip rounds (cfg-5 uses 8)")
     ap.add_argument("--workload", choices=["infer", "stage1", "stage4", "vae", "pipeline"], default="infer",
                     help="infer = cfg-2 next-clip denoise (default, BASELINE metric part 1); "
@@ -398,6 +399,37 @@ def main():
                                "achieved": round((flops_step * args.steps + flops_prefill) / elapsed / 1e12, 1),
                                "frac": round((flops_step * args.steps + flops_prefill) / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4)}}
 
+    breakdown = None
+    if rank == 0 and args.breakdown:
+        names = ["linear", "gated_mlp_act", "attention_qkv", "attention_qkv_range", "rmsnorm", "rope_qk_inplace"]
+        evs = {n: [] for n in names}
+        saved = {n: getattr(ops, n) for n in names}
+
+        def wrap(n):
+            def f(*a, **k):
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record(stream)
+                out = saved[n](*a, **k)
+                e_.record(stream)
+                evs[n].append((s_, e_))
+                return out
+            return f
+        with torch.cuda.stream(stream):
+            for n in names:
+                setattr(ops, n, wrap(n))
+            try:
+                for _ in range(3):
+                    for n in names:
+                        evs[n].clear()
+                    eng.step.zero_()
+                    ops.sampler_set_timesteps(eng.sigma, eng.step, eng.ts)
+                    eng.forward_step()
+            finally:
+                for n in names:
+                    setattr(ops, n, saved[n])
+            stream.synchronize()
+        breakdown = {n: {"calls": len(v), "ms": round(sum(a.elapsed_time(b) for a, b in v), 3)} for n, v in evs.items() if v}
+
     # ---- second half of the BASELINE metric: stage-1 train samples/sec at this GPU count (data parallel over RCCL),
     #      a short run (1 warm-up + 3 steps) on the same model; reported inside the same JSON line ----
     stage1 = None
@@ -423,6 +455,8 @@ def main():
                            "condition_prefix_reuse": reuse, "tokens_computed_per_step": real_tokens_step,
                            "finite": finite},
                 "roofline": roof, "stage1_train": stage1}
+        if breakdown:
+            line["breakdown_ms_per_step"] = breakdown
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, batch)
         print(json.dumps(line), flush=True)

@@ -119,12 +119,43 @@ int vgpt_attn_supported(int head_dim);
 /* Same, computing only query rows [q_start, L) (q_start % 128 == 0) against ALL L keys: rows before q_start are a
  * cached, step-invariant key/value prefix (condition frames never see the clip being denoised, LVM/processor.py:
  * 682-731, so their K/V need not be recomputed every denoise step as LVM/scheduler.py:174 does).  q, o and the mask
- * are indexed by absolute row. */
+ * are indexed by absolute row.  order: NULL, or the launch order computed by vgpt_attn_qblock_order for the same
+ * (summary, q_start): block masks give q blocks very different key counts, and starting the long ones first keeps
+ * the launch from ending on a few stragglers (results do not depend on it). */
 int vgpt_attn_blockmask_fwd_qrange(const void* q, const void* k, const void* v, void* o, int64_t q_start,
-                                   const uint32_t* bits, const uint8_t* summary, int64_t B, int64_t L, int n_heads,
+                                   const uint32_t* bits, const uint8_t* summary, const int32_t* order, int64_t B, int64_t L,
+                                   int n_heads,
                                    int n_kv_heads, int head_dim, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
                                    int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb,
                                    int64_t o_sh, int64_t o_ss, float scale, void* stream);
+
+/* ---- planned forward.  A PLAN describes the query side of one mask:
+ *   items         (n_items, 4) int32: {batch, row0, nrows (1..item_rows), 0}; disjoint row ranges, cut wherever the
+ *                 caller likes -- at the boundaries of packed sequences, so that no item mixes rows with different key
+ *                 sets (an aligned block straddling two sequences would walk the key tiles of both);
+ *   item_summary  (n_items, ceil(L/64)) uint16: 2 bits per 32-row slab of the item (0 none / 1 all / 2 mixed);
+ *   order         (n_items) int32: items sorted longest first.
+ * item_rows selects the kernel: 128 = the 4-wave kernel of vgpt_attn_blockmask_fwd (two workgroups per CU; the default
+ * of the Python host), 256 = an 8-wave kernel (head_dim 96 only) whose two wave groups alternate matrix and vector
+ * phases under workgroup barriers -- measured slower on MI355X at the cfg-2 shapes and kept selectable.
+ * vgpt_attn_plan_build fills item_summary and order from bits and items.  vgpt_attn_fwd_plan computes exactly the rows
+ * the items cover (same math as vgpt_attn_blockmask_fwd); lse may be NULL. */
+int vgpt_attn_plan_build(const uint32_t* bits, int64_t B, int64_t L, const int32_t* items, int64_t n_items, int item_rows,
+                         uint16_t* item_summary, int32_t* order, void* stream);
+int vgpt_attn_fwd_plan(const void* q, const void* k, const void* v, void* o, float* lse, const uint32_t* bits,
+                       const int32_t* items, const uint16_t* item_summary, const int32_t* order, int64_t n_items,
+                       int item_rows, int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim, int64_t q_sb,
+                       int64_t q_sh, int64_t q_ss, int64_t k_sb, int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
+                       int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss, float scale, void* stream);
+
+/* order (B, ceil(L/128) - q_start/128) int32 <- the 128-row q blocks [q_start/128, ...) of every batch item, the one
+ * with the most non-empty 64-key tiles first (stable). */
+int vgpt_attn_qblock_order(const uint8_t* summary, int64_t B, int64_t L, int64_t q_start, int32_t* order, void* stream);
+
+/* Diagnostics: while `buf` (device memory, 4 x uint64 per workgroup) is set, every forward launch with at most
+ * `capacity_workgroups` workgroups records {start, end (100 MHz realtime ticks), XCC_ID<<32|HW_ID, work item<<32 |
+ * key tiles processed} per workgroup.  buf = NULL switches it off (the default). */
+int vgpt_attn_trace(void* buf, int64_t capacity_workgroups);
 
 /* ---- model glue ---------------------------------------------------------- */
 
@@ -218,9 +249,11 @@ int vgpt_affine_to_f32(const void* x, int x_is_bf16, float* y, int64_t n, float 
 /* ---- stage-1 pre-training step (LVM/train_helper/loss.py:128-243, LVM/train/train_x1_stage1_noiseinput.py:351-405;
  *      the reference gets these from torch.autograd + DeepSpeed) ---------------------------------------- */
 
-/* Attention forward that also returns the base-2 log-sum-exp of the scaled scores, lse (B, n_heads, L) fp32. */
+/* Attention forward that also returns the base-2 log-sum-exp of the scaled scores, lse (B, n_heads, L) fp32.
+ * order: NULL or the launch order from vgpt_attn_qblock_order(q_start = 0). */
 int vgpt_attn_blockmask_fwd_lse(const void* q, const void* k, const void* v, void* o, float* lse,
-                                const uint32_t* bits, const uint8_t* summary, int64_t B, int64_t L, int n_heads,
+                                const uint32_t* bits, const uint8_t* summary, const int32_t* order, int64_t B, int64_t L,
+                                int n_heads,
                                 int n_kv_heads, int head_dim, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
                                 int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb,
                                 int64_t o_sh, int64_t o_ss, float scale, void* stream);

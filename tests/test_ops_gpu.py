@@ -226,6 +226,122 @@ def test_attention_fused_qkv(ops, variant, B, L, nh, nkv, hd):
     assert float((out.cpu().double() - ref).abs().max()) < 0.05
 
 
+@pytest.mark.parametrize("B,L,q_start", [(1, 700, 0), (2, 1300, 0), (1, 1500, 256), (1, 64, 0)])
+def test_qblock_order(ops, B, L, q_start):
+    """Longest-first launch order == stable descending sort of the non-empty key tiles per q block."""
+    m = _random_block_mask(B, L, 21)
+    pm = ops.pack_mask(torch.from_numpy(m).to(DEV))
+    got = pm.order(q_start).cpu().numpy()
+    cnt = (_np_summary(m) != 0).sum(-1)[:, q_start // 128:]
+    for b in range(B):
+        want = np.argsort(-cnt[b], kind="stable") + q_start // 128
+        assert np.array_equal(got[b], want)
+
+
+@pytest.mark.parametrize("B,L,nh,nkv", [(1, 700, 8, 8), (2, 520, 4, 2), (1, 1100, 16, 4)])
+def test_attention_launch_order_is_result_neutral(ops, B, L, nh, nkv):
+    """The ordered, XCD-grouped work mapping (n_heads * B % 8 == 0) computes exactly what the plain mapping does."""
+    import importlib
+    lib = importlib.import_module("video-gpt_amd._lib")
+    hd = 96
+    m = _random_block_mask(B, L, 22)
+    # make the q blocks unequal so the order is not the identity
+    m[:, : L // 3, L // 2:] = 0
+    for b in range(B):
+        np.fill_diagonal(m[b], 1)
+    qkv = bf(torch.randn(B, L, (nh + 2 * nkv) * hd, generator=g(23))).to(DEV, BF)
+    pm = ops.pack_mask(torch.from_numpy(m).to(DEV))
+    out = ops.attention_qkv(qkv, pm, nh, nkv, hd, variant=2)   # 4-wave kernel, ordered launch
+    plain = torch.empty_like(out)
+    width = qkv.shape[-1]
+    kq = qkv.data_ptr() + nh * hd * 2
+    vq = kq + nkv * hd * 2
+    sb = L * width
+    lib.call("vgpt_attn_blockmask_fwd", qkv.data_ptr(), kq, vq, plain.data_ptr(), pm.bits.data_ptr(), pm.summary.data_ptr(),
+             B, L, nh, nkv, hd, sb, hd, width, sb, hd, width, sb, hd, width, L * nh * hd, hd, nh * hd,
+             1.0 / math.sqrt(hd), 0, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(out, plain)
+    assert not np.array_equal(pm.order(0).cpu().numpy()[0], np.arange((L + 127) // 128))
+
+
+def _np_item_summary(m, items):
+    B, L, _ = m.shape
+    nkt = (L + 63) // 64
+    out = np.zeros((len(items), nkt), dtype=np.uint16)
+    for n, (b, r0, nr, _) in enumerate(items):
+        for kt in range(nkt):
+            code = 0
+            for s_ in range(8):
+                rows = m[b, r0 + 32 * s_: min(r0 + 32 * s_ + 32, r0 + nr), kt * 64: kt * 64 + 64]
+                if rows.shape[0] == 0 or not rows.any():
+                    c = 0
+                elif rows.shape[1] == 64 and rows.all():
+                    c = 1
+                else:
+                    c = 2
+                code |= c << (2 * s_)
+            out[n, kt] = code
+    return out
+
+
+@pytest.mark.parametrize("item_rows", [128, 256])
+@pytest.mark.parametrize("B,L,segs", [(1, 700, None), (2, 530, None), (1, 900, ((0, 0, 300), (0, 300, 316), (0, 316, 900))),
+                                      (1, 64, None), (1, 1300, ((0, 256, 1300),))])
+def test_attention_plan_build(ops, B, L, segs, item_rows):
+    """Items, their 16-bit tile summaries and the longest-first order (vgpt_attn_plan_build) against numpy."""
+    m = _random_block_mask(B, L, 31)
+    m[:, : L // 3, L // 2:] = 0
+    pm = ops.pack_mask(torch.from_numpy(m).to(DEV))
+    plan = pm.plan(segs, item_rows)
+    items = plan.items.cpu().numpy()
+    want_items = [(b, r, min(item_rows, r1 - r), 0) for b, r0, r1 in (segs or [(b, 0, L) for b in range(B)])
+                  for r in range(r0, r1, item_rows)]
+    assert items.tolist() == [list(t) for t in want_items]
+    summ = plan.summary.cpu().numpy().view(np.uint16)[: len(want_items)]
+    want = _np_item_summary(m, want_items)
+    assert np.array_equal(summ, want)
+    cnt = np.array([(want[i] != 0).sum() if (want_items[i][2] > 32 or item_rows == 128) else ((want[i] != 0).sum() + 7) // 8
+                    for i in range(len(want_items))])
+    assert np.array_equal(plan.order.cpu().numpy()[: len(want_items)], np.argsort(-cnt, kind="stable"))
+
+
+@pytest.mark.parametrize("item_rows,hd", [(128, 96), (256, 96), (128, 128), (128, 64)])
+@pytest.mark.parametrize("B,L,nh,nkv,segs", [(1, 700, 8, 8, None), (2, 530, 4, 2, None), (1, 1100, 16, 4, None),
+                                             (1, 900, 3, 3, ((0, 0, 300), (0, 300, 316), (0, 316, 900))),
+                                             (1, 1300, 8, 8, ((0, 256, 790), (0, 790, 1300)))])
+def test_attention_planned_kernel(ops, B, L, nh, nkv, segs, item_rows, hd):
+    """Planned launches (arbitrary row segments, longest-first order; 4-wave kernel on 128-row items, 8-wave kernel with
+    thin items on 256-row items) against the fp64 reference and, bit for bit on the rows of ordinary items, against
+    the 4-wave kernel on aligned q blocks."""
+    m = _random_block_mask(B, L, 32)
+    m[:, : L // 3, L // 2:] = 0
+    for b in range(B):
+        np.fill_diagonal(m[b], 1)
+    qkv = bf(torch.randn(B, L, (nh + 2 * nkv) * hd, generator=g(33)))
+    pm = ops.pack_mask(torch.from_numpy(m).to(DEV))
+    dq = qkv.to(DEV, BF)
+    legacy = ops.attention_qkv(dq, pm, nh, nkv, hd, variant=2)
+    if segs is None:
+        out = ops.attention_qkv(dq, pm, nh, nkv, hd, variant=3 if item_rows == 256 else 0)
+        covered = [(b, 0, L) for b in range(B)]
+    else:
+        out = torch.full((B, L, nh * hd), 7.0, dtype=BF, device=DEV)
+        ops.attention_qkv_range(dq, pm, nh, nkv, hd, 0, out, segments=segs, item_rows=item_rows)
+        covered = list(segs)
+    q = qkv[..., : nh * hd].view(B, L, nh, hd).transpose(1, 2)
+    k = qkv[..., nh * hd:(nh + nkv) * hd].view(B, L, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
+    v = qkv[..., (nh + nkv) * hd:].view(B, L, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
+    ref = _ref_attention(q, k, v, torch.from_numpy(m), 1 / math.sqrt(hd)).transpose(1, 2).reshape(B, L, -1)
+    seen = torch.zeros(B, L, dtype=torch.bool)
+    for b, r0, r1 in covered:
+        seen[b, r0:r1] = True
+        assert rel_l2(out[b, r0:r1], ref[b, r0:r1]) < 1e-2
+        for r in range(r0, r1, item_rows):
+            if min(item_rows, r1 - r) > 32 or item_rows == 128:   # ordinary item: same per-row operation sequence
+                assert torch.equal(out[b, r:min(r + item_rows, r1)], legacy[b, r:min(r + item_rows, r1)])
+    assert bool((out.cpu()[~seen].float() == 7.0).all())   # rows outside the segments are not touched
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_attention_forced_rescale(ops, variant):
     """Spike one key late in the sequence so the running max jumps at a later tile (online-softmax rescale)."""

@@ -11,7 +11,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvgpt_hip.so")
+# VGPT_LIB selects another build of the same library (the `make stamps` diagnostic build); never a different backend
+LIB_PATH = os.environ.get("VGPT_LIB") or os.path.join(_HERE, "libvgpt_hip.so")
 
 # enums mirrored from include/vgpt.h
 ACT_SILU, ACT_GELU, ACT_GELU_TANH, ACT_NONE = 0, 1, 2, 3
@@ -40,7 +41,12 @@ SIGNATURES = {
     ),
     "vgpt_attn_supported": (c_int, [c_int]),
     "vgpt_attn_blockmask_fwd_qrange": (
-        c_int, [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
+        c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
+    "vgpt_attn_qblock_order": (c_int, [_P, _I64, _I64, _I64, _P, _P]),
+    "vgpt_attn_trace": (c_int, [_P, _I64]),
+    "vgpt_attn_plan_build": (c_int, [_P, _I64, _I64, _P, _I64, c_int, _P, _P, _P]),
+    "vgpt_attn_fwd_plan": (
+        c_int, [_P] * 9 + [_I64, c_int, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
     "vgpt_embed_gather": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "vgpt_patch_embed_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64, c_int, _P]),
     "vgpt_timestep_sinusoid": (c_int, [_P, _P, _P, c_int, c_int, _P]),
@@ -57,7 +63,7 @@ SIGNATURES = {
     "vgpt_vae_postprocess_u8": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vgpt_affine_to_f32": (c_int, [_P, c_int, _P, _I64, c_float, c_float, _P]),
     "vgpt_attn_blockmask_fwd_lse": (
-        c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
+        c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
     "vgpt_attn_blockmask_bwd": (
         c_int, [_P] * 12 + [_I64, _I64, c_int, c_int, c_int, _P, c_float, _P]),
     "vgpt_transpose_pad_bf16": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _P]),

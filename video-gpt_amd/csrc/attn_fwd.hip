@@ -27,6 +27,13 @@ struct AttnArgs {
     bf16* o;
     const uint32_t* bits;
     const uint8_t* summary;
+    const int32_t* order;  // optional (B, nqb - qb0): q blocks in launch order (vgpt_attn_qblock_order)
+    // planned launches (vgpt_attn_fwd_plan with 128-row items): work item = (items[order[rank]], head); then
+    // `summary`/`order` above are unused
+    const int32_t* items;      // n_items x 4: batch, row0, nrows (<= 128), 0
+    const uint16_t* isum;      // n_items x nkt, 2 bits per 32-row slab
+    const int32_t* iorder;     // n_items
+    int n_items;
     float* lse;  // optional (B, n_heads, L): base-2 log-sum-exp of the scaled scores, for the backward
     int B, L, n_heads, kv_group;  // kv_group = n_heads / n_kv_heads
     int W;                        // mask words per row
@@ -34,6 +41,7 @@ struct AttnArgs {
     int qb0;                      // first q block computed (rows before qb0*128 are keys only: cached prefix)
     int64_t q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss;
     float scale_log2e;
+    unsigned long long* trace;  // diagnostics (vgpt_attn_trace): 4 x u64 per workgroup, or null
 };
 
 // One 1-KiB LDS-DMA piece: lane i's 16 bytes at base + off land at lds_dst + 16 i.  Issued from inline asm so
@@ -91,27 +99,63 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    int n_tiles_done = 0;
 
-    // ---- work item: keep all q blocks of a (batch, head) on one XCD (shared K/V in its L2) ----
-    const int nqa = a.nqb - a.qb0;  // q blocks actually computed
-    const int total = nqa * a.n_heads * a.B;
-    int wid = blockIdx.x;
-    {
-        const int xcd = wid & 7, qn = total >> 3, rn = total & 7;
-        wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (wid >> 3);
+    // ---- work item ----
+    int wid = blockIdx.x, head, b, row0, row_last;
+    const uint8_t* sum8 = nullptr;
+    const uint16_t* sum16 = nullptr;
+    if (a.items) {
+        // XCD x (workgroups x, x+8, ...) owns n_heads/8 consecutive heads -- their K/V stay in its L2 -- and walks the
+        // items longest first, so every head's long items start before any short one
+        int rank;
+        if ((a.n_heads & 7) == 0) {
+            const int per = a.n_heads >> 3, j = wid >> 3;
+            rank = j / per;
+            head = (wid & 7) * per + j % per;
+        } else {
+            rank = wid / a.n_heads;
+            head = wid % a.n_heads;
+        }
+        const int item = a.iorder[rank];
+        b = a.items[4 * item];
+        row0 = a.items[4 * item + 1];
+        row_last = row0 + a.items[4 * item + 2] - 1;
+        sum16 = a.isum + (int64_t)item * a.nkt;
+        wid = item;
+    } else {
+        // aligned 128-row q blocks; keep all q blocks of a (batch, head) on one XCD
+        const int nqa = a.nqb - a.qb0;  // q blocks actually computed
+        const int nbh = a.n_heads * a.B;
+        const int total = nqa * nbh;
+        int qrank, bh;
+        if ((nbh & 7) == 0) {
+            const int per = nbh >> 3, j = wid >> 3;
+            qrank = j / per;
+            bh = (wid & 7) * per + j % per;
+            wid = bh * nqa + qrank;
+        } else {
+            const int xcd = wid & 7, qn = total >> 3, rn = total & 7;
+            wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (wid >> 3);
+            qrank = wid % nqa;
+            bh = wid / nqa;
+        }
+        head = bh % a.n_heads;
+        b = bh / a.n_heads;
+        const int qb = a.order ? a.order[b * nqa + qrank] : a.qb0 + qrank;
+        row0 = qb * 128;
+        row_last = min(row0 + 127, a.L - 1);
+        sum8 = a.summary + ((int64_t)b * a.nqb + qb) * a.nkt;
     }
-    const int qb = a.qb0 + wid % nqa;
-    const int head = (wid / nqa) % a.n_heads;
-    const int b = wid / (nqa * a.n_heads);
     const int kvh = head / a.kv_group;
-
-    const uint8_t* sum_row = a.summary + ((int64_t)b * a.nqb + qb) * a.nkt;
     const bf16* kbase = a.k + (int64_t)b * a.k_sb + (int64_t)kvh * a.k_sh;
     const bf16* vbase = a.v + (int64_t)b * a.v_sb + (int64_t)kvh * a.v_sh;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q][16s + 8h .. +8) ----
-    const int q_row = qb * 128 + wave * 32 + r;
-    const int q_ld = min(q_row, a.L - 1);
+    const int q_row = row0 + wave * 32 + r;
+    const bool q_valid = q_row <= row_last;
+    const int q_ld = min(q_row, row_last);
     const bf16* qp = a.q + (int64_t)b * a.q_sb + (int64_t)head * a.q_sh + (int64_t)q_ld * a.q_ss;
     bf16x8 Qf[KS];
 #pragma unroll
@@ -200,7 +244,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     // ahead like K/V, into a per-wave 256-byte slot: the tile loop then holds no compiler-tracked global load.
     constexpr int MASK_OFF = 2 * STAGE + 4096;
     const uint32_t* mrow_src =
-        a.bits + ((int64_t)b * a.L + min(qb * 128 + wave * 32 + (lane >> 1), a.L - 1)) * a.W;
+        a.bits + ((int64_t)b * a.L + min(row0 + wave * 32 + (lane >> 1), row_last)) * a.W;
     auto mask_dma = [&](int buf_, uint32_t e) {
         if (((e >> (2 * wave)) & 3) == 2) {
             const int t = (int)(e >> 8);
@@ -221,7 +265,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         int n = 0;
         for (int base = chunk0; base < lim; base += 64) {
             const int t = base + lane;
-            const uint32_t c = t < lim ? sum_row[t] : 0u;
+            const uint32_t c = t < lim ? (sum16 ? (uint32_t)sum16[t] & 0xffu : (uint32_t)sum8[t]) : 0u;
             const uint64_t bal = __ballot(c != 0);
             if (c) alist[1 + n + __popcll(bal & ((1ull << lane) - 1))] = ((uint32_t)t << 8) | c;
             n += __popcll(bal);
@@ -231,6 +275,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     __syncthreads();
     const int n_act = __builtin_amdgcn_readfirstlane((int)alist[0]);
     if (n_act == 0) continue;
+    n_tiles_done += n_act;
     uint32_t e_cur = __builtin_amdgcn_readfirstlane(alist[1]);
     uint32_t e_nxt = __builtin_amdgcn_readfirstlane(n_act > 1 ? alist[2] : 0u);
     int buf = 0;
@@ -318,25 +363,25 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
                     }
                 }
             }
-            float mx = -INFINITY;
+            float mxp[2] = {-INFINITY, -INFINITY};  // two chains: the max3 latency, not its issue, would pace one
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, S[kb][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2e;  // scale > 0: max commutes with it
+                for (int i = 0; i < 16; ++i) mxp[kb] = fmaxf(mxp[kb], S[kb][i]);
+            const float mx = half_max(fmaxf(mxp[0], mxp[1])) * a.scale_log2e;  // scale > 0: max commutes with it
             const float m_new = fmaxf(m_i, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_i - m_use);
-            float rs = 0.f;
+            float rsp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kb][i], a.scale_log2e, -m_use));
                     S[kb][i] = p;
-                    rs += p;
+                    rsp[i & 3] += p;
                 }
-            rs += __shfl_xor(rs, 32, 64);
+            const float rs = half_sum((rsp[0] + rsp[1]) + (rsp[2] + rsp[3]));
             l_i = l_i * alpha + rs;
             // rescale the accumulator only when some row's running max moved (wave-uniform branch)
             if (__any(m_new != m_i)) {
@@ -365,10 +410,20 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     }
     }
 
+    if (a.trace && tid == 0) {
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        unsigned long long* t = a.trace + 4ull * blockIdx.x;
+        t[0] = t_start;
+        t[1] = __builtin_amdgcn_s_memrealtime();
+        t[2] = ((unsigned long long)xcc_id << 32) | hw_id;
+        t[3] = ((unsigned long long)(unsigned)wid << 32) | (unsigned)n_tiles_done;
+    }
     // ---- epilogue: lane holds O^T[d = 32dt + (i&3) + 8(i>>2) + 4h][q = r] ----
-    if (a.lse && q_row < a.L && h == 0)
+    if (a.lse && q_valid && h == 0)
         a.lse[((int64_t)b * a.n_heads + head) * a.L + q_row] = l_i > 0.f ? m_i + __builtin_amdgcn_logf(l_i) : INFINITY;
-    if (q_row < a.L) {
+    if (q_valid) {
         const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
         bf16* op = a.o + (int64_t)b * a.o_sb + (int64_t)head * a.o_sh + (int64_t)q_row * a.o_ss;
 #pragma unroll
@@ -396,7 +451,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
         }
         attr_set = true;
     }
-    const int total = (a.nqb - a.qb0) * a.n_heads * a.B;
+    const int total = a.items ? a.n_items * a.n_heads : (a.nqb - a.qb0) * a.n_heads * a.B;
     hipLaunchKernelGGL((attn_fwd_kernel<D, TR>), dim3(total), dim3(256), lds, s, a);
     VGPT_CHECK_LAUNCH("vgpt_attn_blockmask_fwd");
     return VGPT_OK;
@@ -404,18 +459,38 @@ int launch(const AttnArgs& a, hipStream_t s) {
 
 }  // namespace
 
+static unsigned long long* g_trace = nullptr;
+static int64_t g_trace_cap = 0;
+
+void vgpt_attn_pp_set_trace(void* buf, int64_t cap);  // attn_fwd_pp.hip
+
+VGPT_EXPORT int vgpt_attn_trace(void* buf, int64_t capacity_workgroups) {
+    vgpt_attn_pp_set_trace(buf, capacity_workgroups);
+    g_trace = (unsigned long long*)buf;
+    g_trace_cap = buf ? capacity_workgroups : 0;
+    return VGPT_OK;
+}
+
 VGPT_EXPORT int vgpt_attn_supported(int head_dim) {
     return head_dim == 64 || head_dim == 96 || head_dim == 128;
 }
 
+struct ItemPlan {
+    const int32_t* items;
+    const uint16_t* isum;
+    const int32_t* order;
+    int64_t n_items;
+};
+
 static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, int64_t q_start,
-                         const uint32_t* bits, const uint8_t* summary, int64_t B,
+                         const uint32_t* bits, const uint8_t* summary, const int32_t* order, const ItemPlan* plan,
+                         int64_t B,
                          int64_t L, int n_heads, int n_kv_heads, int head_dim,
                          int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
                          int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
                          int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
                          float scale, int variant, void* stream) {
-    VGPT_REQUIRE(q && k && v && o && bits && summary, VGPT_ERR_INVALID,
+    VGPT_REQUIRE(q && k && v && o && bits && (summary || plan), VGPT_ERR_INVALID,
                  "vgpt_attn_blockmask_fwd: null pointer");
     VGPT_REQUIRE(B >= 0 && L >= 0 && n_heads > 0 && n_kv_heads > 0, VGPT_ERR_INVALID,
                  "vgpt_attn_blockmask_fwd: bad shape");
@@ -441,14 +516,21 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
     VGPT_REQUIRE(q_start >= 0 && q_start % 128 == 0 && q_start <= L, VGPT_ERR_INVALID,
                  "vgpt_attn_blockmask_fwd: q_start must be a multiple of 128 in [0, L]");
     if (B == 0 || L == 0 || q_start >= L) return VGPT_OK;
+    if (plan && plan->n_items == 0) return VGPT_OK;
     AttnArgs a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o;
-    a.bits = bits; a.summary = summary; a.lse = lse;
+    a.bits = bits; a.summary = summary; a.order = order; a.lse = lse;
     a.B = (int)B; a.L = (int)L; a.n_heads = n_heads; a.kv_group = n_heads / n_kv_heads;
     a.W = (int)cdiv(L, 32); a.nqb = (int)cdiv(L, 128); a.nkt = (int)cdiv(L, 64); a.qb0 = (int)(q_start / 128);
     a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
     a.v_sb = v_sb; a.v_sh = v_sh; a.v_ss = v_ss; a.o_sb = o_sb; a.o_sh = o_sh; a.o_ss = o_ss;
     a.scale_log2e = scale * 1.4426950408889634f;
+    a.items = plan ? plan->items : nullptr;
+    a.isum = plan ? plan->isum : nullptr;
+    a.iorder = plan ? plan->order : nullptr;
+    a.n_items = plan ? (int)plan->n_items : 0;
+    const int64_t n_wg = plan ? plan->n_items * n_heads : (int64_t)(a.nqb - a.qb0) * n_heads * B;
+    a.trace = n_wg <= g_trace_cap ? g_trace : nullptr;
     hipStream_t s = (hipStream_t)stream;
 #define ATTN_CASE(DD)                                   \
     case DD:                                            \
@@ -467,12 +549,12 @@ VGPT_EXPORT int vgpt_attn_blockmask_fwd(const void* q, const void* k, const void
                                         int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
                                         int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
                                         float scale, int variant, void* stream) {
-    return attn_fwd_impl(q, k, v, o, nullptr, 0, bits, summary, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
+    return attn_fwd_impl(q, k, v, o, nullptr, 0, bits, summary, nullptr, nullptr, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
                          k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, scale, variant, stream);
 }
 
 VGPT_EXPORT int vgpt_attn_blockmask_fwd_lse(const void* q, const void* k, const void* v, void* o, float* lse,
-                                            const uint32_t* bits, const uint8_t* summary, int64_t B,
+                                            const uint32_t* bits, const uint8_t* summary, const int32_t* order, int64_t B,
                                             int64_t L, int n_heads, int n_kv_heads, int head_dim,
                                             int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
                                             int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
@@ -482,17 +564,28 @@ VGPT_EXPORT int vgpt_attn_blockmask_fwd_lse(const void* q, const void* k, const 
         vgpt_set_error("vgpt_attn_blockmask_fwd_lse: null lse");
         return VGPT_ERR_INVALID;
     }
-    return attn_fwd_impl(q, k, v, o, lse, 0, bits, summary, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
+    return attn_fwd_impl(q, k, v, o, lse, 0, bits, summary, order, nullptr, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
                          k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, scale, 0, stream);
 }
 
 VGPT_EXPORT int vgpt_attn_blockmask_fwd_qrange(const void* q, const void* k, const void* v, void* o, int64_t q_start,
-                                               const uint32_t* bits, const uint8_t* summary, int64_t B,
+                                               const uint32_t* bits, const uint8_t* summary, const int32_t* order,
+                                               int64_t B,
                                                int64_t L, int n_heads, int n_kv_heads, int head_dim,
                                                int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
                                                int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
                                                int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
                                                float scale, void* stream) {
-    return attn_fwd_impl(q, k, v, o, nullptr, q_start, bits, summary, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh,
+    return attn_fwd_impl(q, k, v, o, nullptr, q_start, bits, summary, order, nullptr, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh,
                          q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, scale, 0, stream);
+}
+
+// 128-row items of a plan on the 4-wave kernel (called by vgpt_attn_fwd_plan, attn_fwd_pp.hip)
+int vgpt_attn_fwd_items128(const void* q, const void* k, const void* v, void* o, float* lse, const uint32_t* bits,
+                           const int32_t* items, const uint16_t* item_summary, const int32_t* order, int64_t n_items,
+                           int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim, const int64_t* st, float scale,
+                           void* stream) {
+    const ItemPlan plan = {items, item_summary, order, n_items};
+    return attn_fwd_impl(q, k, v, o, lse, 0, bits, nullptr, nullptr, &plan, B, L, n_heads, n_kv_heads, head_dim, st[0], st[1],
+                         st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], scale, 0, stream);
 }

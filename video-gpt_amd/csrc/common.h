@@ -50,6 +50,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Combine a value with the one held by the lane 32 away (the two halves of a wave) without an LDS round trip:
+// v_permlane32_swap hands every lane both halves' values.
+__device__ __forceinline__ float half_max(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
     switch (act) {
         case VGPT_ACT_SILU: return x / (1.0f + __expf(-x));

@@ -79,6 +79,34 @@ __global__ void mask_empty_rows_kernel(const uint32_t* __restrict__ bits, int32_
     if (!any) atomicAdd(count, 1);
 }
 
+// Longest-first launch order of the 128-row q blocks of one batch item: cost = key tiles with any visible key
+// (what a workgroup of the attention kernel iterates over).  Rank sort, stable; more than ORDER_MAX q blocks
+// keep their natural order.
+constexpr int ORDER_MAX = 2048;
+__global__ void qblock_order_kernel(const uint8_t* __restrict__ summary, int nqb, int nkt, int qb0,
+                                    int32_t* __restrict__ order) {
+    __shared__ int cnt[ORDER_MAX];
+    const int b = blockIdx.x, n = nqb - qb0;
+    int32_t* out = order + (int64_t)b * n;
+    if (n > ORDER_MAX) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = qb0 + i;
+        return;
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint8_t* row = summary + ((int64_t)b * nqb + qb0 + i) * nkt;
+        int c = 0;
+        for (int t = 0; t < nkt; ++t) c += row[t] != 0;
+        cnt[i] = c;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int ci = cnt[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (cnt[j] > ci) || (cnt[j] == ci && j < i);
+        out[rank] = qb0 + i;
+    }
+}
+
 }  // namespace
 
 VGPT_EXPORT int vgpt_mask_pack_bool(const uint8_t* mask, uint32_t* bits, int64_t B, int64_t L,
@@ -125,6 +153,19 @@ VGPT_EXPORT int vgpt_mask_tile_summary(const uint32_t* bits, uint8_t* summary, i
     hipLaunchKernelGGL(mask_summary_kernel, dim3(nkt, nqb, (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream, bits, summary, (int)L, (int)cdiv(L, 32), nqb, nkt);
     VGPT_CHECK_LAUNCH("vgpt_mask_tile_summary");
+    return VGPT_OK;
+}
+
+VGPT_EXPORT int vgpt_attn_qblock_order(const uint8_t* summary, int64_t B, int64_t L, int64_t q_start, int32_t* order,
+                                       void* stream) {
+    VGPT_REQUIRE(summary && order, VGPT_ERR_INVALID, "vgpt_attn_qblock_order: null pointer");
+    VGPT_REQUIRE(B >= 0 && L >= 0 && L < (1 << 24) && q_start >= 0 && q_start % 128 == 0 && q_start <= L,
+                 VGPT_ERR_INVALID, "vgpt_attn_qblock_order: bad shape");
+    const int nqb = (int)cdiv(L, 128), nkt = (int)cdiv(L, 64), qb0 = (int)(q_start / 128);
+    if (B == 0 || nqb == qb0) return VGPT_OK;
+    hipLaunchKernelGGL(qblock_order_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, summary, nqb, nkt, qb0,
+                       order);
+    VGPT_CHECK_LAUNCH("vgpt_attn_qblock_order");
     return VGPT_OK;
 }
 

@@ -75,10 +75,12 @@ class StaticDenoiser:
         B, L = input_ids.shape
         row_of = lambda b, s: b * L + s
         self.packed = False
+        seq_bounds = None   # packed layout: row range of every original batch row, for the attention plan
         pads = count_left_pads(attention_mask) if pack_padding and not isinstance(attention_mask, ops.PackedMask) else []
         if any(pads):
             input_ids, position_ids, attention_mask, offs = pack_left_padded(input_ids, position_ids, attention_mask, pads)
             row_of = lambda b, s: offs[b] + s - pads[b]
+            seq_bounds = [(offs[b], offs[b] + (L - pads[b])) for b in range(B)]
             B, L = input_ids.shape
             self.packed = True
         # ---- condition-prefix reuse: rows before the first <|diffusion|> token never see a
@@ -108,8 +110,20 @@ class StaticDenoiser:
                 row_of = lambda b, s, prev=prev, S0=S0, npad=npad: (lambda r: r if r < S0 else r + npad)(prev(b, s))
                 L = L2
                 self.S = S
+                if seq_bounds is not None:
+                    sh = lambda r_: r_ if r_ < S0 else r_ + npad
+                    seq_bounds = [(sh(a_), sh(e_ - 1) + 1) for a_, e_ in seq_bounds]
         H, I = cfg.hidden_size, cfg.intermediate_size
         self.B, self.L, self.H = B, L, H
+        # query-row segments of the attention plan: cut where two packed sequences meet (their key sets differ) so
+        # that no work item of the kernel straddles them; `seg_live` covers the rows computed at every step
+        self.seg_all = self.seg_live = None
+        if seq_bounds is not None and B == 1:
+            cuts = sorted({0, L, *[a_ for a_, _ in seq_bounds]})
+            self.seg_all = tuple((0, a_, e_) for a_, e_ in zip(cuts[:-1], cuts[1:]) if e_ > a_)
+            if self.S:
+                cl = sorted({self.S, L, *[a_ for a_, _ in seq_bounds if a_ > self.S]})
+                self.seg_live = tuple((0, a_, e_) for a_, e_ in zip(cl[:-1], cl[1:]) if e_ > a_)
         self.nf = n_frames
         self.h, self.w = latent_hw
         C = model.in_channels
@@ -197,7 +211,7 @@ class StaticDenoiser:
             ops.rmsnorm(hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=nrm)
             ops.linear(nrm, at.qkv_proj.weight, out=qkv)
             ops.rope_qk_inplace(qkv, self.rope[0], self.rope[1], nq, nk, hd)
-            ops.attention_qkv(qkv, self.pm, nq, nk, hd, out=ctx)
+            ops.attention_qkv_range(qkv, self.pm, nq, nk, hd, 0, ctx, segments=self.seg_all)
             ops.linear(ctx, at.o_proj.weight, residual=hid, out=hid)
             ops.rmsnorm(hid, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon, out=nrm)
             ops.gated_mlp_act(nrm, mlp.gate_up_proj.weight, mlp.act, out=act)
@@ -241,11 +255,14 @@ class StaticDenoiser:
                 live = full[S:]                                  # this step's q/k/v rows, behind the cached prefix
                 ops.linear(self.nrm, at.qkv_proj.weight, out=live)
                 ops.rope_qk_inplace(live, rope[0], rope[1], nq, nk, hd)
-                ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, S, self.ctx)
+                ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, S, self.ctx, segments=self.seg_live)
             else:
                 ops.linear(self.nrm, at.qkv_proj.weight, out=self.qkv)
                 ops.rope_qk_inplace(self.qkv, rope[0], rope[1], nq, nk, hd)
-                ops.attention_qkv(self.qkv, self.pm, nq, nk, hd, out=self.ctx)
+                if self.seg_all is not None:
+                    ops.attention_qkv_range(self.qkv, self.pm, nq, nk, hd, 0, self.ctx, segments=self.seg_all)
+                else:
+                    ops.attention_qkv(self.qkv, self.pm, nq, nk, hd, out=self.ctx)
             ops.linear(self.ctx, at.o_proj.weight, residual=self.hid, out=self.hid)
             ops.rmsnorm(self.hid, layer.post_attention_layernorm.weight,
                         layer.post_attention_layernorm.variance_epsilon, out=self.nrm)

@@ -142,11 +142,54 @@ def gated_mlp_act(x: torch.Tensor, w_gate_up: torch.Tensor, act: int = ACT_SILU,
 
 # ---- attention --------------------------------------------------------------------------------
 
+class AttnPlan:
+    def __init__(self, items, summary, order, n_items, item_rows):
+        self.items, self.summary, self.order, self.n_items, self.item_rows = items, summary, order, n_items, item_rows
+
+
 class PackedMask:
     """Bit-packed (B,L,L) visibility mask + tile summary consumed by the attention kernel."""
 
     def __init__(self, bits: torch.Tensor, summary: torch.Tensor, B: int, L: int):
         self.bits, self.summary, self.B, self.L = bits, summary, B, L
+        self._order = {}
+        self._plans = {}
+
+    def plan(self, segments=None, item_rows: int = 128) -> "AttnPlan":
+        """Work plan of the head_dim-96 forward kernel (include/vgpt.h, vgpt_attn_plan_build) for the query rows of
+        `segments` = ((batch, row_begin, row_end), ...); default: every row, one segment per batch item.  Each
+        segment is cut into items of item_rows (128: 4-wave kernel, 256: 8-wave head_dim-96 kernel) rows; cut
+        segments where packed sequences meet."""
+        skey = tuple(tuple(int(v) for v in s_) for s_ in segments) if segments is not None else None
+        key = (skey, item_rows)
+        p = self._plans.get(key)
+        if p is None:
+            segs = skey if skey is not None else tuple((b, 0, self.L) for b in range(self.B))
+            items = []
+            for b, r0, r1 in segs:
+                if not (0 <= b < self.B and 0 <= r0 <= r1 <= self.L):
+                    raise VgptError(f"attention plan: bad segment {(b, r0, r1)}")
+                items += [(b, r, min(item_rows, r1 - r), 0) for r in range(r0, r1, item_rows)]
+            n = len(items)
+            dev = self.bits.device
+            it = torch.tensor(items, dtype=torch.int32).reshape(n, 4).to(dev)
+            summ = torch.empty(max(n, 1), (self.L + 63) // 64, dtype=torch.int16, device=dev)
+            order = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            if n:
+                call("vgpt_attn_plan_build", self.bits.data_ptr(), self.B, self.L, it.data_ptr(), n, item_rows,
+                     summ.data_ptr(), order.data_ptr(), _stream())
+            p = self._plans[key] = AttnPlan(it, summ, order, n, item_rows)
+        return p
+
+    def order(self, q_start: int = 0) -> torch.Tensor:
+        """Longest-first launch order of the q blocks from row q_start on (include/vgpt.h, vgpt_attn_qblock_order)."""
+        t = self._order.get(q_start)
+        if t is None:
+            n = (self.L + 127) // 128 - q_start // 128
+            t = torch.empty(self.B, max(n, 0), dtype=torch.int32, device=self.bits.device)
+            call("vgpt_attn_qblock_order", self.summary.data_ptr(), self.B, self.L, q_start, t.data_ptr(), _stream())
+            self._order[q_start] = t
+        return t
 
     def count_empty_rows(self) -> int:
         cnt = torch.empty(1, dtype=torch.int32, device=self.bits.device)
@@ -208,6 +251,17 @@ def attention_qkv(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: i
     kq = qkv.data_ptr() + n_heads * head_dim * es
     vq = kq + n_kv_heads * head_dim * es
     sb, ss = L * width, width
+    if variant in (0, 3):   # planned launch: 0 = 4-wave kernel on 128-row items, 3 = 8-wave kernel on 256-row items
+        _attn_plan_call(qkv.data_ptr(), kq, vq, out.data_ptr(), None, pm, pm.plan(None, 256 if variant == 3 else 128), B, L,
+                        n_heads, n_kv_heads, head_dim,
+                        (sb, head_dim, ss) * 3 + (L * n_heads * head_dim, head_dim, n_heads * head_dim), scale)
+        return out
+    if variant == 2:   # 4-wave kernel on aligned 128-row q blocks, launched longest-first
+        call("vgpt_attn_blockmask_fwd_qrange", qkv.data_ptr(), kq, vq, out.data_ptr(), 0, pm.bits.data_ptr(),
+             pm.summary.data_ptr(), pm.order(0).data_ptr(), B, L, n_heads, n_kv_heads, head_dim,
+             sb, head_dim, ss, sb, head_dim, ss, sb, head_dim, ss,
+             L * n_heads * head_dim, head_dim, n_heads * head_dim, float(scale), _stream())
+        return out
     call("vgpt_attn_blockmask_fwd", qkv.data_ptr(), kq, vq, out.data_ptr(), pm.bits.data_ptr(),
          pm.summary.data_ptr(), B, L, n_heads, n_kv_heads, head_dim,
          sb, head_dim, ss, sb, head_dim, ss, sb, head_dim, ss,
@@ -215,10 +269,19 @@ def attention_qkv(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: i
     return out
 
 
+def _attn_plan_call(q, k, v, o, lse, pm, plan, B, L, n_heads, n_kv_heads, head_dim, strides, scale):
+    if plan.n_items:
+        call("vgpt_attn_fwd_plan", q, k, v, o, lse, pm.bits.data_ptr(), plan.items.data_ptr(), plan.summary.data_ptr(),
+             plan.order.data_ptr(), plan.n_items, plan.item_rows, B, L, n_heads, n_kv_heads, head_dim, *strides, float(scale),
+             _stream())
+
+
 def attention_qkv_range(qkv_full: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: int, head_dim: int,
-                        q_start: int, out_active: torch.Tensor, scale: Optional[float] = None):
+                        q_start: int, out_active: torch.Tensor, scale: Optional[float] = None, segments=None,
+                        item_rows: int = 128):
     """Attention of query rows [q_start, L) against all L rows of the fused (1, L, 3H-like) buffer; `out_active`
-    holds the L - q_start computed rows (condition-prefix reuse, see include/vgpt.h)."""
+    holds the L - q_start computed rows (condition-prefix reuse, see include/vgpt.h).  segments: optional
+    ((0, row_begin, row_end), ...) covering [q_start, L), cut where packed sequences meet."""
     _chk(qkv_full, BF16, "attention.qkv"); _chk(out_active, BF16, "attention.out")
     B, L, width = qkv_full.shape
     if B != 1 or pm.B != 1 or pm.L != L:
@@ -229,9 +292,9 @@ def attention_qkv_range(qkv_full: torch.Tensor, pm: PackedMask, n_heads: int, n_
     kq = qkv_full.data_ptr() + hq * 2
     vq = kq + n_kv_heads * head_dim * 2
     o_base = out_active.data_ptr() - q_start * hq * 2   # absolute-row addressing of the active output buffer
-    call("vgpt_attn_blockmask_fwd_qrange", qkv_full.data_ptr(), kq, vq, o_base, q_start, pm.bits.data_ptr(),
-         pm.summary.data_ptr(), 1, L, n_heads, n_kv_heads, head_dim, L * width, head_dim, width, L * width, head_dim,
-         width, L * width, head_dim, width, L * hq, head_dim, hq, float(scale), _stream())
+    plan = pm.plan(segments if segments is not None else ((0, q_start, L),), item_rows)
+    _attn_plan_call(qkv_full.data_ptr(), kq, vq, o_base, None, pm, plan, 1, L, n_heads, n_kv_heads, head_dim,
+                    (L * width, head_dim, width) * 3 + (L * hq, head_dim, hq), scale)
     return out_active
 
 
@@ -255,11 +318,18 @@ def sdpa(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attn_mask=
     out = torch.empty(B, Hq, S, d, dtype=BF16, device=query.device)
     if scale is None:
         scale = 1.0 / math.sqrt(d)
+    if variant in (0, 3):
+        _attn_plan_call(query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(), None, pm,
+                        pm.plan(None, 256 if variant == 3 else 128), B, S, Hq, Hkv,
+                        d, (query.stride(0), query.stride(1), query.stride(2), key.stride(0), key.stride(1), key.stride(2),
+                            value.stride(0), value.stride(1), value.stride(2), out.stride(0), out.stride(1), out.stride(2)),
+                        scale)
+        return out
     call("vgpt_attn_blockmask_fwd", query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),
          pm.bits.data_ptr(), pm.summary.data_ptr(), B, S, Hq, Hkv, d,
          query.stride(0), query.stride(1), query.stride(2), key.stride(0), key.stride(1), key.stride(2),
          value.stride(0), value.stride(1), value.stride(2), out.stride(0), out.stride(1), out.stride(2),
-         float(scale), variant, _stream())
+         float(scale), 0 if variant == 2 else variant, _stream())
     return out
 
 

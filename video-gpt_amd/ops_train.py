@@ -30,9 +30,10 @@ def attention_qkv_train(qkv, pm, n_heads, n_kv_heads, head_dim, out, lse, scale=
     vq = kq + n_kv_heads * head_dim * es
     sb, ss = L * width, width
     scale = 1.0 / math.sqrt(head_dim) if scale is None else scale
-    call("vgpt_attn_blockmask_fwd_lse", qkv.data_ptr(), kq, vq, out.data_ptr(), lse.data_ptr(), pm.bits.data_ptr(),
-         pm.summary.data_ptr(), B, L, n_heads, n_kv_heads, head_dim, sb, head_dim, ss, sb, head_dim, ss, sb, head_dim, ss,
-         L * n_heads * head_dim, head_dim, n_heads * head_dim, float(scale), _stream())
+    strides = (sb, head_dim, ss) * 3 + (L * n_heads * head_dim, head_dim, n_heads * head_dim)
+    from .ops import _attn_plan_call
+    _attn_plan_call(qkv.data_ptr(), kq, vq, out.data_ptr(), lse.data_ptr(), pm, pm.plan(), B, L, n_heads, n_kv_heads,
+                    head_dim, strides, scale)
     return out
 
 
