@@ -76,6 +76,16 @@ int vgpt_rope_qk_inplace(void* qkv, const float* cos_t, const float* sin_t, int6
 int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void* extra, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int epilogue,
                    void* stream);
+/* The same product with operands stored transposed, for the backward of the Linear layers without materialising a
+ * transpose (the reference gets these from torch.autograd: dX = dY W, dW = dY^T X):
+ *   w_transposed: W is stored (K, N) row-major (ldw = its row stride)   -> dX[M,N'] = dY[M,K'] W[K',N']
+ *   a_transposed: A is stored (K, M) row-major; needs w_transposed      -> dW[N,K'] = dY^T X with A = dY, W = X
+ * Widths of transposed operands must be multiples of 8; K % 64 == 0 unless BOTH operands are transposed (then the
+ * rows of a partial last k-tile are zero-filled by the hardware's buffer range check).  A transposed operand must
+ * stay below 2 GiB.  With both flags 0 this is vgpt_gemm_bf16. */
+int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const void* extra, int64_t M, int64_t N, int64_t K,
+                      int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int epilogue, int a_transposed,
+                      int w_transposed, void* stream);
 
 /* Phi3MLP first half, fused: out[M,I] = act(A Wg^T) * (A Wu^T) where
  * W_gate_up (2I, K) = [Wg ; Wu] as stored by Phi3MLP.gate_up_proj.

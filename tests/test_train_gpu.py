@@ -46,6 +46,30 @@ def test_transpose_and_backward_gemms(ops, T):
     assert rel_l2(dw, dy.double().t() @ x.double()) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 576, 192), (515, 256, 128), (7, 320, 64), (1100, 3072, 320), (64, 64, 8)])
+def test_transposed_operand_gemms(ops, T, M, N, K):
+    """dX = dY W (weight read transposed) and dW = dY^T X (both operands transposed, reduction over the M rows with
+    a zero-filled partial last tile) against fp64 matmuls of the same bf16 values."""
+    dy = bf(torch.randn(M, N, generator=g(11)))
+    x = bf(torch.randn(M, K, generator=g(12)))
+    w = bf(torch.randn(N, K, generator=g(13)) * 0.05)
+    res = bf(torch.randn(M, K, generator=g(14)))
+    d = lambda t: t.to(DEV, BF)
+    dx = T.linear_dx(d(dy), d(w))
+    assert rel_l2(dx, dy.double() @ w.double()) < 4e-3
+    dx2 = T.linear_dx(d(dy), d(w), dres=d(res))
+    assert rel_l2(dx2, dy.double() @ w.double() + res.double()) < 4e-3
+    dw = torch.full((N, K), 3.0, dtype=BF, device=DEV)
+    T.linear_dw(d(dy), d(x), out=dw)
+    assert rel_l2(dw, dy.double().t() @ x.double()) < 4e-3
+    # strided views (a column slice of a wider buffer) go through the row strides
+    wide = torch.zeros(M, N + 64, dtype=BF, device=DEV)
+    wide[:, 32:32 + N] = d(dy)
+    if N % 8 == 0:
+        dw2 = T.linear_dw(wide[:, 32:32 + N], d(x))
+        assert torch.equal(dw2, dw)
+
+
 def test_elementwise_backward(ops, T):
     M, I, H = 37, 64, 192
     gu = bf(torch.randn(M, 2 * I, generator=g(5))).requires_grad_()

@@ -67,6 +67,38 @@ __device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
                                      0);
 }
 
+// LDS-DMA issued from inline asm (kernels with transposed operands): hipcc cannot tell that a ds_read_b64_tr_b16
+// does not alias an LDS-DMA in flight and would drain vmcnt(0) before every such read; hidden from it, completion is
+// tracked by the kernel's own s_waitcnt vmcnt(0) in front of its barrier.
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void glds16_asm(const char* base, uint32_t voffset, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffset), "s"(base), "s"(lds_dst)
+        : "memory");
+}
+// 16 bytes per lane through a buffer descriptor covering [base, base + num_bytes): lanes whose offset falls outside
+// read zeros (the zero fill of a partial reduction tile)
+__device__ __forceinline__ v4i32 make_rsrc(const void* base, int num_bytes) {
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    v4i32 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32) & 0xffff);
+    r[2] = __builtin_amdgcn_readfirstlane(num_bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void buf_glds16_asm(v4i32 rsrc, uint32_t voffset, int soffset, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffset), "s"(rsrc), "s"(soffset), "s"(lds_dst)
+        : "memory");
+}
+
 // weight row feeding n-slot s of a tile (gated mode interleaves gate/up every 16 slots)
 template <int MODE>
 __device__ __forceinline__ int w_row_of_slot(int n0, int s, int I) {
@@ -79,8 +111,14 @@ __device__ __forceinline__ int w_row_of_slot(int n0, int s, int I) {
 
 constexpr bool getenv_prio = VGPT_GEMM_SETPRIO;
 
-template <int MODE, typename C, bool PIPE>
+// ATR / WTR: the operand is stored with the reduction index as its ROW index (A as [K][M], W as [K][N]) -- the dX and
+// dW products of the backward (dX = dY W, dW = dY^T X) without materialising a transpose.  Such a tile is staged in
+// its natural [64 reduction rows][256 columns] layout and its MFMA fragments come from ds_read_b64_tr_b16; the
+// 32-byte units of a row are XOR-swizzled with ((row>>3)&1)<<2 | (row&3) (on the DMA source address and on the
+// read) so that the 8 rows x 32 B a half-wave reads transposed hit 64 different banks.
+template <int MODE, typename C, bool PIPE, bool ATR = false, bool WTR = false>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
+    static_assert(!(ATR || WTR) || MODE == MODE_PLAIN, "transposed operands: plain kernel only");
     constexpr int BM = C::BM, BN = C::BN, MI = C::MI, NI = C::NI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -107,33 +145,77 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     // ---- staging addresses: wave w stages its share of 8-row slabs of both tiles ----
     const int srow = lane >> 3;            // row inside the 8-row slab
     const int schunk = (lane & 7) ^ srow;  // source 16-B chunk (XOR swizzle)
-    const bf16* a_src[C::A_SLABS];
-    const bf16* w_src[C::W_SLABS];
+    // per-lane BYTE offsets of the pieces this wave stages, relative to the (wave-uniform) tile origin: one
+    // 32-bit register per piece instead of a 64-bit pointer, and the k-tile advance stays in scalar registers
+    uint32_t a_off[C::A_SLABS], w_off[C::W_SLABS];
     const int n_rows_w = (MODE == MODE_GATED) ? 2 * g.I : g.N;
+    // transposed operand (tile = 64 reduction rows x BM or BN columns): a 1-KiB piece covers 2 (256 columns) or 4
+    // (128 columns) consecutive rows; lane -> (row, 16-B chunk)
+    auto tr_off = [&](int64_t ld, int piece, int col0, int width, int cols) {
+        const int cpr = cols / 8;  // 16-B chunks per row
+        const int row = piece * (64 / cpr) + lane / cpr, t_c = lane % cpr;
+        const int key = (((row >> 3) & 1) << 2) | (row & 3);
+        const int lchunk = ((((t_c >> 1) ^ key) << 1) | (t_c & 1));
+        const int col = min(col0 + lchunk * 8, width - 8) - col0;
+        return (uint32_t)(row * (int)ld + col) * 2u;
+    };
+    const char* a_org = reinterpret_cast<const char*>(ATR ? g.A + m0 : g.A + (int64_t)m0 * g.lda);
+    const char* w_org;
+    if constexpr (WTR) w_org = reinterpret_cast<const char*>(g.W + n0);
+    else if constexpr (MODE == MODE_GATED) w_org = reinterpret_cast<const char*>(g.W);
+    else w_org = reinterpret_cast<const char*>(g.W + (int64_t)n0 * g.ldw);
 #pragma unroll
     for (int i = 0; i < C::A_SLABS; ++i) {
-        const int r = (wave * C::A_SLABS + i) * 8 + srow;
-        const int am = min(m0 + r, g.M - 1);
-        a_src[i] = g.A + (int64_t)am * g.lda + schunk * 8;
+        if constexpr (ATR) {
+            a_off[i] = tr_off(g.lda, wave * C::A_SLABS + i, m0, g.M, BM);
+        } else {
+            const int r = min((wave * C::A_SLABS + i) * 8 + srow, g.M - 1 - m0);
+            a_off[i] = (uint32_t)(r * (int)g.lda + schunk * 8) * 2u;
+        }
     }
 #pragma unroll
     for (int i = 0; i < C::W_SLABS; ++i) {
-        const int r = (wave * C::W_SLABS + i) * 8 + srow;
-        const int wr = min(w_row_of_slot<MODE>(n0, r, g.I), n_rows_w - 1);
-        w_src[i] = g.W + (int64_t)wr * g.ldw + schunk * 8;
+        if constexpr (WTR) {
+            w_off[i] = tr_off(g.ldw, wave * C::W_SLABS + i, n0, g.N, BN);
+        } else {
+            const int r = (wave * C::W_SLABS + i) * 8 + srow;
+            const int wr = min(w_row_of_slot<MODE>(n0, r, g.I), n_rows_w - 1) - (MODE == MODE_GATED ? 0 : n0);
+            w_off[i] = (uint32_t)(wr * (int)g.ldw + schunk * 8) * 2u;
+        }
     }
+    const int64_t a_step = (ATR ? (int64_t)BK * g.lda : BK) * 2, w_step = (WTR ? (int64_t)BK * g.ldw : BK) * 2;
+    // A transposed operand is fetched with buffer_load ... lds through a descriptor that ends after reduction row
+    // K-1: the rows of a partial last k-tile are out of range and the hardware returns zeros for them.
+    const uint32_t lds_base =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    v4i32 a_rs = {0, 0, 0, 0}, w_rs = {0, 0, 0, 0};
+    if constexpr (ATR) a_rs = make_rsrc(a_org, (int)(((int64_t)g.K * g.lda - m0) * 2));
+    if constexpr (WTR) w_rs = make_rsrc(w_org, (int)(((int64_t)g.K * g.ldw - n0) * 2));
+    auto a_issue = [&](int i, int kt, char* dst) {
+        if constexpr (ATR)
+            buf_glds16_asm(a_rs, a_off[i], (int)(kt * a_step), lds_base + (uint32_t)(dst - smem));
+        else if constexpr (WTR)
+            glds16_asm(a_org + kt * a_step, a_off[i], lds_base + (uint32_t)(dst - smem));
+        else
+            glds16(reinterpret_cast<const bf16*>(a_org + kt * a_step + a_off[i]), dst);
+    };
+    auto w_issue = [&](int i, int kt, char* dst) {
+        if constexpr (WTR)
+            buf_glds16_asm(w_rs, w_off[i], (int)(kt * w_step), lds_base + (uint32_t)(dst - smem));
+        else
+            glds16(reinterpret_cast<const bf16*>(w_org + kt * w_step + w_off[i]), dst);
+    };
     char* sA = smem;                    // [2][A_BYTES]
     char* sW = smem + 2 * C::A_BYTES;   // [2][W_BYTES]
 
     auto stage = [&](int buf, int kt) {
         if (g.debug & 1) return;
-        const int koff = kt * BK;
 #pragma unroll
         for (int i = 0; i < C::A_SLABS; ++i)
-            glds16(a_src[i] + koff, sA + buf * C::A_BYTES + (wave * C::A_SLABS + i) * 1024);
+            a_issue(i, kt, sA + buf * C::A_BYTES + (wave * C::A_SLABS + i) * 1024);
 #pragma unroll
         for (int i = 0; i < C::W_SLABS; ++i)
-            glds16(w_src[i] + koff, sW + buf * C::W_BYTES + (wave * C::W_SLABS + i) * 1024);
+            w_issue(i, kt, sW + buf * C::W_BYTES + (wave * C::W_SLABS + i) * 1024);
     };
 
     // ---- fragment read addresses ----
@@ -151,7 +233,18 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K / BK;
+    // transposed image: lane (g4 = lane>>4, li = lane&15) of the 16-column sub-tile `unit` reads rows
+    // 32 ks + 8 g4 + (li>>2) (+4 for the upper half) at columns 4 (li&3) .. +4 -> k = 8 g4 + j of column li
+    const int tr_li = lane & 15, tr_g = lane >> 4;
+    const int tr_key = ((tr_g & 1) << 2) | (tr_li >> 2);
+    auto ld_tr = [&](const char* tile, int rowb, int ks, int unit) {
+        const char* p = tile + (ks * 32 + 8 * tr_g + (tr_li >> 2)) * rowb + 8 * (tr_li & 3) + ((unit ^ tr_key) << 5);
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 4 * rowb));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    const int nk = (g.K + BK - 1) / BK;  // a partial last k-tile exists only with transposed operands (zero rows)
     if constexpr (!PIPE) {
         // one barrier per k-tile: wait for tile kt, issue tile kt+1's DMA, compute tile kt
         stage(0, 0);
@@ -167,9 +260,15 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                 const int coff = ((ks * 4 + fk) ^ sw) * 16;
                 bf16x8 wf[NI], af[MI];
 #pragma unroll
-                for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(bW + i * 2048 + coff);
+                for (int i = 0; i < NI; ++i) {
+                    if constexpr (WTR) wf[i] = ld_tr(sW + buf * C::W_BYTES, 2 * BN, ks, wn * NI + i);
+                    else wf[i] = *reinterpret_cast<const bf16x8*>(bW + i * 2048 + coff);
+                }
 #pragma unroll
-                for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const bf16x8*>(bA + j * 2048 + coff);
+                for (int j = 0; j < MI; ++j) {
+                    if constexpr (ATR) af[j] = ld_tr(sA + buf * C::A_BYTES, 2 * BM, ks, wm * MI + j);
+                    else af[j] = *reinterpret_cast<const bf16x8*>(bA + j * 2048 + coff);
+                }
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -196,15 +295,25 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         }
         auto ldW = [&](bf16x8(&dst)[4], int buf, int ks) {
             if (g.debug & 2) return;
-            const char* b = sW + buf * C::W_BYTES + w_base + ((ks * 4 + fk) ^ sw) * 16;
+            if constexpr (WTR) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(b + i * 2048);
+                for (int i = 0; i < 4; ++i) dst[i] = ld_tr(sW + buf * C::W_BYTES, 2 * BN, ks, wn * 4 + i);
+            } else {
+                const char* b = sW + buf * C::W_BYTES + w_base + ((ks * 4 + fk) ^ sw) * 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(b + i * 2048);
+            }
         };
         auto ldA = [&](bf16x8(&dst)[4], int buf, int ks, int mh) {
             if (g.debug & 2) return;
-            const char* b = sA + buf * C::A_BYTES + a_base + mh * 8192 + ((ks * 4 + fk) ^ sw) * 16;
+            if constexpr (ATR) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(b + j * 2048);
+                for (int j = 0; j < 4; ++j) dst[j] = ld_tr(sA + buf * C::A_BYTES, 2 * BM, ks, wm * 8 + mh * 4 + j);
+            } else {
+                const char* b = sA + buf * C::A_BYTES + a_base + mh * 8192 + ((ks * 4 + fk) ^ sw) * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(b + j * 2048);
+            }
         };
         auto mma = [&](const bf16x8(&wf)[4], const bf16x8(&af)[4], auto mh) {
             constexpr int MH = decltype(mh)::value;
@@ -219,16 +328,15 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         };
         auto stage_half = [&](int buf, int kt, int half) {
             if (g.debug & 1) return;
-            const int koff = kt * BK;
 #pragma unroll
             for (int i = 0; i < C::A_SLABS / 2; ++i) {
                 const int ii = half * (C::A_SLABS / 2) + i;
-                glds16(a_src[ii] + koff, sA + buf * C::A_BYTES + (wave * C::A_SLABS + ii) * 1024);
+                a_issue(ii, kt, sA + buf * C::A_BYTES + (wave * C::A_SLABS + ii) * 1024);
             }
 #pragma unroll
             for (int i = 0; i < C::W_SLABS / 2; ++i) {
                 const int ii = half * (C::W_SLABS / 2) + i;
-                glds16(w_src[ii] + koff, sW + buf * C::W_BYTES + (wave * C::W_SLABS + ii) * 1024);
+                w_issue(ii, kt, sW + buf * C::W_BYTES + (wave * C::W_SLABS + ii) * 1024);
             }
         };
         using H0 = std::integral_constant<int, 0>;
@@ -316,11 +424,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
-template <int MODE, typename C, bool PIPE>
+template <int MODE, typename C, bool PIPE, bool ATR = false, bool WTR = false>
 int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE, C, PIPE>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) {
             vgpt_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
@@ -335,7 +443,7 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
         if (dbg < 0) { const char* e = getenv("VGPT_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
         g.debug = dbg;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C, PIPE>), dim3(g.tiles_m * g.tiles_n), dim3(C::THREADS),
+    hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>), dim3(g.tiles_m * g.tiles_n), dim3(C::THREADS),
                        C::LDS_BYTES, s, g);
     VGPT_CHECK_LAUNCH(name);
     return VGPT_OK;
@@ -352,7 +460,7 @@ int forced_tile() {
     return v;
 }
 
-template <int MODE>
+template <int MODE, bool ATR = false, bool WTR = false>
 int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const int f = forced_tile();
     // the 256-tile pays off once the grid fills the chip (>= ~half of the 256 CUs with 256x256 tiles)
@@ -360,8 +468,8 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const int64_t tiles_m = cdiv(g.M, 256);
     const int64_t big_tiles = tiles_m * tiles_n;
     const bool use256 = f == 256 || f == 257 || (f != 128 && big_tiles >= 128);
-    if (!use256) return launch_cfg<MODE, Cfg128, false>(g, n_out, s, name);
-    if (f == 257) return launch_cfg<MODE, Cfg256, false>(g, n_out, s, name);
+    if (!use256) return launch_cfg<MODE, Cfg128, false, ATR, WTR>(g, n_out, s, name);
+    if (f == 257) return launch_cfg<MODE, Cfg256, false, ATR, WTR>(g, n_out, s, name);
     // Wave quantisation: the 256-tile kernel runs one block per CU, so a grid of T tiles takes ceil(T/256) rounds.
     // When the last round would be badly filled, give the big-tile kernel only the m-tile rows that make full
     // rounds and run the remaining rows with the 128x128 kernel (2 blocks/CU, 4x smaller tiles) behind it.
@@ -374,15 +482,15 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
             const int64_t m1 = rows_big * 256;
             g1.M = (int)m1;
             g2.M = g.M - (int)m1;
-            g2.A = g.A + m1 * g.lda;
+            g2.A = ATR ? g.A + m1 : g.A + m1 * g.lda;  // a transposed A keeps m along its columns
             g2.C = g.C + m1 * g.ldc;
             if (g.epi == VGPT_EPI_RESID) g2.extra = g.extra + m1 * g.ldr;
-            int rc = launch_cfg<MODE, Cfg256, true>(g1, n_out, s, name);
+            int rc = launch_cfg<MODE, Cfg256, true, ATR, WTR>(g1, n_out, s, name);
             if (rc != VGPT_OK) return rc;
-            return launch_cfg<MODE, Cfg128, false>(g2, n_out, s, name);
+            return launch_cfg<MODE, Cfg128, false, ATR, WTR>(g2, n_out, s, name);
         }
     }
-    return launch_cfg<MODE, Cfg256, true>(g, n_out, s, name);
+    return launch_cfg<MODE, Cfg256, true, ATR, WTR>(g, n_out, s, name);
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -415,6 +523,40 @@ VGPT_EXPORT int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void
     g.epi = epilogue; g.act = VGPT_ACT_NONE; g.I = 0;
     g.tiles_m = g.tiles_n = 0;
     return launch<MODE_PLAIN>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16");
+}
+
+VGPT_EXPORT int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const void* extra, int64_t M, int64_t N, int64_t K,
+                                  int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int epilogue, int a_transposed,
+                                  int w_transposed, void* stream) {
+    if (!a_transposed && !w_transposed)
+        return vgpt_gemm_bf16(A, W, C, extra, M, N, K, lda, ldw, ldc, ldr, epilogue, stream);
+    VGPT_REQUIRE(A && W && C, VGPT_ERR_INVALID, "vgpt_gemm_bf16_tr: null pointer");
+    VGPT_REQUIRE(M >= 0 && N > 0 && K > 0, VGPT_ERR_INVALID, "vgpt_gemm_bf16_tr: bad shape");
+    VGPT_REQUIRE(epilogue == VGPT_EPI_NONE || epilogue == VGPT_EPI_RESID || epilogue == VGPT_EPI_BIAS, VGPT_ERR_INVALID,
+                 "vgpt_gemm_bf16_tr: unknown epilogue %d", epilogue);
+    VGPT_REQUIRE(epilogue == VGPT_EPI_NONE || extra, VGPT_ERR_INVALID, "vgpt_gemm_bf16_tr: epilogue needs `extra`");
+    VGPT_REQUIRE(a_transposed || K % BK == 0, VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_tr: K=%ld must be a multiple of 64 unless both operands are transposed", (long)K);
+    VGPT_REQUIRE(!a_transposed || w_transposed, VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_tr: a transposed A needs a transposed W (dW = dY^T X)");
+    VGPT_REQUIRE(N % 8 == 0 && N >= 8 && (!a_transposed || (M % 8 == 0 && M >= 8)), VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_tr: the width of a transposed operand must be a multiple of 8");
+    VGPT_REQUIRE(ldc % 4 == 0 && (epilogue != VGPT_EPI_RESID || ldr % 4 == 0), VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_tr: ldc/ldr must be multiples of 4");
+    VGPT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && aligned16(A) && aligned16(W) && ((uintptr_t)C & 7) == 0,
+                 VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_tr: operands must be 16-byte aligned rows");
+    VGPT_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30) && K * ldw < (1ll << 30) &&
+                     (!a_transposed || K * lda < (1ll << 30)),
+                 VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_tr: dimension too large (a transposed operand must stay below 2 GiB)");
+    if (M == 0) return VGPT_OK;
+    GemmArgs g;
+    g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = (bf16*)C; g.extra = (const bf16*)extra;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+    g.epi = epilogue; g.act = VGPT_ACT_NONE; g.I = 0;
+    g.tiles_m = g.tiles_n = 0;
+    if (a_transposed) return launch<MODE_PLAIN, true, true>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_tr");
+    return launch<MODE_PLAIN, false, true>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_tr");
 }
 
 VGPT_EXPORT int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, void* out, int64_t M,

@@ -201,17 +201,36 @@ def adamw_step(master, param, grad, m, v, lr, beta1, beta2, eps, weight_decay, s
          _ptr(grad_scale), _stream())
 
 
-def linear_dx(dy2d, weight, scratch, dres=None, out=None):
-    """dX = dY @ W (+ dres): NT GEMM against W^T (transposed into `scratch`)."""
-    N, K = weight.shape
-    wt = transpose_pad(weight, scratch, N)  # (K, N)
-    return linear(dy2d, wt, residual=dres, out=out)
+def linear_dx(dy2d, weight, scratch=None, dres=None, out=None):
+    """dX (M, K) = dY (M, N) @ W (N, K) (+ dres): the weight is read as the transposed operand of the GEMM
+    (include/vgpt.h, vgpt_gemm_bf16_tr); `scratch` is unused (kept for callers of the transposing version)."""
+    _chk(dy2d, BF16, "linear_dx.dy", contiguous=False); _chk(weight, BF16, "linear_dx.weight", contiguous=False)
+    if dy2d.stride(1) != 1 or weight.stride(1) != 1:
+        raise VgptError("linear_dx: rows must be contiguous")
+    M, N = dy2d.shape
+    N2, K = weight.shape
+    if N != N2:
+        raise VgptError("linear_dx: shape mismatch")
+    if out is None:
+        out = torch.empty(M, K, dtype=BF16, device=dy2d.device)
+    epi, extra, ldr = (1, dres.data_ptr(), K) if dres is not None else (0, None, 0)
+    call("vgpt_gemm_bf16_tr", dy2d.data_ptr(), weight.data_ptr(), out.data_ptr(), extra, M, K, N, dy2d.stride(0),
+         weight.stride(0), K, ldr, epi, 0, 1, _stream())
+    return out
 
 
-def linear_dw(dy2d, x2d, scratch_a, scratch_b, out):
-    """dW (N, K) = dY^T @ X with M zero-padded to a multiple of 64."""
-    M = dy2d.shape[0]
-    Mp = (M + 63) // 64 * 64
-    dyt = transpose_pad(dy2d, scratch_a, Mp)  # (N, Mp)
-    xt = transpose_pad(x2d, scratch_b, Mp)    # (K, Mp)
-    return linear(dyt, xt, out=out)
+def linear_dw(dy2d, x2d, scratch_a=None, scratch_b=None, out=None):
+    """dW (N, K) = dY (M, N)^T @ X (M, K): both operands are read transposed, the reduction runs over the M rows
+    (a partial last 64-row tile is zero-filled by the hardware)."""
+    _chk(dy2d, BF16, "linear_dw.dy", contiguous=False); _chk(x2d, BF16, "linear_dw.x", contiguous=False)
+    if dy2d.stride(1) != 1 or x2d.stride(1) != 1:
+        raise VgptError("linear_dw: rows must be contiguous")
+    M, N = dy2d.shape
+    M2, K = x2d.shape
+    if M != M2:
+        raise VgptError("linear_dw: shape mismatch")
+    if out is None:
+        out = torch.empty(N, K, dtype=BF16, device=dy2d.device)
+    call("vgpt_gemm_bf16_tr", dy2d.data_ptr(), x2d.data_ptr(), out.data_ptr(), None, N, K, M, dy2d.stride(0), x2d.stride(0),
+         K, 0, 0, 1, 1, _stream())
+    return out

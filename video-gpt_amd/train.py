@@ -222,10 +222,7 @@ class Stage1Trainer:
         dtemb = T.act_bwd(temb, T.matmul(dmod, ada.weight), ops.ACT_SILU)
         self._mlp_bwd("t_embedder", te, dtemb, te_act, te_pre, sin)
         # decoder layers, last to first
-        sw = self._buf("sw", (max(2 * I, (nq + 2 * nk) * hd) * max(H, I),))           # W^T scratch
-        Mp = (M + 63) // 64 * 64
-        sa = self._buf("sa", (max(2 * I, (nq + 2 * nk) * hd) * Mp,))                    # dY^T scratch
-        sb = self._buf("sb", (max(H, I) * Mp,))                                         # X^T scratch
+        sw = sa = sb = None   # dX / dW read their operands transposed inside the GEMM (vgpt_gemm_bf16_tr)
         dact = self._buf("dact", (M, I)); dgu = self._buf("dgu", (M, 2 * I)); dn = self._buf("dn", (M, H))
         dctx = self._buf("dctx", (M, nq * hd)); dqkv = self._buf("dqkv", (M, (nq + 2 * nk) * hd))
         delta = self._buf("delta", (B, nq, L), F32)
