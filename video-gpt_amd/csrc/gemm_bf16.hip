@@ -194,16 +194,14 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     auto a_issue = [&](int i, int kt, char* dst) {
         if constexpr (ATR)
             buf_glds16_asm(a_rs, a_off[i], (int)(kt * a_step), lds_base + (uint32_t)(dst - smem));
-        else if constexpr (WTR)
-            glds16_asm(a_org + kt * a_step, a_off[i], lds_base + (uint32_t)(dst - smem));
         else
-            glds16(reinterpret_cast<const bf16*>(a_org + kt * a_step + a_off[i]), dst);
+            glds16_asm(a_org + kt * a_step, a_off[i], lds_base + (uint32_t)(dst - smem));
     };
     auto w_issue = [&](int i, int kt, char* dst) {
         if constexpr (WTR)
             buf_glds16_asm(w_rs, w_off[i], (int)(kt * w_step), lds_base + (uint32_t)(dst - smem));
         else
-            glds16(reinterpret_cast<const bf16*>(w_org + kt * w_step + w_off[i]), dst);
+            glds16_asm(w_org + kt * w_step, w_off[i], lds_base + (uint32_t)(dst - smem));
     };
     char* sA = smem;                    // [2][A_BYTES]
     char* sW = smem + 2 * C::A_BYTES;   // [2][W_BYTES]
