@@ -1,0 +1,33 @@
+"""Developer probe (GPU): attention forward / backward kernels on the cfg-3 stage-1 mask (B=2, L=3870, 32 heads)."""
+import importlib, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+importlib.import_module("video-gpt_amd")
+P = importlib.import_module("video-gpt_amd.processor"); ops = importlib.import_module("video-gpt_amd.ops")
+T = importlib.import_module("video-gpt_amd.ops_train")
+dev = "cuda:0"; BF = torch.bfloat16
+F, hw, bs, nh, hd = 8, (32, 32), 2, 32, 96
+proc = P.LVMProcessor(P.SpecialTokenizer(10, 11, 12))
+rows = []
+for _ in range(bs):
+    prompt = "".join(f"<|diffusion|><|image_{i + 1}|><img><|image_{i + 1}|></img>" if i < F - 1 else f"<|diffusion|><|image_{i + 1}|>" for i in range(F))
+    rows.append(proc.process_multi_modal_prompt_training(prompt, [torch.zeros(3, 256, 256) for _ in range(F)]))
+batch = proc.collator.collate_stage1(rows, F)
+mask = batch["attention_mask"].to(dev)
+B, L = mask.shape[:2]
+pm = ops.pack_mask(mask)
+summ = pm.summary.cpu()
+print("B", B, "L", L, "active (128-row block, 64-key tile) pairs per batch item:", int((summ != 0).sum()) // B, "of", summ[0].numel())
+qkv = torch.randn(B, L, 3 * nh * hd, device=dev).to(BF)
+out = torch.empty(B, L, nh * hd, dtype=BF, device=dev); lse = torch.empty(B, nh, L, dtype=torch.float32, device=dev)
+dout = torch.randn(B, L, nh * hd, device=dev).to(BF); dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse)
+def timeit(f, n=10):
+    for _ in range(2): f()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): f()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+print("fwd us", timeit(lambda: T.attention_qkv_train(qkv, pm, nh, nh, hd, out, lse)))
+print("bwd (delta + dQ + dV + dK) us", timeit(lambda: T.attention_qkv_bwd(qkv, out, dout, lse, delta, dqkv, pm, nh, nh, hd)))

@@ -37,14 +37,34 @@ struct BwdArgs {
     float scale, scale_log2e;
 };
 
-__device__ __forceinline__ void dma4(const void* src, char* lds) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds, 4, 0, 0);
+// LDS-DMA from inline asm (lane i's 4 / 16 bytes land at lds_dst + 4 i / 16 i): hipcc does not see LDS being written,
+// so it neither drains vmcnt(0) before the transposed LDS reads nor at the barrier; completion is tracked by the
+// explicit s_waitcnt vmcnt(0) + raw s_barrier at the top of every tile (same scheme as attn_fwd.hip).
+__device__ __forceinline__ void dma4(const void* src, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
 }
-__device__ __forceinline__ void dma16(const bf16* src, char* lds) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+__device__ __forceinline__ void dma16(const bf16* src, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
 }
+__device__ __forceinline__ void tile_sync() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+constexpr int LIST_MAX = 1023;  // active tiles per list chunk (4 KiB of LDS)
+// VGPT_BWD_EXPERIMENT (diagnostic builds of the dK/dV kernels, results are WRONG): 1 = no element-wise math,
+// 2 = transposed fragments read once, 3 = no statistics / mask DMA, 4 = no Q/dO DMA after the first tile
+#ifndef VGPT_BWD_EXPERIMENT
+#define VGPT_BWD_EXPERIMENT 0
+#endif
 
 // row read of a swizzled [row][192 B] image: lane (r = row, h) gets elements [16s + 8h, +8)
 __device__ __forceinline__ bf16x8 row_frag(const char* img, int row, int s, int h) {
@@ -129,7 +149,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     }
     const int64_t stat = ((int64_t)b * a.n_heads + head) * a.L + q_ld;
     const float lse = a.lse[stat], dlt = a.delta[stat];
-    const uint32_t* bits_row = a.bits + ((int64_t)b * a.L + q_ld) * a.W;
 
     f32x16 dQ[DT];
 #pragma unroll
@@ -144,8 +163,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
         g_key[j] = unit / CHUNKS;
         g_chunk[j] = (unit % CHUNKS) ^ ((g_key[j] >> 2) & 3);
     }
+    const uint32_t lds_base =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    constexpr int LIST_OFF = 2 * STAGE, MASK_OFF = LIST_OFF + 4096;
+    uint32_t* alist = reinterpret_cast<uint32_t*>(smem + LIST_OFF);
     auto stage = [&](int buf, int kt) {
-        char* sk = smem + buf * STAGE;
+        const uint32_t sk = lds_base + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < PIECES; ++j) {
             const int key = min(kt * 64 + g_key[j], a.L - 1);
@@ -154,85 +177,104 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
             dma16(vbase + (int64_t)key * a.v_ss + g_chunk[j] * 8, sk + TILE_BYTES + off);
         }
     };
-    auto next_active = [&](int kt) {
-        for (int k2 = kt + 1; k2 < a.nkt; ++k2)
-            if (sum_row[k2]) return k2;
-        return -1;
+    // mask words of a mixed tile: one dword per lane (row lane>>1, word lane&1) into this wave's 256-byte slot
+    const uint32_t* mrow_src = a.bits + ((int64_t)b * a.L + min(qb * 128 + wave * 32 + (lane >> 1), a.L - 1)) * a.W;
+    auto mask_dma = [&](int buf, uint32_t e) {
+        if (((e >> (2 * wave)) & 3) == 2)
+            dma4(mrow_src + min(2 * (int)(e >> 8) + (lane & 1), a.W - 1), lds_base + MASK_OFF + buf * 1024 + wave * 256);
     };
-    auto mask_words = [&](int t, uint32_t& w0, uint32_t& w1) {
-        w0 = w1 = 0xffffffffu;
-        if (((sum_row[t] >> (2 * wave)) & 3) == 2) {
-            w0 = (2 * t < a.W) ? bits_row[2 * t] : 0u;
-            w1 = (2 * t + 1 < a.W) ? bits_row[2 * t + 1] : 0u;
-        }
-    };
+    // everything loaded with ordinary global loads is retired here, before any LDS-DMA is in flight
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(Qf[s]), "+v"(dOf[s]));
+    float lse_r = lse, dlt_r = dlt;
+    asm volatile("" : "+v"(lse_r), "+v"(dlt_r));
 
-    int kt = next_active(-1), buf = 0;
-    uint32_t mw0 = 0xffffffffu, mw1 = 0xffffffffu;
-    if (kt >= 0) {
-        mask_words(kt, mw0, mw1);
-        stage(0, kt);
-    }
-    while (kt >= 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int chunk0 = 0; chunk0 < a.nkt; chunk0 += LIST_MAX) {
         __syncthreads();
-        const int nxt = next_active(kt);
-        uint32_t nw0 = 0xffffffffu, nw1 = 0xffffffffu;
-        if (nxt >= 0) {
-            mask_words(nxt, nw0, nw1);
-            stage(buf ^ 1, nxt);
-        }
-        const int code = (sum_row[kt] >> (2 * wave)) & 3;
-        if (code) {
-            const char* sk = smem + buf * STAGE;
-            const char* sv = sk + TILE_BYTES;
-            // the two 32-key halves of the tile are processed one after the other (register budget: 2 waves/SIMD)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                bf16x8 Kf[KS], Vf[KS];
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    Kf[s] = row_frag(sk, kb * 32 + r, s, h);
-                    Vf[s] = row_frag(sv, kb * 32 + r, s, h);
-                }
-                // K^T fragments for dQ^T += K^T dS^T (independent of the element-wise math below)
-                bf16x8 Kt[DT][2];
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) Kt[dt][t] = tr_frag(sk, kb * 32 + t * 16, dt, lane);
-                __builtin_amdgcn_sched_barrier(0);
-                f32x16 S, dP;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[s], Qf[s], S, 0, 0, 0);
-                    dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vf[s], dOf[s], dP, 0, 0, 0);
-                }
-                // dS^T = P^T o (dP^T - delta) * scale, P^T = exp2(c S^T - LSE); masked keys -> 0
-                const uint32_t w = (kb ? mw1 : mw0) >> (4 * h);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int bit = (i & 3) + 8 * (i >> 2);
-                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], a.scale_log2e, -lse));
-                    if (code == 2) p = ((w >> bit) & 1u) ? p : 0.f;
-                    S[i] = p * (dP[i] - dlt) * a.scale;
-                }
-                bf16x8 dSf[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) dSf[t] = pack8(S, t);
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kt[dt][t], dSf[t], dQ[dt], 0, 0, 0);
+        if (wave == 0) {  // compact the active key tiles of this q block into LDS: entry = tile << 8 | summary byte
+            const int lim = min(chunk0 + LIST_MAX, a.nkt);
+            int n = 0;
+            for (int base = chunk0; base < lim; base += 64) {
+                const int t = base + lane;
+                const uint32_t c = t < lim ? sum_row[t] : 0u;
+                const uint64_t bal = __ballot(c != 0);
+                if (c) alist[1 + n + __popcll(bal & ((1ull << lane) - 1))] = ((uint32_t)t << 8) | c;
+                n += __popcll(bal);
             }
+            if (lane == 0) alist[0] = (uint32_t)n;
         }
-        kt = nxt;
-        buf ^= 1;
-        mw0 = nw0;
-        mw1 = nw1;
+        __syncthreads();
+        const int n_act = __builtin_amdgcn_readfirstlane((int)alist[0]);
+        if (n_act == 0) continue;
+        uint32_t e_cur = __builtin_amdgcn_readfirstlane(alist[1]);
+        uint32_t e_nxt = __builtin_amdgcn_readfirstlane(n_act > 1 ? alist[2] : 0u);
+        int buf = 0;
+        mask_dma(0, e_cur);
+        stage(0, (int)(e_cur >> 8));
+        for (int it = 0; it < n_act; ++it) {
+            tile_sync();
+            const uint32_t e_n2 = it + 2 < n_act ? alist[3 + it] : 0u;
+            if (it + 1 < n_act) {
+                mask_dma(buf ^ 1, e_nxt);
+                stage(buf ^ 1, (int)(e_nxt >> 8));
+            }
+            const int code = (e_cur >> (2 * wave)) & 3;
+            if (code) {
+                const char* sk = smem + buf * STAGE;
+                const char* sv = sk + TILE_BYTES;
+                uint32_t mw0 = 0xffffffffu, mw1 = 0xffffffffu;
+                if (code == 2) {
+                    const uint2 mw = *reinterpret_cast<const uint2*>(smem + MASK_OFF + buf * 1024 + wave * 256 + r * 8);
+                    mw0 = mw.x;
+                    mw1 = (2 * (int)(e_cur >> 8) + 1 < a.W) ? mw.y : 0u;
+                }
+                // the two 32-key halves of the tile are processed one after the other (register budget: 2 waves/SIMD)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    bf16x8 Kf[KS], Vf[KS];
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        Kf[s] = row_frag(sk, kb * 32 + r, s, h);
+                        Vf[s] = row_frag(sv, kb * 32 + r, s, h);
+                    }
+                    // K^T fragments for dQ^T += K^T dS^T (independent of the element-wise math below)
+                    bf16x8 Kt[DT][2];
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) Kt[dt][t] = tr_frag(sk, kb * 32 + t * 16, dt, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x16 S, dP;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[s], Qf[s], S, 0, 0, 0);
+                        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vf[s], dOf[s], dP, 0, 0, 0);
+                    }
+                    // dS^T = P^T o (dP^T - delta) * scale, P^T = exp2(c S^T - LSE); masked keys -> 0
+                    const uint32_t w = (kb ? mw1 : mw0) >> (4 * h);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int bit = (i & 3) + 8 * (i >> 2);
+                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], a.scale_log2e, -lse_r));
+                        if (code == 2) p = ((w >> bit) & 1u) ? p : 0.f;
+                        S[i] = p * (dP[i] - dlt_r) * a.scale;
+                    }
+                    bf16x8 dSf[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) dSf[t] = pack8(S, t);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kt[dt][t], dSf[t], dQ[dt], 0, 0, 0);
+                }
+            }
+            e_cur = e_nxt;
+            e_nxt = __builtin_amdgcn_readfirstlane(e_n2);
+            buf ^= 1;
+        }
     }
     if (q_row < a.L) {
         bf16* op = a.dq + (int64_t)b * a.dq_sb + (int64_t)head * a.dq_sh + (int64_t)q_row * a.dq_ss;
@@ -251,7 +293,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
 // ------------------------------------------------------------------------------------------------------
 // dK, dV: block = 4 waves = 128 keys of one (batch, kv head); Q/dO tiles of 64 query rows in LDS
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs a) {
+// WANT_DK / WANT_DV: the kernel is launched twice, once per gradient.  Keeping both 96 x 32 accumulator sets plus their
+// operands in one wave needs ~380 VGPRs (one wave per SIMD); each half fits the 256-register budget of two waves per
+// SIMD, which more than pays for recomputing S = Q K^T in both.
+template <bool WANT_DK, bool WANT_DV>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
     // stage: Q image | dO image | lse[64] | delta[64] | mask words [64][4]
     constexpr int STAT_OFF = 2 * TILE_BYTES, MASK_OFF = STAT_OFF + 512, STAGE = MASK_OFF + 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -268,14 +314,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs a) {
     const int kblk = wid % nkb, kvh = (wid / nkb) % a.n_kv_heads, b = wid / (nkb * a.n_kv_heads);
     const int key_row = kblk * 128 + wave * 32 + r;
     const int key_ld = min(key_row, a.L - 1);
-    const int ktile = kblk * 2 + (wave >> 1);  // 64-key tile of this wave (summary column)
     const bf16* kp = a.k + (int64_t)b * a.k_sb + (int64_t)kvh * a.k_sh + (int64_t)key_ld * a.k_ss;
     const bf16* vp = a.v + (int64_t)b * a.v_sb + (int64_t)kvh * a.v_sh + (int64_t)key_ld * a.v_ss;
     bf16x8 Kf[KS], Vf[KS];  // B operands: lane holds K[key r][16s + 8h .. +8)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         Kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s + 8 * h);
-        Vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s + 8 * h);
+        if constexpr (WANT_DK) Vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s + 8 * h);
     }
     f32x16 dK[DT], dV[DT];
 #pragma unroll
@@ -291,6 +336,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs a) {
         g_chunk[j] = (unit % CHUNKS) ^ ((g_row[j] >> 2) & 3);
     }
     const int nqt = (a.L + 63) / 64;
+    const uint32_t lds_base =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    uint32_t* alist = reinterpret_cast<uint32_t*>(smem + 2 * STAGE);
+    // the K/V fragment loads are retired here, before any LDS-DMA is in flight
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        asm volatile("" : "+v"(Kf[s]));
+        if constexpr (WANT_DK) asm volatile("" : "+v"(Vf[s]));
+    }
 
     for (int gh = 0; gh < a.kv_group; ++gh) {
         const int head = kvh * a.kv_group + gh;
@@ -298,19 +352,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs a) {
         const bf16* dobase = a.dout + (int64_t)b * a.do_sb + (int64_t)head * a.do_sh;
         const float* lse_b = a.lse + ((int64_t)b * a.n_heads + head) * a.L;
         const float* dlt_b = a.delta + ((int64_t)b * a.n_heads + head) * a.L;
-        // activity of query tile qt for this block: any code bit in the two summary bytes of its 128-row block
-        auto tile_bits = [&](int qt, int kt) -> int {
-            if (kt >= a.nkt) return 0;
+        // 4 code bits (two 32-row halves) of query tile qt against key tile kt
+        auto tile_bits = [&](int qt, int kt) -> uint32_t {
+            if (kt >= a.nkt) return 0u;
             const uint8_t sbyte = a.summary[((int64_t)b * a.nqb + (qt >> 1)) * a.nkt + kt];
-            return (sbyte >> (4 * (qt & 1))) & 15;  // 2 x 2-bit codes of the two 32-row halves of this 64-row tile
-        };
-        auto next_active = [&](int qt) {
-            for (int q2 = qt + 1; q2 < nqt; ++q2)
-                if (tile_bits(q2, kblk * 2) | tile_bits(q2, kblk * 2 + 1)) return q2;
-            return -1;
+            return (sbyte >> (4 * (qt & 1))) & 15u;
         };
         auto stage = [&](int buf, int qt) {
-            char* sq = smem + buf * STAGE;
+            const uint32_t sq = lds_base + buf * STAGE;
 #pragma unroll
             for (int j = 0; j < PIECES; ++j) {
                 const int row = min(qt * 64 + g_row[j], a.L - 1);
@@ -318,35 +367,53 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs a) {
                 dma16(qbase + (int64_t)row * a.q_ss + g_chunk[j] * 8, sq + off);
                 dma16(dobase + (int64_t)row * a.do_ss + g_chunk[j] * 8, sq + TILE_BYTES + off);
             }
-            // row statistics and mask words also arrive by LDS-DMA (4-byte form), so that no ordinary
-            // global load sits behind the tile DMA in the in-order vmcnt queue
+            // row statistics and mask words also arrive by LDS-DMA (4-byte form)
+            if (VGPT_BWD_EXPERIMENT == 3) return;
             if (wave == 0) {
                 const int row = min(qt * 64 + lane, a.L - 1);
                 dma4(lse_b + row, sq + STAT_OFF);
                 dma4(dlt_b + row, sq + STAT_OFF + 256);
             } else if (wave == 1) {
+                // mask words as [32-key group of the block][query row]: the words a wave needs for four
+                // consecutive query rows are then one 16-byte LDS read
+                const int row = min(qt * 64 + lane, a.L - 1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = i * 64 + lane;
-                    const int row = min(qt * 64 + (idx >> 2), a.L - 1);
-                    const int wi = min(kblk * 4 + (idx & 3), a.W - 1);
-                    dma4(a.bits + ((int64_t)b * a.L + row) * a.W + wi, sq + MASK_OFF + i * 256);
-                }
+                for (int i = 0; i < 4; ++i)
+                    dma4(a.bits + ((int64_t)b * a.L + row) * a.W + min(kblk * 4 + i, a.W - 1), sq + MASK_OFF + i * 256);
             }
         };
 
-        int qt = next_active(-1), buf = 0;
-        if (qt >= 0) stage(0, qt);
-        while (qt >= 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const int nxt = next_active(qt);
-            if (nxt >= 0) stage(buf ^ 1, nxt);
+        for (int chunk0 = 0; chunk0 < nqt; chunk0 += LIST_MAX) {
+        __syncthreads();  // previous list / buffers are free (also separates the heads)
+        if (wave == 0) {  // active query tiles of this key block: entry = qt << 8 | bits(ktile 0) | bits(ktile 1) << 4
+            const int lim = min(chunk0 + LIST_MAX, nqt);
+            int n = 0;
+            for (int base = chunk0; base < lim; base += 64) {
+                const int t = base + lane;
+                const uint32_t c = t < lim ? (tile_bits(t, kblk * 2) | (tile_bits(t, kblk * 2 + 1) << 4)) : 0u;
+                const uint64_t bal = __ballot(c != 0);
+                if (c) alist[1 + n + __popcll(bal & ((1ull << lane) - 1))] = ((uint32_t)t << 8) | c;
+                n += __popcll(bal);
+            }
+            if (lane == 0) alist[0] = (uint32_t)n;
+        }
+        __syncthreads();
+        const int n_act = __builtin_amdgcn_readfirstlane((int)alist[0]);
+        if (n_act == 0) continue;
+        uint32_t e_cur = __builtin_amdgcn_readfirstlane(alist[1]);
+        uint32_t e_nxt = __builtin_amdgcn_readfirstlane(n_act > 1 ? alist[2] : 0u);
+        int buf = 0;
+        stage(0, (int)(e_cur >> 8));
+        for (int it = 0; it < n_act; ++it) {
+            tile_sync();
+            const uint32_t e_n2 = it + 2 < n_act ? alist[3 + it] : 0u;
+            if (it + 1 < n_act && VGPT_BWD_EXPERIMENT != 4) stage(buf ^ 1, (int)(e_nxt >> 8));
+            const int qt = (int)(e_cur >> 8);
+            const int codes = (e_cur >> (4 * (wave >> 1))) & 15;
             const char* sq = smem + buf * STAGE;
             const char* sdo = sq + TILE_BYTES;
             const float* st = reinterpret_cast<const float*>(sq + STAT_OFF);
             const uint32_t* mw = reinterpret_cast<const uint32_t*>(sq + MASK_OFF);
-            const int codes = tile_bits(qt, ktile);
 #pragma unroll
             for (int qh = 0; qh < 2; ++qh) {  // two 32-row halves of the query tile
                 const int code = (codes >> (2 * qh)) & 3;
@@ -361,7 +428,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs a) {
 #pragma unroll
                     for (int s = 0; s < KS; ++s) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qr[s], Kf[s], S, 0, 0, 0);
                 }
-                {
+                if constexpr (WANT_DK) {
                     bf16x8 dOr[KS];
 #pragma unroll
                     for (int s = 0; s < KS; ++s) dOr[s] = row_frag(sdo, qh * 32 + r, s, h);
@@ -370,46 +437,82 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs a) {
                 }
                 // transposed operand for dV^T += dO^T P (k index = query row); requested before the element-wise math
                 bf16x8 dOt[DT][2];
+                if constexpr (WANT_DV) {
+                    if (VGPT_BWD_EXPERIMENT != 2 || it == 0) {
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
+                        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) dOt[dt][t] = tr_frag(sdo, qh * 32 + t * 16, dt, lane);
+                            for (int t = 0; t < 2; ++t) dOt[dt][t] = tr_frag(sdo, qh * 32 + t * 16, dt, lane);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
+                // accumulator register i holds query row qh*32 + 8 (i>>2) + 4h + (i&3): the row statistics of four
+                // consecutive registers are one 16-byte LDS read
+                f32x4 lse4[4], dlt4[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    lse4[g4] = *reinterpret_cast<const f32x4*>(st + qh * 32 + 8 * g4 + 4 * h);
+                    if constexpr (WANT_DK) dlt4[g4] = *reinterpret_cast<const f32x4*>(st + 64 + qh * 32 + 8 * g4 + 4 * h);
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int qrow = qh * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;  // accumulator row -> query row
-                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], a.scale_log2e, -st[qrow]));
-                    if (code == 2) p = ((mw[qrow * 4 + wave] >> r) & 1u) ? p : 0.f;
-                    if (key_row >= a.L || qt * 64 + qrow >= a.L) p = 0.f;
-                    S[i] = p * (dP[i] - st[64 + qrow]) * a.scale;  // dS (in place)
-                    dP[i] = p;                                      // P  (in place)
+                    if (VGPT_BWD_EXPERIMENT == 1) continue;
+                    dP[i] = WANT_DK ? dP[i] - dlt4[i >> 2][i & 3] : 0.f;                                      // dP - delta
+                    S[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], a.scale_log2e, -lse4[i >> 2][i & 3]));  // P
                 }
-                bf16x8 Pf[2], dSf[2];
+                if (code == 2) {  // mixed tile: bit r of the word of (query row, this wave's 32 keys)
+                    const uint32_t mybit = 1u << r;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    Pf[t] = pack8(dP, t);
-                    dSf[t] = pack8(S, t);
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const uint4 w4 = *reinterpret_cast<const uint4*>(mw + wave * 64 + qh * 32 + 8 * g4 + 4 * h);
+                        S[4 * g4 + 0] = (w4.x & mybit) ? S[4 * g4 + 0] : 0.f;
+                        S[4 * g4 + 1] = (w4.y & mybit) ? S[4 * g4 + 1] : 0.f;
+                        S[4 * g4 + 2] = (w4.z & mybit) ? S[4 * g4 + 2] : 0.f;
+                        S[4 * g4 + 3] = (w4.w & mybit) ? S[4 * g4 + 3] : 0.f;
+                    }
                 }
+                if (qt * 64 + 64 > a.L || kblk * 128 + 128 > a.L) {  // rows / keys past L (last tiles only)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
+                    for (int i = 0; i < 16; ++i) {
+                        const int qrow = qh * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key_row >= a.L || qt * 64 + qrow >= a.L) S[i] = 0.f;
+                    }
+                }
+                // S now holds P; dP holds dP - delta.  dS = P (dP - delta) scale goes to dP, P stays in S.
+                if constexpr (WANT_DK) {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dOt[dt][t], Pf[t], dV[dt], 0, 0, 0);
-                // dK^T += Q^T dS
+                    for (int i = 0; i < 16; ++i) dP[i] = S[i] * dP[i] * a.scale;
+                }
+                if constexpr (WANT_DV) {
+                    bf16x8 Pf[2];
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    bf16x8 Qt[2];
+                    for (int t = 0; t < 2; ++t) Pf[t] = pack8(S, t);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) Qt[t] = tr_frag(sq, qh * 32 + t * 16, dt, lane);
+                    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qt[t], dSf[t], dK[dt], 0, 0, 0);
+                        for (int t = 0; t < 2; ++t)
+                            dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dOt[dt][t], Pf[t], dV[dt], 0, 0, 0);
+                }
+                if constexpr (WANT_DK) {  // dK^T += Q^T dS
+                    bf16x8 dSf[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) dSf[t] = pack8(dP, t);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        bf16x8 Qt[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) Qt[t] = tr_frag(sq, qh * 32 + t * 16, dt, lane);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qt[t], dSf[t], dK[dt], 0, 0, 0);
+                    }
                 }
             }
-            qt = nxt;
+            e_cur = e_nxt;
+            e_nxt = __builtin_amdgcn_readfirstlane(e_n2);
             buf ^= 1;
         }
-        __syncthreads();  // the next head's prologue DMA reuses buffer 0
+        }
     }
     if (key_row < a.L) {
         bf16* kp_o = a.dk + (int64_t)b * a.dk_sb + (int64_t)kvh * a.dk_sh + (int64_t)key_row * a.dk_ss;
@@ -424,8 +527,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs a) {
                     ok[t] = f2bf(dK[dt][4 * g4 + t]);
                     ov[t] = f2bf(dV[dt][4 * g4 + t]);
                 }
-                *reinterpret_cast<bf16x4*>(kp_o + dt * 32 + 8 * g4 + 4 * h) = ok;
-                *reinterpret_cast<bf16x4*>(vp_o + dt * 32 + 8 * g4 + 4 * h) = ov;
+                if constexpr (WANT_DK) *reinterpret_cast<bf16x4*>(kp_o + dt * 32 + 8 * g4 + 4 * h) = ok;
+                if constexpr (WANT_DV) *reinterpret_cast<bf16x4*>(vp_o + dt * 32 + 8 * g4 + 4 * h) = ov;
             }
     }
 }
@@ -459,11 +562,14 @@ VGPT_EXPORT int vgpt_attn_blockmask_bwd(const void* q, const void* k, const void
     a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
     static bool attr_set = false;
-    constexpr int lds_dq = 2 * 2 * TILE_BYTES, lds_dkv = 2 * (2 * TILE_BYTES + 512 + 1024);
+    constexpr int lds_dq = 2 * 2 * TILE_BYTES + 4096 + 2048, lds_dkv = 2 * (2 * TILE_BYTES + 512 + 1024) + 4096;
     if (!attr_set) {
         hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
-        hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
-        if (e1 != hipSuccess || e2 != hipSuccess) {
+        hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true, false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
+        hipError_t e3 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
             vgpt_set_error("vgpt_attn_blockmask_bwd: hipFuncSetAttribute failed");
             return VGPT_ERR_HIP;
         }
@@ -473,7 +579,9 @@ VGPT_EXPORT int vgpt_attn_blockmask_bwd(const void* q, const void* k, const void
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(nstat, 256)), dim3(256), 0, st, a.o, a.dout, delta_ws, a.B,
                        a.L, n_heads, a.o_sb, a.o_sh, a.o_ss, a.do_sb, a.do_sh, a.do_ss);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(a.nqb * n_heads * a.B), dim3(256), lds_dq, st, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(cdiv(L, 128) * n_kv_heads * B)), dim3(256), lds_dkv, st, a);
+    const dim3 grid_kv((unsigned)(cdiv(L, 128) * n_kv_heads * B));
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), grid_kv, dim3(256), lds_dkv, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), grid_kv, dim3(256), lds_dkv, st, a);
     VGPT_CHECK_LAUNCH("vgpt_attn_blockmask_bwd");
     return VGPT_OK;
 }
