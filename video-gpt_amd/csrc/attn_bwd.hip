@@ -293,11 +293,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
 // ------------------------------------------------------------------------------------------------------
 // dK, dV: block = 4 waves = 128 keys of one (batch, kv head); Q/dO tiles of 64 query rows in LDS
 // ------------------------------------------------------------------------------------------------------
-// WANT_DK / WANT_DV: the kernel is launched twice, once per gradient.  Keeping both 96 x 32 accumulator sets plus their
-// operands in one wave needs ~380 VGPRs (one wave per SIMD); each half fits the 256-register budget of two waves per
-// SIMD, which more than pays for recomputing S = Q K^T in both.
+// WANT_DK / WANT_DV: both gradients in one launch need ~380 VGPRs (one wave per SIMD); each alone fits the 256-register
+// budget of two waves per SIMD at the price of recomputing S = Q K^T.  Both forms are built (see the launch below).
 template <bool WANT_DK, bool WANT_DV>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, (WANT_DK && WANT_DV) ? 1 : 2) void attn_bwd_dkv_kernel(BwdArgs a) {
     // stage: Q image | dO image | lse[64] | delta[64] | mask words [64][4]
     constexpr int STAT_OFF = 2 * TILE_BYTES, MASK_OFF = STAT_OFF + 512, STAGE = MASK_OFF + 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -569,7 +568,9 @@ VGPT_EXPORT int vgpt_attn_blockmask_bwd(const void* q, const void* k, const void
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
         hipError_t e3 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false, true>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        hipError_t e4 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
             vgpt_set_error("vgpt_attn_blockmask_bwd: hipFuncSetAttribute failed");
             return VGPT_ERR_HIP;
         }
@@ -580,8 +581,16 @@ VGPT_EXPORT int vgpt_attn_blockmask_bwd(const void* q, const void* k, const void
                        a.L, n_heads, a.o_sb, a.o_sh, a.o_ss, a.do_sb, a.do_sh, a.do_ss);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(a.nqb * n_heads * a.B), dim3(256), lds_dq, st, a);
     const dim3 grid_kv((unsigned)(cdiv(L, 128) * n_kv_heads * B));
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), grid_kv, dim3(256), lds_dkv, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), grid_kv, dim3(256), lds_dkv, st, a);
+    // dK and dV in one launch (one wave per SIMD, ~380 VGPRs) measured 5 % faster than two launches at two waves per
+    // SIMD that each recompute S (927 vs 971 us on the cfg-3 mask); VGPT_ATTN_BWD_SPLIT=1 selects the latter for A/B runs
+    static int split = -1;
+    if (split < 0) { const char* e = getenv("VGPT_ATTN_BWD_SPLIT"); split = e ? atoi(e) : 0; }
+    if (!split) {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true>), grid_kv, dim3(256), lds_dkv, st, a);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), grid_kv, dim3(256), lds_dkv, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), grid_kv, dim3(256), lds_dkv, st, a);
+    }
     VGPT_CHECK_LAUNCH("vgpt_attn_blockmask_bwd");
     return VGPT_OK;
 }
