@@ -382,9 +382,9 @@ def main():
         n_launch = len(ev)
         alg = 2 * (4 * H * H + H * I) * real_tokens_step * nl  # qkv (3H^2) + o (H^2) + down (HI), computed tokens
         achieved = alg / t_gemm / 1e12
-        traffic = None  # per-launch bytes beyond L2 from the committed PMC passes (profiles/r01_pmc_traffic.json)
+        traffic = None  # per-launch bytes beyond L2 from the committed PMC passes (profiles/r01_pmc_traffic_v2.json, scripts/pmc_traffic.py)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v2.json")) as f:
                 for name, rec in json.load(f)["kernels"].items():
                     if "gemm_bf16_kernel<0" in name:
                         traffic = rec["traffic_bytes_per_launch"]
