@@ -71,13 +71,24 @@ class LVMPipeline:
             return [x.to(self.device) for x in data]
         return data.to(self.device)
 
-    def vae_encode(self, x, dtype, noise: Optional[torch.Tensor] = None):
-        """LVM/pipeline.py:110-117: sample the posterior, (z - shift) * scaling, cast to `dtype`."""
-        d = self.vae.encode(x).latent_dist
+    def vae_encode(self, x, dtype, noise: Optional[torch.Tensor] = None, dist=None):
+        """LVM/pipeline.py:110-117: sample the posterior, (z - shift) * scaling, cast to `dtype`.  `dist`: the
+        posterior of this image when the encoder already ran on a batch (vae_posteriors)."""
+        d = dist if dist is not None else self.vae.encode(x).latent_dist
         if noise is None:
             p = d.parameters
             noise = torch.randn(p.shape[0], p.shape[1] // 2, *p.shape[2:], device=p.device, dtype=torch.float32)
         return d.sample_scaled(noise, self.vae.config.shift_factor or 0.0, self.vae.config.scaling_factor).to(dtype)
+
+    def vae_posteriors(self, imgs):
+        """Encoder convolutions of all condition frames of a round in ONE batched pass (the reference encodes them one
+        by one, LVM/pipeline.py:482-486; the convolutions are per-sample, so the moments are the same and the
+        launches are 4-16x larger).  Sampling stays per image, in the reference's RNG order."""
+        from .vae import DiagonalGaussianDistribution
+        if len(imgs) > 1 and all(t.shape == imgs[0].shape for t in imgs):
+            mom = self.vae.encode(torch.cat(imgs, dim=0)).latent_dist.parameters
+            return [DiagonalGaussianDistribution(mom[i:i + 1]) for i in range(len(imgs))]
+        return [self.vae.encode(t).latent_dist for t in imgs]
 
     def _to_images(self, u8: torch.Tensor, output_type: str):
         if output_type == "pt":
@@ -138,10 +149,11 @@ class LVMPipeline:
             latents = latents * (1 + num_cfg)
 
             input_img_latents = []
+            dists = self.vae_posteriors([input_data["input_pixel_values"][idx].to(self.device)
+                                         for idx in range(prompt_img_len)])
             for idx in range(prompt_img_len):
-                img = input_data["input_pixel_values"][idx].to(self.device)
                 vn = vae_noise[len(self.last_latents)] if vae_noise is not None else None
-                lat = self.vae_encode(img, dtype, None if vn is None else vn.to(self.device))
+                lat = self.vae_encode(None, dtype, None if vn is None else vn.to(self.device), dist=dists[idx])
                 self.last_latents.append(lat)
                 if k > 0:  # re-noise the re-encoded condition frames (pipeline.py:496-497); 16 KB blend, torch RNG
                     c = clean_image_noise_level
