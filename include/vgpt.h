@@ -286,10 +286,12 @@ int vgpt_act_bwd(const void* pre, const void* dy, void* dx, int64_t n, int act, 
 int vgpt_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dres, void* dx, float* dw,
                      float* rstd_ws /* rows floats */, int64_t rows, int64_t H, float eps, void* stream);
 /* C[m][n] = alpha * sum_k A[m*sa_m + k*sa_k] * B[k*sb_k + n*sb_n] (+ C); *_f32: 0 = bf16, 1 = fp32.  For the
- * small heads (patch embeds, timestep MLPs, adaLN, final Linear) whose backward is not worth an MFMA kernel. */
+ * small heads (patch embeds, timestep MLPs, adaLN, final Linear) whose backward is not worth an MFMA kernel.
+ * splitk_ws (NULL or ws_floats floats): workspace that lets long reductions with few outputs be sliced over the chip
+ * (slices are added in a fixed order: deterministic). */
 int vgpt_matmul_generic(const void* A, int a_f32, int64_t sa_m, int64_t sa_k, const void* B, int b_f32, int64_t sb_k,
                         int64_t sb_n, void* C, int c_f32, int64_t sc_m, int64_t sc_n, int64_t M, int64_t N, int64_t K,
-                        float alpha, int accumulate, void* stream);
+                        float alpha, int accumulate, float* splitk_ws, int64_t ws_floats, void* stream);
 /* out[c] (+)= sum_r X[r*ld + c]  (bias gradients). */
 int vgpt_colsum(const void* X, int x_f32, float* out, int64_t R, int64_t C, int64_t ld, int accumulate, void* stream);
 /* xt[f] = t[f]*x1[f] + (1-t[f])*x0[f]  (loss.py:175,186), fp32 in, bf16 out. */

@@ -74,7 +74,7 @@ SIGNATURES = {
     "vgpt_act_bwd": (c_int, [_P, _P, _P, _I64, c_int, _P]),
     "vgpt_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, c_float, _P]),
     "vgpt_matmul_generic": (c_int, [_P, c_int, _I64, _I64, _P, c_int, _I64, _I64, _P, c_int, _I64, _I64, _I64, _I64,
-                                    _I64, c_float, c_int, _P]),
+                                    _I64, c_float, c_int, _P, _I64, _P]),
     "vgpt_colsum": (c_int, [_P, c_int, _P, _I64, _I64, _I64, c_int, _P]),
     "vgpt_lerp_frames": (c_int, [_P, _P, _P, _P, c_int, _I64, _P]),
     "vgpt_mse_frames": (c_int, [_P, _P, _P, _P, c_int, _I64, _P]),

@@ -35,7 +35,7 @@ VGPT_EXPORT int vgpt_graph_end_capture(void* stream, void** graph_exec_out) {
     }
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);  // the executable graph keeps what it needs
     if (e != hipSuccess) {
         vgpt_set_error("vgpt_graph_end_capture: instantiate: %s", hipGetErrorString(e));
         return VGPT_ERR_HIP;

@@ -195,6 +195,37 @@ __global__ __launch_bounds__(256) void matmul_generic_kernel(const TA* __restric
     *c = (TC)acc;
 }
 
+// split-K form for long reductions with few outputs (dW of the patch embeds / final Linear, the adaLN and timestep-MLP
+// input gradients: K = 3072..6144 against ~49 k outputs): slice s of the reduction goes to ws[s][m][n], a second kernel
+// adds the slices in a fixed order (deterministic) and applies alpha / accumulate / the output type.
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void matmul_splitk_kernel(const TA* __restrict__ A, int64_t sa_m, int64_t sa_k,
+                                                            const TB* __restrict__ B, int64_t sb_k, int64_t sb_n,
+                                                            float* __restrict__ ws, int M, int N, int K, int kc) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    const int k0 = blockIdx.y * kc, k1 = min(K, k0 + kc);
+    const TA* a = A + m * sa_m;
+    const TB* b = B + n * sb_n;
+    float acc = 0.f;
+    for (int k = k0; k < k1; ++k) acc += (float)a[k * sa_k] * (float)b[k * sb_k];
+    ws[(int64_t)blockIdx.y * M * N + idx] = acc;
+}
+template <typename TC>
+__global__ __launch_bounds__(256) void matmul_splitk_reduce_kernel(const float* __restrict__ ws, TC* __restrict__ C,
+                                                                   int64_t sc_m, int64_t sc_n, int M, int N, int splits,
+                                                                   float alpha, int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += ws[(int64_t)s * M * N + idx];
+    acc *= alpha;
+    TC* c = C + (idx / N) * sc_m + (idx % N) * sc_n;
+    if (accumulate) acc += (float)*c;
+    *c = (TC)acc;
+}
+
 // ---- column sums: out[c] (+)= sum_r X[r][c] -------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ out, int64_t R, int C,
@@ -568,12 +599,40 @@ VGPT_EXPORT int vgpt_rmsnorm_bwd(const void* x, const void* w, const void* dy, c
 
 VGPT_EXPORT int vgpt_matmul_generic(const void* A, int a_f32, int64_t sa_m, int64_t sa_k, const void* B, int b_f32,
                                     int64_t sb_k, int64_t sb_n, void* C, int c_f32, int64_t sc_m, int64_t sc_n,
-                                    int64_t M, int64_t N, int64_t K, float alpha, int accumulate, void* stream) {
+                                    int64_t M, int64_t N, int64_t K, float alpha, int accumulate, float* splitk_ws,
+                                    int64_t ws_floats, void* stream) {
     VGPT_REQUIRE(A && B && C, VGPT_ERR_INVALID, "vgpt_matmul_generic: null pointer");
     VGPT_REQUIRE(M >= 0 && N >= 0 && K >= 0 && M * N < (1ll << 40), VGPT_ERR_INVALID, "vgpt_matmul_generic: bad shape");
     if (M == 0 || N == 0) return VGPT_OK;
     dim3 grid((unsigned)cdiv(M * N, 256));
     hipStream_t s = (hipStream_t)stream;
+    // long reduction, few outputs: slice K so that the grid fills the chip
+    if (splitk_ws && K >= 512 && M * N <= (1 << 18)) {
+        int64_t splits = std::min<int64_t>({(int64_t)64, K / 64, ws_floats / (M * N), cdiv((int64_t)256 * 1024, M * N)});
+        if (splits >= 2) {
+            const int kc = (int)cdiv(K, splits);
+            splits = cdiv(K, kc);
+            dim3 g2(grid.x, (unsigned)splits);
+#define SK(TA, TB)                                                                                                   \
+    hipLaunchKernelGGL((matmul_splitk_kernel<TA, TB>), g2, dim3(256), 0, s, (const TA*)A, sa_m, sa_k, (const TB*)B, \
+                       sb_k, sb_n, splitk_ws, (int)M, (int)N, (int)K, kc)
+            switch ((a_f32 ? 2 : 0) | (b_f32 ? 1 : 0)) {
+                case 0: SK(bf16, bf16); break;
+                case 1: SK(bf16, float); break;
+                case 2: SK(float, bf16); break;
+                default: SK(float, float); break;
+            }
+#undef SK
+            if (c_f32)
+                hipLaunchKernelGGL(matmul_splitk_reduce_kernel<float>, grid, dim3(256), 0, s, splitk_ws, (float*)C, sc_m, sc_n,
+                                   (int)M, (int)N, (int)splits, alpha, accumulate);
+            else
+                hipLaunchKernelGGL(matmul_splitk_reduce_kernel<bf16>, grid, dim3(256), 0, s, splitk_ws, (bf16*)C, sc_m, sc_n,
+                                   (int)M, (int)N, (int)splits, alpha, accumulate);
+            VGPT_CHECK_LAUNCH("vgpt_matmul_generic");
+            return VGPT_OK;
+        }
+    }
 #define MG(TA, TB, TC)                                                                                              \
     hipLaunchKernelGGL((matmul_generic_kernel<TA, TB, TC>), grid, dim3(256), 0, s, (const TA*)A, sa_m, sa_k,        \
                        (const TB*)B, sb_k, sb_n, (TC*)C, sc_m, sc_n, (int)M, (int)N, (int)K, alpha, accumulate)

@@ -107,6 +107,9 @@ def rmsnorm_bwd(x, w, dy, dx, dw, eps, dres=None):
     return dx
 
 
+_splitk_ws = {}
+
+
 def matmul(a, b, out=None, ta=False, tb=False, alpha=1.0, accumulate=False, out_dtype=BF16):
     """out = alpha * op(a) @ op(b) (+ out) on the generic strided kernel (small heads only)."""
     M, K = (a.shape[1], a.shape[0]) if ta else a.shape
@@ -117,8 +120,12 @@ def matmul(a, b, out=None, ta=False, tb=False, alpha=1.0, accumulate=False, out_
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
     sa_m, sa_k = (a.stride(1), a.stride(0)) if ta else (a.stride(0), a.stride(1))
     sb_k, sb_n = (b.stride(1), b.stride(0)) if tb else (b.stride(0), b.stride(1))
+    ws = _splitk_ws.get(a.device)
+    if ws is None:
+        ws = _splitk_ws[a.device] = torch.empty(4 << 20, dtype=F32, device=a.device)   # 16 MiB of reduction slices
     call("vgpt_matmul_generic", a.data_ptr(), _f32flag(a), sa_m, sa_k, b.data_ptr(), _f32flag(b), sb_k, sb_n,
-         out.data_ptr(), _f32flag(out), out.stride(0), out.stride(1), M, N, K, float(alpha), int(accumulate), _stream())
+         out.data_ptr(), _f32flag(out), out.stride(0), out.stride(1), M, N, K, float(alpha), int(accumulate),
+         ws.data_ptr(), ws.numel(), _stream())
     return out
 
 
