@@ -112,6 +112,9 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    # torch first: it brings its own copy of the HIP runtime, and the one that is loaded first serves the whole process;
+    # with ours (/opt/rocm) loaded first, torch's device state and our launches end up in different runtimes
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name, None)
