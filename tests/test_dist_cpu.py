@@ -46,3 +46,41 @@ def test_single_process_is_a_noop():
     D = importlib.import_module("video-gpt_amd.dist_utils")
     assert D.shard_units(5, 0, 1) == [0, 1, 2, 3, 4]
     assert D.max_over_ranks(1.5) == 1.5
+
+
+# ---- Ulysses all-to-all layout (video-gpt_amd/sequence_parallel.py), world 2 over gloo with CPU tensors ----
+def _sp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    SP = importlib.import_module("video-gpt_amd.sequence_parallel")
+    g = SP.initialize_sequence_parallel_state(world)
+    B, S, H, d = 2, 6 * world, 4 * world, 3
+    full = torch.arange(B * S * H * d, dtype=torch.float32).view(B, S, H, d)       # the unsharded (B, S, heads, d)
+    c, hp = S // world, H // world
+    mine = full[:, rank * c:(rank + 1) * c].contiguous()                           # this rank's sequence slice
+    a2a = SP.seq_all_to_all(mine, 2, 1, g)                                         # -> (B, S, heads/P, d)
+    ok_fwd = torch.equal(a2a, full[:, :, rank * hp:(rank + 1) * hp])
+    back = SP.seq_all_to_all(a2a, 1, 2, g)                                         # -> (B, S/P, heads, d)
+    ok_bwd = torch.equal(back, mine)
+    emb, pos = SP.shard_sequence(full.view(B, S, H * d), torch.arange(S).repeat(B, 1))
+    ok_shard = torch.equal(emb, mine.view(B, c, H * d)) and torch.equal(pos[0], torch.arange(rank * c, (rank + 1) * c))
+    ok_gather = torch.equal(SP.gather_sequence(emb), full.view(B, S, H * d))
+    q.put((rank, ok_fwd, ok_bwd, ok_shard, ok_gather))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ulysses_all_to_all_layout_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(all(r[1:]) for r in res), res

@@ -188,9 +188,12 @@ class Phi3Attention(nn.Module):
             q = qkv[..., : nq * hd].view(B, L, nq, hd).transpose(1, 2)
             k = qkv[..., nq * hd:(nq + nk) * hd].view(B, L, nk, hd).transpose(1, 2)
             v = qkv[..., (nq + nk) * hd:].view(B, L, nk, hd).transpose(1, 2)
-            fn = self.local_attn if self.dist_attn is None else self.dist_attn
-            ctx = fn(q, k, v, attn_mask=pm, dropout_p=0.0, is_causal=False)
-            ctx = ctx.transpose(1, 2).reshape(B, L, nq * hd).contiguous()
+            if self.dist_attn is None:
+                ctx = self.local_attn(q, k, v, attn_mask=pm, dropout_p=0.0, is_causal=False).transpose(1, 2)
+            else:   # Ulysses: (B, L/P, heads, d) in and out (LVM/transform/sdpa_transform.py:78-86)
+                ctx = self.dist_attn(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 0, attn_mask=pm,
+                                     dropout_p=0.0, is_causal=False)
+            ctx = ctx.reshape(B, L, nq * hd).contiguous()
         out = ops.linear(ctx, self.o_proj.weight, residual=residual)
         return out, None, past_key_value
 
@@ -479,8 +482,15 @@ class LVM(nn.Module):
         assert input_ids is not None, "input_ids is None"
         seq, rows, shapes = self.assemble_sequence(x, timestep, input_ids, input_img_latents, input_image_sizes,
                                                    denoise_image_sizes, time_emb_inx)
-        output = self.llm(inputs_embeds=seq, attention_mask=attention_mask, position_ids=position_ids,
-                          past_key_values=past_key_values, offload_model=offload_model)
+        from . import sequence_parallel as SP
+        if SP.sp_world() > 1:   # LVM/model.py:457-473: every rank runs its L/P slice, the last hidden state is gathered
+            seq_l, pos_l = SP.shard_sequence(seq, position_ids)
+            output = self.llm(inputs_embeds=seq_l, attention_mask=attention_mask, position_ids=pos_l,
+                              past_key_values=past_key_values, offload_model=offload_model)
+            output.last_hidden_state = SP.gather_sequence(output.last_hidden_state)
+        else:
+            output = self.llm(inputs_embeds=seq, attention_mask=attention_mask, position_ids=position_ids,
+                              past_key_values=past_key_values, offload_model=offload_model)
         latents = self.decode_frames(output.last_hidden_state, timestep, rows, shapes, out=out)
         if return_past_key_values:
             return latents, None
