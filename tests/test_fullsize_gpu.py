@@ -1,0 +1,158 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the CPU oracle cannot run these shapes
+in test time): cfg-2 geometry (256^2, C=4 + G=8 frames, CFG: B=2, L=3096, H=3072, 32 heads x 96, I=8192) with 2 decoder
+layers, and the cfg-3 stage-1 mask (B=2, L=3870).
+
+  * sampler: hipGraph replay == eager launches (bit-exact); condition-prefix reuse == recomputing every token;
+    packed (pads dropped) == unpacked layout
+  * attention: planned launch with items cut at the packed-sequence seams == the aligned 4-wave kernel (bit-exact);
+    the 8-wave kernel's ordinary items too
+  * GEMM: weight stored [N][K] (NT) == the same weight stored [K][N] read transposed (bit-exact); dW = dY^T X read
+    transposed == the same product through explicit transposes (bit-exact, same reduction order)
+  * attention backward: one fused dK/dV launch vs the reference-free identity dK(k) / dV(v) linearity in dO
+"""
+import importlib
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def mods():
+    importlib.import_module("video-gpt_amd")
+    names = ["model", "processor", "engine", "scheduler", "ops", "ops_train"]
+    return {n: importlib.import_module(f"video-gpt_amd.{n}") for n in names}
+
+
+@pytest.fixture(scope="module")
+def cfg2(mods):
+    import bench
+    M, P = mods["model"], mods["processor"]
+    cfg = bench.full_config(M, 2)
+    model = bench.build_model(M, cfg, torch.device(DEV), seed=0)
+    C, G, hw = 4, 8, (32, 32)
+    proc = P.LVMProcessor(P.SpecialTokenizer(10, 11, 12))
+    prompt = "".join(f"<img><|image_{i + 1}|></img>" if i < C else f"<|diffusion|><|image_{i + 1}|>" for i in range(C + G))
+    prompt_ = "".join(f"<|diffusion|><|image_{i + 1}|>" for i in range(G))
+    batch = proc.prompt_condition_frame_block_inference([prompt, prompt_], [[torch.zeros(3, 256, 256)] * C, []], height=256,
+                                                        width=256, use_img_cfg=True, frame_blocks=[C, G])
+    g = torch.Generator("cpu").manual_seed(7)
+    z = [torch.randn(1, 4, *hw, generator=g).to(DEV, BF) for _ in range(G)] * 2
+    cond = [torch.randn(1, 4, *hw, generator=g).to(DEV, BF) for _ in range(C)]
+    return cfg, model, batch, z, cond, hw
+
+
+def _engine(mods, cfg2, **kw):
+    cfg, model, batch, z, cond, hw = cfg2
+    sched = mods["scheduler"].LVMScheduler(num_steps=3, time_shifting_factor=1)
+    eng = mods["engine"].StaticDenoiser(model, batch["input_ids"].to(DEV), batch["position_ids"].to(DEV),
+                                        batch["attention_mask"].to(DEV), cond, batch["input_image_sizes"],
+                                        batch["denoise_image_sizes"], batch["time_emb_inx"], len(z), hw, True, 1.6, "x1",
+                                        sigma=sched.sigma, **kw)
+    eng.set_latents(torch.cat(z, dim=0))
+    return eng
+
+
+def _run(eng, use_graph):
+    st = torch.cuda.Stream(device=DEV)
+    with torch.cuda.stream(st):
+        out = eng.run(3, use_graph=use_graph).clone()
+    st.synchronize()
+    return out
+
+
+def test_sampler_graph_equals_eager_and_layouts_agree(mods, cfg2):
+    assert cfg2[2]["input_ids"].shape == (2, 3096)
+    ref = _run(_engine(mods, cfg2, reuse_condition_prefix=True), use_graph=False)
+    e_graph = _engine(mods, cfg2, reuse_condition_prefix=True)
+    assert e_graph.S == 1152 and e_graph.Ma == 4128 and e_graph.L == 5280
+    assert torch.equal(_run(e_graph, use_graph=True), ref)                      # hipGraph replay == eager, bit-exact
+    full = _run(_engine(mods, cfg2, reuse_condition_prefix=False), use_graph=False)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    # Different layouts shift the 64-key tile boundaries of the online softmax, so P is rounded to bf16 against a
+    # different running maximum: equal up to bf16 rounding noise (2 layers x 3 Euler steps), not bit for bit.
+    unpacked = _run(_engine(mods, cfg2, pack_padding=False), use_graph=False)   # reference layout: B=2 with 1032 pads
+    r_reuse, r_pack = rel(ref, full), rel(full, unpacked)
+    print(f"prefix reuse vs full recompute: {r_reuse:.2e}; packed vs unpacked: {r_pack:.2e}")
+    assert torch.isfinite(ref).all() and r_reuse < 2e-2 and r_pack < 2e-2
+
+
+def test_attention_plan_equals_aligned_kernel_on_engine_layout(mods, cfg2):
+    ops = mods["ops"]
+    eng = _engine(mods, cfg2, reuse_condition_prefix=True)
+    eng.sampler_step()
+    cfg = cfg2[0]
+    nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    qkv = eng.qkv_full[1].view(1, eng.L, -1)
+    aligned = ops.attention_qkv(qkv, eng.pm, nq, nk, hd, variant=2)[:, eng.S:]
+    assert eng.seg_live == ((0, 1152, 3216), (0, 3216, 5280))
+    planned = torch.empty_like(eng.ctx)
+    ops.attention_qkv_range(qkv, eng.pm, nq, nk, hd, eng.S, planned, segments=eng.seg_live)
+    assert torch.equal(planned, aligned)
+    pp = torch.empty_like(eng.ctx)
+    ops.attention_qkv_range(qkv, eng.pm, nq, nk, hd, eng.S, pp, segments=eng.seg_live, item_rows=256)
+    for a, e in eng.seg_live and [(s[1], s[2]) for s in eng.seg_live]:
+        full_items = a + (e - a) // 256 * 256          # the trailing 16-row item merges partial results differently
+        assert torch.equal(pp[0, a - eng.S:full_items - eng.S], aligned[0, a - eng.S:full_items - eng.S])
+    assert float((pp.float() - aligned.float()).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(4128, 9216, 3072), (4128, 3072, 8192), (7740, 3072, 3072)])
+def test_gemm_layout_invariance(mods, M, N, K):
+    ops, T = mods["ops"], mods["ops_train"]
+    g = torch.Generator("cpu").manual_seed(3)
+    x = torch.randn(M, K, generator=g).to(DEV, BF)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV, BF)
+    y = ops.linear(x, w)
+    assert torch.equal(T.linear_dx(x, w.t().contiguous()), y)                  # NT == NN on the transposed weight
+    dy = torch.randn(M, N, generator=g).to(DEV, BF)
+    dw = T.linear_dw(dy, x)                                                     # both operands read transposed
+    Mp = (M + 63) // 64 * 64
+    dyt = T.transpose_pad(dy, torch.empty(N * Mp, dtype=BF, device=DEV), Mp)
+    xt = T.transpose_pad(x, torch.empty(K * Mp, dtype=BF, device=DEV), Mp)
+    assert torch.equal(ops.linear(dyt, xt), dw)                                 # == explicit transposes + NT
+
+
+def test_attention_backward_is_linear_in_dout(mods):
+    """dQ, dK, dV are linear in dO for fixed q, k, v: bwd(a dO1 + dO2) == a bwd(dO1) + bwd(dO2) up to bf16 rounding, on
+    the cfg-3 stage-1 mask (B=2, L=3870), 4 heads."""
+    P, ops, T = mods["processor"], mods["ops"], mods["ops_train"]
+    F_, nh, hd = 8, 4, 96
+    proc = P.LVMProcessor(P.SpecialTokenizer(10, 11, 12))
+    rows = []
+    for _ in range(2):
+        prompt = "".join(f"<|diffusion|><|image_{i + 1}|><img><|image_{i + 1}|></img>" if i < F_ - 1
+                         else f"<|diffusion|><|image_{i + 1}|>" for i in range(F_))
+        rows.append(proc.process_multi_modal_prompt_training(prompt, [torch.zeros(3, 256, 256) for _ in range(F_)]))
+    mask = proc.collator.collate_stage1(rows, F_)["attention_mask"].to(DEV)
+    B, L = mask.shape[:2]
+    assert (B, L) == (2, 3870)
+    pm = ops.pack_mask(mask)
+    g = torch.Generator("cpu").manual_seed(5)
+    qkv = torch.randn(B, L, 3 * nh * hd, generator=g).to(DEV, BF)
+    out = torch.empty(B, L, nh * hd, dtype=BF, device=DEV)
+    lse = torch.empty(B, nh, L, dtype=torch.float32, device=DEV)
+    T.attention_qkv_train(qkv, pm, nh, nh, hd, out, lse)
+    d1 = torch.randn(B, L, nh * hd, generator=g).to(DEV, BF)
+    d2 = torch.randn(B, L, nh * hd, generator=g).to(DEV, BF)
+    delta = torch.empty_like(lse)
+
+    def bwd(d):
+        r = torch.empty_like(qkv)
+        T.attention_qkv_bwd(qkv, out, d, lse, delta, r, pm, nh, nh, hd)
+        return r.float()
+    lhs = bwd((2.0 * d1.float() + d2.float()).to(BF))
+    rhs = 2.0 * bwd(d1) + bwd(d2)
+    assert float((lhs - rhs).norm() / rhs.norm()) < 1e-2
+    # softmax rows sum to one: with dO = const along d for every row, dS = P o (dP - delta) vanishes -> dq = dk = 0
+    ones = torch.ones(B, L, nh * hd, dtype=BF, device=DEV)
+    vfix = qkv.clone()
+    vfix[..., 2 * nh * hd:] = 1.0                                   # V = 1 => O = 1 and dP = delta = d for dO = 1
+    T.attention_qkv_train(vfix, pm, nh, nh, hd, out, lse)
+    r = torch.empty_like(qkv)
+    T.attention_qkv_bwd(vfix, out, ones, lse, delta, r, pm, nh, nh, hd)
+    assert float(r[..., : 2 * nh * hd].float().abs().max()) < 2e-2
