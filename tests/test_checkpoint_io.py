@@ -78,3 +78,30 @@ def test_hub_names_are_refused_offline():
         M.LVM.from_pretrained("GrayShine/Video-GPT")
     with pytest.raises(FileNotFoundError):
         V.AutoencoderKL.from_pretrained("stabilityai/sdxl-vae")
+
+
+def test_checkpoint_layouts_of_the_reference_inference_script(tmp_path):
+    """model.pt, one pytorch_model.bin, or a pytorch_model.bin/ directory of shards (LVM/inference/...inference.py:48-68);
+    torch files written by THIS test (plain tensor dicts) and read back with weights_only=True."""
+    cfg = R.Phi3Cfg(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                    num_key_value_heads=2, vocab_size=32, pos_embed_max_size=192)
+    params = {k: v.contiguous() for k, v in R.make_params(cfg, seed=9).items()}
+    keys = sorted(params)
+    layouts = {}
+    for name in ("pt", "bin", "shards"):
+        d = str(tmp_path / name)
+        _write_lvm_dir(d, cfg, params)
+        os.remove(os.path.join(d, "model.safetensors"))
+        layouts[name] = d
+    torch.save(params, os.path.join(layouts["pt"], "model.pt"))
+    torch.save(params, os.path.join(layouts["bin"], "pytorch_model.bin"))
+    os.makedirs(os.path.join(layouts["shards"], "pytorch_model.bin"))
+    half = len(keys) // 2
+    torch.save({k: params[k] for k in keys[:half]}, os.path.join(layouts["shards"], "pytorch_model.bin", "shard-00001.bin"))
+    torch.save({k: params[k] for k in keys[half:]}, os.path.join(layouts["shards"], "pytorch_model.bin", "shard-00002.bin"))
+    for name, d in layouts.items():
+        sd = M.LVM.from_pretrained(d).state_dict()
+        assert all(torch.equal(sd[k], params[k]) for k in keys), name
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        M.load_checkpoint_state_dict(str(tmp_path))

@@ -268,6 +268,42 @@ def test_stage2_frame_block_layout_gradients():
     assert not bad, bad
 
 
+def test_trainer_checkpoint_resume(tmp_path):
+    """checkpoint-{step} save + auto-resume (LVM/train/train_x1_stage1_noiseinput.py:304-334,437-451): a trainer restored
+    from the checkpoint takes exactly the step the original takes next (parameters, fp32 master weights, Adam moments and
+    the bias-correction step counter all restored), and the saved model.safetensors loads through LVM.from_pretrained."""
+    cfg = R.TINY
+    p, batch, x1, x0, t, clean, x0i, ti = _stage1_case(cfg)
+    TR = importlib.import_module("video-gpt_amd.train")
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    a = TR.Stage1Trainer(SC.build_product_model(cfg, p, DEV, cls_name="LVMTraining"), lr=1e-3, weight_decay=0.1)
+    for _ in range(2):
+        a.step(dbatch, x1, x0, t, clean, x0i, ti)
+    path = a.save_checkpoint(str(tmp_path))
+    assert path.endswith("checkpoint-2")
+    a.save_checkpoint(str(tmp_path), global_step=1)          # an older one: auto-resume must pick the largest step
+    b = TR.Stage1Trainer(SC.build_product_model(cfg, p, DEV, cls_name="LVMTraining"), lr=1e-3, weight_decay=0.1)
+    assert b.auto_resume(str(tmp_path / "nothing-here")) is None
+    assert b.auto_resume(str(tmp_path)) == 2 and b.step_count == 2
+    # restored state == the saved trainer's state, bit for bit
+    for (ka, va), (kb, vb) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    for ta, tb in zip([a.master_small, a.m_small, a.v_small] + a.master_layers + a.m_layers + a.v_layers,
+                      [b.master_small, b.m_small, b.v_small] + b.master_layers + b.m_layers + b.v_layers):
+        assert torch.equal(ta, tb)
+    # ... and both take the same next step (same forward bit for bit; the small-head gradients use fp32 atomics, so the
+    # updated weights agree to rounding, not bitwise)
+    la = a.step(dbatch, x1, x0, t, clean, x0i, ti)
+    lb = b.step(dbatch, x1, x0, t, clean, x0i, ti)
+    torch.cuda.synchronize()
+    assert torch.equal(la, lb)
+    for (ka, va), (kb, vb) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert rel_l2(va.float(), vb.float()) < 1e-3, ka
+    M = importlib.import_module("video-gpt_amd.model")
+    saved = M.load_checkpoint_state_dict(path)           # the loader LVM.from_pretrained uses
+    assert set(saved) == set(a.model.state_dict())
+
+
 # ---- data-parallel step: 2 ranks on the one GPU of the test box, gloo transport (RCCL refuses two ranks on
 #      one device); the trainer code path (per-layer bucket all-reduce, 1/world folded into the clip) is the
 #      same one `bench.py --workload stage1 --gpus N` runs over RCCL ----

@@ -278,6 +278,28 @@ class Phi3Transformer(nn.Module):
         return SimpleNamespace(last_hidden_state=h, past_key_values=None, hidden_states=None, attentions=None)
 
 
+def load_checkpoint_state_dict(ckpt_dir: str) -> dict:
+    """model.pt | model.safetensors | pytorch_model.bin (one file) | pytorch_model.bin/ (directory of *.bin shards), in
+    the reference's order of preference (LVM/inference/...inference.py:48-68).  torch files are read with
+    weights_only=True: nothing from the file is executed."""
+    pt, st, bn = (os.path.join(ckpt_dir, n) for n in ("model.pt", "model.safetensors", "pytorch_model.bin"))
+    if os.path.exists(pt):
+        return torch.load(pt, map_location="cpu", weights_only=True)
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        return load_file(st)
+    if os.path.isfile(bn):
+        return torch.load(bn, map_location="cpu", weights_only=True)
+    if os.path.isdir(bn):
+        sd = {}
+        for f in sorted(os.listdir(bn)):
+            if f.endswith(".bin"):
+                sd.update(torch.load(os.path.join(bn, f), map_location="cpu", weights_only=True))
+        if sd:
+            return sd
+    raise FileNotFoundError(f"{ckpt_dir}: no model.pt, model.safetensors or pytorch_model.bin")
+
+
 # ------------------------------------------------------------------------------------------------
 # LVM
 # ------------------------------------------------------------------------------------------------
@@ -326,18 +348,13 @@ class LVM(nn.Module):
     # -- construction / checkpoints --
     @classmethod
     def from_pretrained(cls, model_name, load_llm_ckpt=True):
-        """Local checkpoint directories only (no network): config.json + model.safetensors | model.pt."""
+        """Local checkpoint directories only (no network): config.json + one of the layouts the reference's
+        inference script accepts (LVM/inference/...inference.py:48-68)."""
         if not os.path.exists(model_name):
             raise FileNotFoundError(f"{model_name}: hub download is unavailable offline; pass a local directory")
         model = cls(Phi3Config.from_pretrained(model_name))
         if load_llm_ckpt:
-            st = os.path.join(model_name, "model.safetensors")
-            if os.path.exists(st):
-                from safetensors.torch import load_file
-                ckpt = load_file(st)
-            else:
-                ckpt = torch.load(os.path.join(model_name, "model.pt"), map_location="cpu", weights_only=True)
-            model.load_state_dict(ckpt)
+            model.load_state_dict(load_checkpoint_state_dict(model_name))
         return model
 
     def initialize_weights(self):

@@ -310,6 +310,62 @@ class Stage1Trainer:
                      self.eps, self.wd, self.step_count, self.coef)
 
 
+    # ---- checkpoints (LVM/train/train_x1_stage1_noiseinput.py:304-334,437-451: accelerate's checkpoint-{step}
+    #      directories with auto-resume from the highest step).  Written with safetensors, nothing is unpickled on
+    #      load: model.safetensors holds the bf16 state_dict under the reference's keys (loadable by
+    #      LVM.from_pretrained), optimizer.safetensors the fp32 master weights and Adam moments per bucket. ----
+    def save_checkpoint(self, results_dir: str, global_step: Optional[int] = None) -> str:
+        import json
+        import os
+        from safetensors.torch import save_file
+        step = self.step_count if global_step is None else int(global_step)
+        path = os.path.join(results_dir, f"checkpoint-{step}")
+        os.makedirs(path, exist_ok=True)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()},
+                  os.path.join(path, "model.safetensors"))
+        opt = {"master_small": self.master_small, "m_small": self.m_small, "v_small": self.v_small}
+        for i in range(len(self.master_layers)):
+            opt[f"master.{i}"], opt[f"m.{i}"], opt[f"v.{i}"] = self.master_layers[i], self.m_layers[i], self.v_layers[i]
+        save_file({k: v.detach().cpu().contiguous() for k, v in opt.items()}, os.path.join(path, "optimizer.safetensors"))
+        with open(os.path.join(path, "trainer_state.json"), "w") as f:
+            json.dump({"step_count": self.step_count, "global_step": step, "lr": self.lr, "weight_decay": self.wd,
+                       "betas": list(self.betas), "eps": self.eps, "small_names": self.small_names}, f)
+        return path
+
+    def load_checkpoint(self, path: str) -> int:
+        """Restores parameters, fp32 master weights, Adam moments and the step counter; returns the global step."""
+        import json
+        import os
+        from safetensors.torch import load_file
+        with open(os.path.join(path, "trainer_state.json")) as f:
+            st = json.load(f)
+        if st["small_names"] != self.small_names:
+            raise VgptError("checkpoint was written for a different parameter layout")
+        opt = load_file(os.path.join(path, "optimizer.safetensors"))
+        pairs = [(self.master_small, "master_small"), (self.m_small, "m_small"), (self.v_small, "v_small")]
+        for i in range(len(self.master_layers)):
+            pairs += [(self.master_layers[i], f"master.{i}"), (self.m_layers[i], f"m.{i}"), (self.v_layers[i], f"v.{i}")]
+        for dst, key in pairs:
+            if opt[key].shape != dst.shape:
+                raise VgptError(f"checkpoint tensor {key} has shape {tuple(opt[key].shape)}, expected {tuple(dst.shape)}")
+            dst.copy_(opt[key])
+        model_sd = load_file(os.path.join(path, "model.safetensors"))
+        with torch.no_grad():     # parameters are views of the flat bf16 buffers: copy in place, keep the views
+            for k, p_ in self.model.state_dict().items():
+                p_.copy_(model_sd[k])
+        self.step_count = int(st["step_count"])
+        return int(st["global_step"])
+
+    def auto_resume(self, results_dir: str) -> Optional[int]:
+        """Load the checkpoint-{N} with the largest N under results_dir, if any (train...stage1.py:304-315)."""
+        import glob
+        import os
+        found = [d for d in glob.glob(os.path.join(results_dir, "checkpoint-*")) if d.rsplit("-", 1)[-1].isdigit()]
+        if not found:
+            return None
+        return self.load_checkpoint(max(found, key=lambda d: int(d.rsplit("-", 1)[-1])))
+
+
 def batch_ntok(sizes) -> int:
     ns = {e - s for v in sizes.values() for s, e in v}
     if len(ns) != 1:
