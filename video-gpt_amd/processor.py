@@ -68,33 +68,30 @@ def plan_frame_block_training(frame_blocks: Sequence[int]):
     return kinds, pos
 
 
-def block_mask(kinds, bl: int, pad: int) -> np.ndarray:
-    """(L, L) uint8 visibility of one row of the batch from its block plan (closed-form rule)."""
+def block_mask(kinds, bl: int, pad: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+    """(L, L) uint8 visibility of one row of the batch from its block plan, written block by block (a few slice
+    assignments per pair of blocks instead of element-wise rules over L x L):
+      clean key block at s:  `<img>` (s) is seen by rows >= s, its slots by rows >= s+1, `</img>` by rows >= s+bl-1;
+      noisy key block at s:  only by the noisy blocks of the same clip -- `<|diffusion|>` (s) by all of their rows, the
+                             time slot (s+1) by rows with offset >= 1, the image slots by rows with offset >= 2;
+      pad rows see everything."""
     n = len(kinds) * bl
     L = n + pad
-    kind = np.zeros(L, dtype=np.int8)
-    clip = np.full(L, -1, dtype=np.int32)
-    off = np.zeros(L, dtype=np.int32)
-    thr = np.zeros(L, dtype=np.int64)
-    idx = np.arange(L)
-    for i, (kd, cl) in enumerate(kinds):
-        s = pad + i * bl
-        kind[s:s + bl] = kd
-        clip[s:s + bl] = cl
-        off[s:s + bl] = np.arange(bl)
+    m = np.zeros((L, L), dtype=np.uint8) if out is None else out    # `out`: a zero-filled (L, L) uint8 view
+    starts = [pad + i * bl for i in range(len(kinds))]
+    for (kd, cl), s in zip(kinds, starts):
         if kd == CLEAN:
-            thr[s:s + bl] = s + 1
-            thr[s] = s
-            thr[s + bl - 1] = s + bl - 1
-    q_is_noisy = (kind == NOISY)[:, None]
-    k_kind = kind[None, :]
-    vis_clean = (k_kind == CLEAN) & (idx[:, None] >= thr[None, :])
-    k_off, q_off = off[None, :], off[:, None]
-    same_clip = q_is_noisy & (k_kind == NOISY) & (clip[:, None] == clip[None, :])
-    vis_noisy = same_clip & ((k_off == 0) | ((k_off == 1) & (q_off >= 1)) | ((k_off >= 2) & (q_off >= 2)))
-    m = vis_clean | vis_noisy
-    m[:pad, :] = True
-    return m.astype(np.uint8)
+            m[s:, s] = 1
+            m[s + 1:, s + 1:s + bl - 1] = 1
+            m[s + bl - 1:, s + bl - 1] = 1
+        elif kd == NOISY:
+            for (qd, qc), sq in zip(kinds, starts):
+                if qd == NOISY and qc == cl:
+                    m[sq:sq + bl, s] = 1
+                    m[sq + 1:sq + bl, s + 1] = 1
+                    m[sq + 2:sq + bl, s + 2:s + bl] = 1
+    m[:pad, :] = 1
+    return m
 
 
 # ------------------------------------------------------------------------------------------------
@@ -170,14 +167,14 @@ class LVMCollator:
     @staticmethod
     def _masks(attention_mask, block_ls, plans):
         seq_len = attention_mask.size(-1)
-        out = np.empty((attention_mask.size(0), seq_len, seq_len), dtype=np.uint8)
+        out = np.zeros((attention_mask.size(0), seq_len, seq_len), dtype=np.uint8)   # written in place, 0/1 bytes
         for i in range(attention_mask.size(0)):
             valid = int(attention_mask[i].sum())
             kinds = plans(i, valid // block_ls[i])
             if len(kinds) * block_ls[i] != valid:
                 raise AssertionError("block plan does not cover the valid tokens")
-            out[i] = block_mask(kinds, block_ls[i], seq_len - valid)
-        return torch.from_numpy(out).to(torch.bool)
+            block_mask(kinds, block_ls[i], seq_len - valid, out=out[i])
+        return torch.from_numpy(out.view(np.bool_))
 
     def create_mask_frame_block_inference(self, attention_mask, block_ls, frame_blocks):
         return self._masks(attention_mask, block_ls, lambda i, n: plan_inference(frame_blocks[i])[0])
