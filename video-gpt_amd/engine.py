@@ -298,8 +298,13 @@ class StaticDenoiser:
 
     def run(self, num_steps: Optional[int] = None, use_graph: bool = True):
         n = self.num_steps if num_steps is None else num_steps
-        if use_graph and self.graph is None:
-            self.capture()
+        if use_graph and self.graph is None and n > 0:
+            # the first step runs eagerly (kernels set their launch attributes on first use, which a capture cannot
+            # record) and counts as a real step; the capture that follows records without executing
+            self.sampler_step()
+            torch.cuda.current_stream().synchronize()
+            self.graph = ops.HipGraph().capture(self.sampler_step)
+            n -= 1
         for _ in range(n):
             if use_graph:
                 self.graph.replay()
