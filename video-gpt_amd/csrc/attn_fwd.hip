@@ -7,15 +7,19 @@
 // and all-visible tiles never read mask bits.
 //
 // Structure:
-//   - block = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows.
-//   - K/V tiles of 64 keys are staged through registers into double-buffered LDS, the next
-//     active tile's global loads are in flight while the current tile is computed.
-//   - S^T = K Q^T with mfma_f32_32x32x16_bf16 (keys on rows): each lane then holds 32 scores of
-//     ONE query row, so row max / row sum are 31 in-register ops + one cross-half shuffle, and
-//     the exponentiated accumulator registers are, unchanged, the B operand of O^T = V^T P^T.
-//   - V^T fragments come from ds_read_b64_tr_b16 (hardware transposed read) on a [key][d] image
-//     whose row stride keeps the four 64-byte windows of a half-wave on disjoint banks.
-//   - K rows are padded by 16 B so the ds_read_b128 16-lane groups are conflict-free.
+//   - workgroup = 4 waves = up to 128 query rows of one (batch, head); each wave owns 32 query rows; two
+//     workgroups per CU.  The rows come either from an aligned 128-row q block or from a PLAN item (arbitrary row
+//     range, vgpt_attn_fwd_plan), dispatched longest first with every XCD owning n_heads/8 heads.
+//   - the key tiles that are visible to the item are compacted ONCE into an LDS list; per tile the K/V images of 64
+//     keys (and the mask words of mixed tiles) arrive by LDS-DMA issued from inline asm into a double buffer, one
+//     tile ahead; completion is s_waitcnt vmcnt(0) + a raw s_barrier at the top of the tile, so the loop contains no
+//     compiler-visible memory traffic whose wait would drain the prefetch (head dims 64 / 128 stage through registers).
+//   - S^T = K Q^T with mfma_f32_32x32x16_bf16 (keys on rows): each lane then holds 32 scores of ONE query row, so
+//     row max / row sum are in-register ops + one v_permlane32_swap, and the exponentiated accumulator registers
+//     are, unchanged, the B operand of O^T = V^T P^T.
+//   - V^T fragments come from ds_read_b64_tr_b16 (hardware transposed read) on a [key][d] image whose row stride
+//     keeps the four 64-byte windows of a half-wave on disjoint banks; the K image is XOR-swizzled on the DMA source
+//     address (chunk ^= (key>>2)&3) so the ds_read_b128 16-lane groups are conflict-free without padding.
 #include "common.h"
 
 namespace {

@@ -5,18 +5,21 @@
 // Phi3MLP.forward (transformers==4.47.1): down_proj(up * act(gate)), [gate|up] = gate_up_proj(x).
 //
 // Structure (gfx950):
-//   - 128(m) x 128(n) x 64(k) tile, 256 threads = 4 waves in a 2(n) x 2(m) grid, each wave
-//     64 x 64 = 4 x 4 MFMA 16x16x32 sub-tiles (64 accumulator registers).
-//   - A and W tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip),
-//     double-buffered; one barrier per k-tile, the next tile's DMA is issued before the
-//     current tile's MFMAs.
-//   - LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with (row & 7)
-//     on the SOURCE address (the LDS-DMA destination is lane-linear), and the same XOR is
-//     applied on the ds_read_b128 side: conflict-free for the 16-lane b128 groups.
-//   - operands are swapped (W is the MFMA "A" operand) so each lane ends up with 4
-//     consecutive n of one m: 8-byte bf16 stores.
-//   - 1-D grid with an XCD-aware, grouped tile order so blocks that share an XCD's L2 work
-//     on neighbouring tiles.
+//   - 256(m) x 256(n) x 64(k) tile, 512 threads = 8 waves in a 2(m) x 4(n) grid, wave tile 128 x 64 = 8 x 4 MFMA
+//     16x16x32 sub-tiles (128 accumulator registers), one workgroup per CU; a 128 x 128 / 4-wave configuration with a
+//     plain double-buffered loop serves small grids and the row remainder of a launch whose last round of 256-tiles
+//     would be badly filled (launch<>()).
+//   - A and W tiles go L2 -> LDS with global_load_lds_dwordx4 issued from inline asm (no VGPR round trip, no
+//     compiler-inserted drain), double-buffered; the 256-tile loop is software-pipelined in 4 phases of 16 MFMAs with
+//     the fragments of phase p+1 read under phase p's MFMAs, one barrier per k-tile, next tile's DMA in two halves.
+//   - LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with (row & 7) on the SOURCE address
+//     (the LDS-DMA destination is lane-linear), and the same XOR is applied on the ds_read_b128 side: conflict-free
+//     for the 16-lane b128 groups.
+//   - operands whose reduction index is their ROW index (the backward's dX = dY W, dW = dY^T X) are staged in their
+//     natural layout and read with ds_read_b64_tr_b16 (template flags ATR / WTR below).
+//   - operands are swapped (W is the MFMA "A" operand) so each lane ends up with 4 consecutive n of one m: 8-byte
+//     bf16 stores; fused residual / bias / act(gate)*up epilogues.
+//   - 1-D grid with an XCD-aware, grouped tile order so blocks that share an XCD's L2 work on neighbouring tiles.
 #include <type_traits>
 
 #include "common.h"
