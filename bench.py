@@ -107,6 +107,7 @@ def bench_pipeline(args, rank, world, device, M, P, D):
     cfg = full_config(M, args.layers)
     model = build_model(M, cfg, device, seed=0)
     pipe = PL.LVMPipeline(synthetic_vae(device), model, P.LVMProcessor(P.SpecialTokenizer(10, 11, 12)), device=device)
+    pipe.vae.conv_precision = args.vae_precision
     g = torch.Generator("cpu").manual_seed(7 + rank)
     frames = [torch.rand(3, 256, 256, generator=g) * 2 - 1 for _ in range(4)]
     kw = dict(input_images=frames, height=256, width=256, num_inference_steps=args.steps, use_img_guidance=True,
@@ -125,7 +126,7 @@ def bench_pipeline(args, rank, world, device, M, P, D):
                           "steps": args.rounds, "warmup": 1, "ms_per_step": round(elapsed / args.rounds * 1e3, 1),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                           "config": {"workload": f"LVMPipeline next-clip rollout: {args.rounds} round(s) x 8 frames, {args.steps} Euler steps, "
-                                                 "C=4 condition frames on round 0 then a 16-frame window, fp32 VAE, bf16 denoiser",
+                                                 f"C=4 condition frames on round 0 then a 16-frame window, fp32 VAE ({args.vae_precision} convolutions), bf16 denoiser",
                                      "frames_returned": len(out[0]), "generated_frames_per_s": round(world * n_gen / elapsed, 2)},
                           "roofline": None}), flush=True)
     if world > 1:
@@ -151,6 +152,7 @@ def bench_vae(args, rank, world, device, D):
             if ("norm" in n_) and n_.endswith("weight"):
                 p_.copy_(1 + 0.1 * torch.randn(p_.shape, generator=g))
     vae = vae.to(device, torch.float32).eval()
+    vae.conv_precision = args.vae_precision
     nfr = 8
     z = torch.randn(nfr, 4, 32, 32, generator=g).to(device)
     x = (torch.rand(nfr, 3, 256, 256, generator=g) * 2 - 1).to(device)
@@ -169,7 +171,7 @@ def bench_vae(args, rank, world, device, D):
                      "hbm_ideal_fusion": {"achieved_gbs": round(gb / per_frame, 1), "peak": 8000.0, "frac": round(gb / per_frame / 8000.0, 4)}}
     if rank == 0:
         d = res["decode"]
-        print(json.dumps({"metric": "VAE decode frames/sec (256^2, sdxl-vae, fp32)", "value": d["frames_per_s"], "unit": "frames/s",
+        print(json.dumps({"metric": f"VAE decode frames/sec (256^2, sdxl-vae, fp32 tensors, {args.vae_precision} convolutions)", "value": d["frames_per_s"], "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(d["ms_per_frame"] * nfr, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"VAE decode+uint8 of {nfr} 256^2 frames per step (also encode)", "detail": res},
@@ -257,6 +259,8 @@ def main():
                     help="skip the short stage-1 data-parallel training measurement appended to the default line")
     ap.add_argument("--no-prefix-reuse", action="store_true",
                     help="recompute the condition frames at every step exactly as the reference does")
+    ap.add_argument("--vae-precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="vae / pipeline workloads: arithmetic of the 3x3 convolutions (video-gpt_amd/vae.py)")
     ap.add_argument("--breakdown", action="store_true", help="add per-operator HIP-event times of one eager denoise step")
     ap.add_argument("--rounds", type=int, default=1, help="pipeline workload: chained next-clip rounds (cfg-5 uses 8)")
     ap.add_argument("--workload", choices=["infer", "stage1", "stage4", "vae", "pipeline"], default="infer",

@@ -95,10 +95,13 @@ def _product_vae(cfg, p):
     return vae.to(DEV, torch.float32).eval()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("cfg,hw", [(VR.TINY_VAE, (16, 24)), (VR.VaeCfg(), (64, 64))])
-def test_vae_encode_decode_match_oracle(cfg, hw):
+def test_vae_encode_decode_match_oracle(cfg, hw, precision):
+    """Same tolerances for both convolution arithmetics: exact fp32 MFMA and split-bf16 ("bf16x3") on the bf16 MFMA."""
     p = VR.make_vae_params(cfg, seed=1)
     vae = _product_vae(cfg, p)
+    vae.conv_precision = precision
     f = 2 ** (len(cfg.block_out_channels) - 1)
     x = torch.randn(2, 3, *hw, generator=g(20)).clamp(-1, 1)
     noise = torch.randn(2, 4, hw[0] // f, hw[1] // f, generator=g(21))
@@ -121,3 +124,31 @@ def test_vae_refuses_cpu():
     V = importlib.import_module("video-gpt_amd.vae")
     with pytest.raises(Exception):
         V.AutoencoderKL(block_out_channels=(32, 64), layers_per_block=1, norm_num_groups=8).decode(torch.zeros(1, 4, 4, 4))
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,up,gn", [(2, 32, 64, 8, 40, False, False), (1, 128, 96, 20, 33, True, True),
+                                                 (1, 4, 70, 7, 9, False, False), (1, 96, 64, 16, 32, False, True)])
+def test_conv3x3_split_bf16(ops, N, Cin, Cout, H, W, up, gn):
+    """bf16x3 convolution (split operands on the bf16 MFMA) against the fp64 convolution of the same fp32 values:
+    error ~1e-5, far inside the 1e-3 of TF32 arithmetic (what cuDNN gives the reference by default)."""
+    g_ = torch.Generator("cpu").manual_seed(41)
+    x = torch.randn(N, Cin, H, W, generator=g_)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g_) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g_)
+    xin = x
+    gn_arg = None
+    if gn:
+        groups = 32
+        gamma, beta = 1 + 0.1 * torch.randn(Cin, generator=g_), 0.1 * torch.randn(Cin, generator=g_)
+        st = ops.groupnorm_stats(x.to(DEV), groups, 1e-6)
+        gn_arg = (st, gamma.to(DEV), beta.to(DEV), groups, 1)
+        xin = torch.nn.functional.silu(torch.nn.functional.group_norm(x.double(), groups, gamma.double(), beta.double(), 1e-6))
+    if up:
+        xin = torch.nn.functional.interpolate(xin.double(), scale_factor=2.0, mode="nearest")
+    ref = torch.nn.functional.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    resid = torch.randn(ref.shape, generator=g_)
+    packed = ops.conv_pack_bx3(w.to(DEV))
+    out = ops.conv2d_bx3(x.to(DEV), packed, b.to(DEV), resid=resid.to(DEV), gn=gn_arg, upsample=up)
+    err = rel_l2(out, ref + resid.double())
+    exact = ops.conv2d(x.to(DEV), w.to(DEV), b.to(DEV), resid=resid.to(DEV), gn=gn_arg, upsample=up)
+    assert err < 3e-5 and rel_l2(out, exact) < 3e-5, err

@@ -146,6 +146,165 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution on the bf16 matrix cores at fp32-class accuracy ("bf16x3").
+// Every fp32 operand is split x = hi + lo (hi = bf16(x), lo = bf16(x - hi)); the product keeps the three leading
+// terms hi*hi + hi*lo + lo*hi in fp32 accumulators (the dropped lo*lo term is 2^-16 relative), i.e. ~16 mantissa
+// bits against the 10 of the TF32 convolutions torch/cuDNN runs by default on the reference's hardware
+// (torch.backends.cudnn.allow_tf32).  Three v_mfma_f32_16x16x32_bf16 (16 cycles each) replace eight
+// v_mfma_f32_16x16x4_f32 (32 cycles each) per 32 reduction elements.
+//
+// K order inside a chunk of 32 input channels: k = tap * 32 + channel, so one MFMA k-step is ONE tap and a lane's 8
+// consecutive k are 8 consecutive channels: with the patch stored [py][px][channel] and the (pre-split, pre-ordered)
+// weights stored [co][tap][channel], both fragments are single ds_read_b128 per hi / lo plane.  Pixel rows are 96 B
+// and weight rows 608 B apart (24 mod 64 dwords): the 16-lane b128 groups read conflict-free.
+// Same tile (64 output channels x 4 x 32 pixels, 4 waves), same GroupNorm(+SiLU) / upsample prologue and
+// bias + residual epilogue as conv_kernel.
+constexpr int BX_CK = 32, BX_PH = TH + 2, BX_PW = TW + 2;
+constexpr int BX_PSTRIDE = 96;                       // bytes per pixel in one patch plane (64 used)
+constexpr int BX_WROW = (9 * BX_CK + 16) * 2;         // bytes per output channel in one weight plane (576 used)
+constexpr int BX_P_BYTES = BX_PH * BX_PW * BX_PSTRIDE, BX_W_BYTES = TCO * BX_WROW;
+constexpr int BX_LDS = 2 * (BX_P_BYTES + BX_W_BYTES);
+
+struct ConvBxArgs {
+    const float* x; const bf16* w_hi; const bf16* w_lo; const float* bias; const float* resid;
+    const float* gn_stats; const float* gn_gamma; const float* gn_beta;
+    float* y;
+    int N, Cin, Cin_pad, Hin, Win, Cout, Hout, Wout;
+    int upsample, gn_groups, gn_silu;
+    int tiles_x, tiles_y, tiles_co;
+};
+
+__global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sWh = smem;
+    char* sWl = sWh + BX_W_BYTES;
+    char* sPh = sWl + BX_W_BYTES;
+    char* sPl = sPh + BX_P_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    const int tco = bid % a.tiles_co;
+    const int n = bid / a.tiles_co;
+    const int co0 = tco * TCO, oy0 = ty * TH, ox0 = tx * TW;
+    const int Hv = a.Hin << a.upsample, Wv = a.Win << a.upsample;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const float* xn = a.x + (int64_t)n * a.Cin * a.Hin * a.Win;
+    const int cpg = a.gn_groups ? a.Cin / a.gn_groups : 1;
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kq = lane >> 4, l16 = lane & 15;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += BX_CK) {
+        __syncthreads();
+        // ---- weights: (co, tap) rows of 32 channels = 64 contiguous bytes per plane, copied as 4 x 16 B ----
+        for (int i = tid; i < TCO * 9 * 4; i += 256) {
+            const int q = i & 3, t = (i >> 2) % 9, co = i / 36;
+            bf16x8 vh = {}, vl = {};
+            if (co0 + co < a.Cout) {
+                const int64_t g = ((int64_t)(co0 + co) * 9 + t) * a.Cin_pad + c0 + q * 8;
+                vh = *reinterpret_cast<const bf16x8*>(a.w_hi + g);
+                vl = *reinterpret_cast<const bf16x8*>(a.w_lo + g);
+            }
+            const int o = co * BX_WROW + (t * BX_CK + q * 8) * 2;
+            *reinterpret_cast<bf16x8*>(sWh + o) = vh;
+            *reinterpret_cast<bf16x8*>(sWl + o) = vl;
+        }
+        // ---- input patch: thread -> (pixel, group of 8 channels); optional upsample / GroupNorm(+SiLU); split ----
+        for (int i = tid; i < BX_PH * BX_PW * 4; i += 256) {
+            const int pix = i % (BX_PH * BX_PW), q = i / (BX_PH * BX_PW);   // consecutive lanes -> consecutive pixels
+            const int py = pix / BX_PW, px = pix % BX_PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool inside = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+            bf16x8 vh, vl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ci = c0 + q * 8 + j;
+                float v = 0.f;
+                if (inside && ci < a.Cin) {
+                    v = xn[((int64_t)ci * a.Hin + (iy >> a.upsample)) * a.Win + (ix >> a.upsample)];
+                    if (a.gn_groups) {
+                        const float* st = a.gn_stats + ((int64_t)n * a.gn_groups + ci / cpg) * 2;
+                        v = (v - st[0]) * st[1] * a.gn_gamma[ci] + a.gn_beta[ci];
+                        if (a.gn_silu) v = v / (1.0f + expf(-v));
+                    }
+                }
+                const bf16 hi = f2bf(v);
+                vh[j] = hi;
+                vl[j] = f2bf(v - bf2f(hi));
+            }
+            const int o = pix * BX_PSTRIDE + q * 16;
+            *reinterpret_cast<bf16x8*>(sPh + o) = vh;
+            *reinterpret_cast<bf16x8*>(sPl + o) = vl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3, dx = t % 3;
+            bf16x8 wh[4], wl[4], ph[2], pl[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = (i * 16 + l16) * BX_WROW + (t * BX_CK + kq * 8) * 2;
+                wh[i] = *reinterpret_cast<const bf16x8*>(sWh + o);
+                wl[i] = *reinterpret_cast<const bf16x8*>(sWl + o);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = ((wave + dy) * BX_PW + j * 16 + l16 + dx) * BX_PSTRIDE + kq * 16;
+                ph[j] = *reinterpret_cast<const bf16x8*>(sPh + o);
+                pl[j] = *reinterpret_cast<const bf16x8*>(sPl + o);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ph[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], pl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], ph[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue: lane holds pixel l16 of sub-tile j, channels (kq*4 + r) of sub-tile i ----
+    const int oy = oy0 + wave;
+    if (oy < a.Hout) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ox = ox0 + j * 16 + l16;
+            if (ox >= a.Wout) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + i * 16 + kq * 4 + r;
+                    if (co >= a.Cout) continue;
+                    const int64_t o = (((int64_t)n * a.Cout + co) * a.Hout + oy) * a.Wout + ox;
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[co];
+                    if (a.resid) v += a.resid[o];
+                    a.y[o] = v;
+                }
+        }
+    }
+}
+
+// w (Cout, Cin, 3, 3) fp32 -> hi / lo bf16 planes laid out [Cout][tap][Cin_pad] (Cin_pad = Cin rounded up to 32, zeros)
+__global__ void conv_pack_bx3_kernel(const float* __restrict__ w, bf16* __restrict__ hi, bf16* __restrict__ lo, int Cout,
+                                     int Cin, int Cin_pad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * 9 * Cin_pad) return;
+    const int ci = (int)(i % Cin_pad), t = (int)((i / Cin_pad) % 9), co = (int)(i / ((int64_t)9 * Cin_pad));
+    const float v = ci < Cin ? w[((int64_t)co * Cin + ci) * 9 + t] : 0.f;
+    const bf16 h = f2bf(v);
+    hi[i] = h;
+    lo[i] = f2bf(v - bf2f(h));
+}
+
 // ---- GroupNorm statistics: one block per (n, group), two passes (mean, then centred variance) ----
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
                                                        int64_t group_elems, float eps) {
@@ -291,6 +450,50 @@ VGPT_EXPORT int vgpt_conv2d_fwd(const float* x, const float* w, const float* bia
     if (ksize == 1) return launch_conv<1, 1>(a, s);
     if (stride == 1) return launch_conv<3, 1>(a, s);
     return launch_conv<3, 2>(a, s);
+}
+
+VGPT_EXPORT int vgpt_conv_pack_weights_bx3(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, void* stream) {
+    VGPT_REQUIRE(w && w_hi && w_lo && Cout > 0 && Cin > 0, VGPT_ERR_INVALID, "vgpt_conv_pack_weights_bx3: bad argument");
+    const int Cin_pad = (Cin + 31) / 32 * 32;
+    const int64_t n = (int64_t)Cout * 9 * Cin_pad;
+    hipLaunchKernelGGL(conv_pack_bx3_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16*)w_hi,
+                       (bf16*)w_lo, Cout, Cin, Cin_pad);
+    VGPT_CHECK_LAUNCH("vgpt_conv_pack_weights_bx3");
+    return VGPT_OK;
+}
+
+VGPT_EXPORT int vgpt_conv2d_bx3_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* resid,
+                                    const float* gn_stats, const float* gn_gamma, const float* gn_beta, float* y, int N,
+                                    int Cin, int Hin, int Win, int Cout, int upsample, int gn_groups, int gn_silu,
+                                    void* stream) {
+    VGPT_REQUIRE(x && w_hi && w_lo && y, VGPT_ERR_INVALID, "vgpt_conv2d_bx3_fwd: null pointer");
+    VGPT_REQUIRE(N >= 0 && Cin > 0 && Hin > 0 && Win > 0 && Cout > 0, VGPT_ERR_INVALID, "vgpt_conv2d_bx3_fwd: bad shape");
+    VGPT_REQUIRE(gn_groups == 0 || (gn_stats && gn_gamma && gn_beta && Cin % gn_groups == 0), VGPT_ERR_INVALID,
+                 "vgpt_conv2d_bx3_fwd: GroupNorm prologue needs stats/gamma/beta and Cin %% groups == 0");
+    VGPT_REQUIRE((((uintptr_t)w_hi | (uintptr_t)w_lo) & 15) == 0, VGPT_ERR_UNSUPPORTED,
+                 "vgpt_conv2d_bx3_fwd: packed weights must be 16-byte aligned");
+    if (N == 0) return VGPT_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_bx3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS);
+        if (e != hipSuccess) {
+            vgpt_set_error("vgpt_conv2d_bx3_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return VGPT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    ConvBxArgs a;
+    a.x = x; a.w_hi = (const bf16*)w_hi; a.w_lo = (const bf16*)w_lo; a.bias = bias; a.resid = resid;
+    a.gn_stats = gn_stats; a.gn_gamma = gn_gamma; a.gn_beta = gn_beta; a.y = y;
+    a.N = N; a.Cin = Cin; a.Cin_pad = (Cin + 31) / 32 * 32; a.Hin = Hin; a.Win = Win; a.Cout = Cout;
+    a.upsample = upsample ? 1 : 0;
+    a.Hout = Hin << a.upsample; a.Wout = Win << a.upsample;
+    a.gn_groups = gn_groups; a.gn_silu = gn_silu;
+    a.tiles_x = (int)cdiv(a.Wout, TW); a.tiles_y = (int)cdiv(a.Hout, TH); a.tiles_co = (int)cdiv(Cout, TCO);
+    const int64_t blocks = (int64_t)a.tiles_x * a.tiles_y * a.tiles_co * N;
+    hipLaunchKernelGGL(conv_bx3_kernel, dim3((unsigned)blocks), dim3(256), BX_LDS, (hipStream_t)stream, a);
+    VGPT_CHECK_LAUNCH("vgpt_conv2d_bx3_fwd");
+    return VGPT_OK;
 }
 
 VGPT_EXPORT int vgpt_col_softmax(float* s, int N, int keys, int queries, float scale, void* stream) {

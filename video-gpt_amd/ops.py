@@ -505,6 +505,44 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+def conv_pack_bx3(weight: torch.Tensor):
+    """(Cout, Cin, 3, 3) fp32 -> (hi, lo) bf16 planes (Cout, 9, Cin_pad) for conv2d_bx3 (include/vgpt.h)."""
+    _chk(weight, F32, "conv_pack_bx3.weight")
+    Cout, Cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise VgptError("conv_pack_bx3: 3x3 kernels only")
+    cp = (Cin + 31) // 32 * 32
+    hi = torch.empty(Cout, 9, cp, dtype=BF16, device=weight.device)
+    lo = torch.empty_like(hi)
+    call("vgpt_conv_pack_weights_bx3", weight.data_ptr(), hi.data_ptr(), lo.data_ptr(), Cout, Cin, _stream())
+    return hi, lo
+
+
+def conv2d_bx3(x: torch.Tensor, packed, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, gn=None,
+               upsample: bool = False, out: Optional[torch.Tensor] = None):
+    """3x3 stride-1 convolution with split-bf16 operands on the bf16 MFMA (fp32 in / out); packed = conv_pack_bx3(w)."""
+    _chk(x, F32, "conv2d_bx3.x")
+    hi, lo = packed
+    N, Cin, Hin, Win = x.shape
+    cout = hi.shape[0]
+    if hi.shape[2] != (Cin + 31) // 32 * 32:
+        raise VgptError("conv2d_bx3: packed weights do not match the input channels")
+    Ho, Wo = (Hin * 2, Win * 2) if upsample else (Hin, Win)
+    if out is None:
+        out = torch.empty(N, cout, Ho, Wo, dtype=F32, device=x.device)
+    if resid is not None:
+        _chk(resid, F32, "conv2d_bx3.resid")
+        if resid.numel() != out.numel():
+            raise VgptError("conv2d_bx3: residual shape mismatch")
+    stats = gamma = beta = None
+    groups = silu = 0
+    if gn is not None:
+        stats, gamma, beta, groups, silu = gn
+    call("vgpt_conv2d_bx3_fwd", x.data_ptr(), hi.data_ptr(), lo.data_ptr(), _ptr(bias), _ptr(resid), _ptr(stats), _ptr(gamma),
+         _ptr(beta), out.data_ptr(), N, Cin, Hin, Win, cout, int(upsample), int(groups), int(silu), _stream())
+    return out
+
+
 def col_softmax(s: torch.Tensor, scale: float):
     _chk(s, F32, "col_softmax.s")
     N, keys, queries = s.shape

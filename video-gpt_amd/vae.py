@@ -33,6 +33,20 @@ class _Norm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(c))
 
 
+def _conv3(mod, x, prec: str, **kw):
+    """3x3 stride-1 convolution of an nn.Conv2d: "fp32" = exact fp32 MFMA, "bf16x3" = split-bf16 operands on the bf16
+    MFMA (include/vgpt.h, vgpt_conv2d_bx3_fwd); the split weights are cached on the module until the weight changes."""
+    if prec == "bf16x3":
+        key = (mod.weight.data_ptr(), mod.weight._version)
+        if getattr(mod, "_bx3_key", None) != key:
+            mod._bx3 = ops.conv_pack_bx3(mod.weight.detach().contiguous())
+            mod._bx3_key = key
+        return ops.conv2d_bx3(x, mod._bx3, mod.bias, **kw)
+    if prec != "fp32":
+        raise VgptError(f"unknown conv precision {prec!r} (fp32 | bf16x3)")
+    return ops.conv2d(x, mod.weight, mod.bias, **kw)
+
+
 class _Resnet(nn.Module):
     def __init__(self, ci, co):
         super().__init__()
@@ -41,15 +55,14 @@ class _Resnet(nn.Module):
         if ci != co:
             self.conv_shortcut = nn.Conv2d(ci, co, 1)
 
-    def run(self, x, groups, eps, upsample_in=False):
+    def run(self, x, groups, eps, prec="fp32"):
         st = ops.groupnorm_stats(x, groups, eps)
-        h = ops.conv2d(x, self.conv1.weight, self.conv1.bias, gn=(st, self.norm1.weight, self.norm1.bias, groups, 1))
+        h = _conv3(self.conv1, x, prec, gn=(st, self.norm1.weight, self.norm1.bias, groups, 1))
         skip = x
         if hasattr(self, "conv_shortcut"):
             skip = ops.conv2d(x, self.conv_shortcut.weight, self.conv_shortcut.bias, ksize=1)
         st2 = ops.groupnorm_stats(h, groups, eps)
-        return ops.conv2d(h, self.conv2.weight, self.conv2.bias, resid=skip,
-                          gn=(st2, self.norm2.weight, self.norm2.bias, groups, 1))
+        return _conv3(self.conv2, h, prec, resid=skip, gn=(st2, self.norm2.weight, self.norm2.bias, groups, 1))
 
 
 class _Attention(nn.Module):
@@ -82,10 +95,10 @@ class _Mid(nn.Module):
         self.resnets = nn.ModuleList([_Resnet(c, c), _Resnet(c, c)])
         self.attentions = nn.ModuleList([_Attention(c)])
 
-    def run(self, x, groups, eps):
-        x = self.resnets[0].run(x, groups, eps)
+    def run(self, x, groups, eps, prec="fp32"):
+        x = self.resnets[0].run(x, groups, eps, prec)
         x = self.attentions[0].run(x, groups, eps)
-        return self.resnets[1].run(x, groups, eps)
+        return self.resnets[1].run(x, groups, eps, prec)
 
 
 class _Sampler(nn.Module):
@@ -167,6 +180,9 @@ class AutoencoderKL(nn.Module):
         self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
         self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
         self.eps = 1e-6
+        # arithmetic of the 3x3 stride-1 convolutions (97 % of the FLOPs): "fp32" = exact fp32 MFMA; "bf16x3" =
+        # split-bf16 operands on the bf16 MFMA, ~16 mantissa bits (the reference's cuDNN default is TF32, 10 bits)
+        self.conv_precision = "fp32"
 
     @classmethod
     def from_pretrained(cls, path):
@@ -192,37 +208,34 @@ class AutoencoderKL(nn.Module):
     @torch.no_grad()
     def encode(self, x):
         self._ready(x)
-        g, eps, enc = self.config.norm_num_groups, self.eps, self.encoder
-        h = ops.conv2d(x.to(F32).contiguous(), enc.conv_in.weight, enc.conv_in.bias)
+        g, eps, enc, pr = self.config.norm_num_groups, self.eps, self.encoder, self.conv_precision
+        h = _conv3(enc.conv_in, x.to(F32).contiguous(), pr)
         for blk in enc.down_blocks:
             for r in blk.resnets:
-                h = r.run(h, g, eps)
+                h = r.run(h, g, eps, pr)
             if hasattr(blk, "downsamplers"):
                 c = blk.downsamplers[0].conv
-                h = ops.conv2d(h, c.weight, c.bias, stride=2)
-        h = enc.mid_block.run(h, g, eps)
+                h = ops.conv2d(h, c.weight, c.bias, stride=2)       # 3 launches per frame: stays on the fp32 kernel
+        h = enc.mid_block.run(h, g, eps, pr)
         st = ops.groupnorm_stats(h, g, eps)
-        h = ops.conv2d(h, enc.conv_out.weight, enc.conv_out.bias,
-                       gn=(st, enc.conv_norm_out.weight, enc.conv_norm_out.bias, g, 1))
+        h = _conv3(enc.conv_out, h, pr, gn=(st, enc.conv_norm_out.weight, enc.conv_norm_out.bias, g, 1))
         moments = ops.conv2d(h, self.quant_conv.weight, self.quant_conv.bias, ksize=1)
         return SimpleNamespace(latent_dist=DiagonalGaussianDistribution(moments))
 
     @torch.no_grad()
     def decode(self, z):
         self._ready(z)
-        g, eps, dec = self.config.norm_num_groups, self.eps, self.decoder
+        g, eps, dec, pr = self.config.norm_num_groups, self.eps, self.decoder, self.conv_precision
         h = ops.conv2d(z.to(F32).contiguous(), self.post_quant_conv.weight, self.post_quant_conv.bias, ksize=1)
-        h = ops.conv2d(h, dec.conv_in.weight, dec.conv_in.bias)
-        h = dec.mid_block.run(h, g, eps)
+        h = _conv3(dec.conv_in, h, pr)
+        h = dec.mid_block.run(h, g, eps, pr)
         for blk in dec.up_blocks:
             for r in blk.resnets:
-                h = r.run(h, g, eps)
+                h = r.run(h, g, eps, pr)
             if hasattr(blk, "upsamplers"):
-                c = blk.upsamplers[0].conv
-                h = ops.conv2d(h, c.weight, c.bias, upsample=True)
+                h = _conv3(blk.upsamplers[0].conv, h, pr, upsample=True)
         st = ops.groupnorm_stats(h, g, eps)
-        h = ops.conv2d(h, dec.conv_out.weight, dec.conv_out.bias,
-                       gn=(st, dec.conv_norm_out.weight, dec.conv_norm_out.bias, g, 1))
+        h = _conv3(dec.conv_out, h, pr, gn=(st, dec.conv_norm_out.weight, dec.conv_norm_out.bias, g, 1))
         return SimpleNamespace(sample=h)
 
     # ---- fused helpers used by the pipeline (LVM/pipeline.py:110-117, 558-590) ----
