@@ -259,7 +259,7 @@ def main():
                     help="skip the short stage-1 data-parallel training measurement appended to the default line")
     ap.add_argument("--no-prefix-reuse", action="store_true",
                     help="recompute the condition frames at every step exactly as the reference does")
-    ap.add_argument("--vae-precision", choices=["fp32", "bf16x3"], default="fp32",
+    ap.add_argument("--vae-precision", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="vae / pipeline workloads: arithmetic of the 3x3 convolutions (video-gpt_amd/vae.py)")
     ap.add_argument("--breakdown", action="store_true", help="add per-operator HIP-event times of one eager denoise step")
     ap.add_argument("--rounds", type=int, default=1, help="pipeline workload: chained next-clip rounds (cfg-5 uses 8)")

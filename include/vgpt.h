@@ -244,12 +244,14 @@ int vgpt_conv2d_fwd(const float* x, const float* w, const float* bias, const flo
 /* 3x3 stride-1 convolution on the bf16 matrix cores at fp32-class accuracy: every operand is split hi + lo (two bf16)
  * and the three leading product terms are accumulated in fp32 (~16 mantissa bits; the reference's torch/cuDNN default
  * for its fp32 VAE is TF32, 10 bits).  Same prologue (nearest x2 upsample, GroupNorm(+SiLU)) and epilogue (bias,
- * residual) as vgpt_conv2d_fwd.  Weights are pre-split and pre-ordered once by vgpt_conv_pack_weights_bx3:
- * w (Cout, Cin, 3, 3) fp32 -> w_hi, w_lo (Cout, 9, Cin_pad) bf16 with Cin_pad = Cin rounded up to 32. */
-int vgpt_conv_pack_weights_bx3(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, void* stream);
-int vgpt_conv2d_bx3_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* resid,
-                        const float* gn_stats, const float* gn_gamma, const float* gn_beta, float* y, int N, int Cin,
-                        int Hin, int Win, int Cout, int upsample, int gn_groups, int gn_silu, void* stream);
+ * residual) as vgpt_conv2d_fwd.  Weights are pre-split once by vgpt_conv_pack_weights_bx3 into LDS-ready images:
+ * w (Cout, Cin, 3, 3) fp32 -> `packed`, vgpt_conv_bx3_packed_bytes(Cout, Cin) bytes (one hi + lo image per 64-channel
+ * output tile and 32-channel input chunk, copied into LDS by LDS-DMA). */
+int64_t vgpt_conv_bx3_packed_bytes(int Cout, int Cin);
+int vgpt_conv_pack_weights_bx3(const float* w, void* packed, int Cout, int Cin, void* stream);
+int vgpt_conv2d_bx3_fwd(const float* x, const void* packed, const float* bias, const float* resid, const float* gn_stats,
+                        const float* gn_gamma, const float* gn_beta, float* y, int N, int Cin, int Hin, int Win, int Cout,
+                        int upsample, int gn_groups, int gn_silu, void* stream);
 /* In-place softmax over the KEY axis of S^T (N, keys, queries) with pre-scale (mid-block attention). */
 int vgpt_col_softmax(float* s, int N, int keys, int queries, float scale, void* stream);
 

@@ -164,24 +164,41 @@ constexpr int BX_CK = 32, BX_PH = TH + 2, BX_PW = TW + 2;
 constexpr int BX_PSTRIDE = 96;                       // bytes per pixel in one patch plane (64 used)
 constexpr int BX_WROW = (9 * BX_CK + 16) * 2;         // bytes per output channel in one weight plane (576 used)
 constexpr int BX_P_BYTES = BX_PH * BX_PW * BX_PSTRIDE, BX_W_BYTES = TCO * BX_WROW;
-constexpr int BX_LDS = 2 * (BX_P_BYTES + BX_W_BYTES);
+
+constexpr int BX_IMG = 2 * BX_W_BYTES;               // one (co tile, channel chunk) weight image: hi plane, lo plane
+constexpr int BX_GN_OFF = 2 * (BX_P_BYTES + BX_W_BYTES), BX_GN_MAX = 1024;   // per-channel GroupNorm scale / shift table
+constexpr int BX_LDS_TOTAL = BX_GN_OFF + 2 * BX_GN_MAX * 4;
+static_assert(BX_IMG % 4096 == 0, "weight image must split into whole 1-KiB pieces per wave");
 
 struct ConvBxArgs {
-    const float* x; const bf16* w_hi; const bf16* w_lo; const float* bias; const float* resid;
+    const float* x; const char* wimg; const float* bias; const float* resid;
     const float* gn_stats; const float* gn_gamma; const float* gn_beta;
     float* y;
-    int N, Cin, Cin_pad, Hin, Win, Cout, Hout, Wout;
+    int N, Cin, nch, Hin, Win, Cout, Hout, Wout;
     int upsample, gn_groups, gn_silu;
     int tiles_x, tiles_y, tiles_co;
 };
 
+__device__ __forceinline__ void bx_glds16(const char* base, uint32_t voffset, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffset), "s"(base), "s"(lds_dst)
+        : "memory");
+}
+
+// Per chunk of 32 input channels:  [barrier]  raw patch values (prefetched into registers under the previous chunk's
+// MFMAs) -> GroupNorm/SiLU/split -> LDS;  the pre-packed weight image of the chunk arrives meanwhile by LDS-DMA;
+// [vmcnt(0), barrier]  issue the raw patch loads of the NEXT chunk;  9 taps x 24 MFMAs.
 __global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sWh = smem;
     char* sWl = sWh + BX_W_BYTES;
     char* sPh = sWl + BX_W_BYTES;
     char* sPl = sPh + BX_P_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* sGN = reinterpret_cast<float*>(smem + BX_GN_OFF);   // [scale Cin][shift Cin]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y; bid /= a.tiles_y;
@@ -191,7 +208,17 @@ __global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
     const int Hv = a.Hin << a.upsample, Wv = a.Win << a.upsample;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const float* xn = a.x + (int64_t)n * a.Cin * a.Hin * a.Win;
-    const int cpg = a.gn_groups ? a.Cin / a.gn_groups : 1;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+
+    if (a.gn_groups) {   // GroupNorm as one FMA per element: scale = rstd * gamma, shift = beta - mean * scale
+        const int cpg = a.Cin / a.gn_groups;
+        for (int ci = tid; ci < a.Cin; ci += 256) {
+            const float* st = a.gn_stats + ((int64_t)n * a.gn_groups + ci / cpg) * 2;
+            const float sc = st[1] * a.gn_gamma[ci];
+            sGN[ci] = sc;
+            sGN[BX_GN_MAX + ci] = a.gn_beta[ci] - st[0] * sc;
+        }
+    }
 
     f32x4 acc[4][2];
 #pragma unroll
@@ -200,39 +227,67 @@ __global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kq = lane >> 4, l16 = lane & 15;
 
-    for (int c0 = 0; c0 < a.Cin; c0 += BX_CK) {
-        __syncthreads();
-        // ---- weights: (co, tap) rows of 32 channels = 64 contiguous bytes per plane, copied as 4 x 16 B ----
-        for (int i = tid; i < TCO * 9 * 4; i += 256) {
-            const int q = i & 3, t = (i >> 2) % 9, co = i / 36;
-            bf16x8 vh = {}, vl = {};
-            if (co0 + co < a.Cout) {
-                const int64_t g = ((int64_t)(co0 + co) * 9 + t) * a.Cin_pad + c0 + q * 8;
-                vh = *reinterpret_cast<const bf16x8*>(a.w_hi + g);
-                vl = *reinterpret_cast<const bf16x8*>(a.w_lo + g);
-            }
-            const int o = co * BX_WROW + (t * BX_CK + q * 8) * 2;
-            *reinterpret_cast<bf16x8*>(sWh + o) = vh;
-            *reinterpret_cast<bf16x8*>(sWl + o) = vl;
-        }
-        // ---- input patch: thread -> (pixel, group of 8 channels); optional upsample / GroupNorm(+SiLU); split ----
-        for (int i = tid; i < BX_PH * BX_PW * 4; i += 256) {
-            const int pix = i % (BX_PH * BX_PW), q = i / (BX_PH * BX_PW);   // consecutive lanes -> consecutive pixels
-            const int py = pix / BX_PW, px = pix % BX_PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            const bool inside = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-            bf16x8 vh, vl;
+    // staging item = (pixel of the 6 x 34 patch, group of 8 channels); 816 items over 256 threads: 4 per thread
+    constexpr int NPIX = BX_PH * BX_PW, ITEMS = NPIX * 4, PER_T = (ITEMS + 255) / 256;
+    float praw[PER_T][8];
+    int64_t pofs[PER_T];   // element offset of channel 0 of the chunk at this item's pixel, -1 = outside the image
+#pragma unroll
+    for (int it = 0; it < PER_T; ++it) {
+        const int i = tid + 256 * it;
+        const int pix = i % NPIX, py = pix / BX_PW, px = pix % BX_PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool inside = i < ITEMS && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        pofs[it] = inside ? (int64_t)(iy >> a.upsample) * a.Win + (ix >> a.upsample) : -1;
+    }
+    const int64_t plane = (int64_t)a.Hin * a.Win;
+    auto load_raw = [&](int c0) {
+#pragma unroll
+        for (int it = 0; it < PER_T; ++it) {
+            const int q = (tid + 256 * it) / NPIX;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ci = c0 + q * 8 + j;
-                float v = 0.f;
-                if (inside && ci < a.Cin) {
-                    v = xn[((int64_t)ci * a.Hin + (iy >> a.upsample)) * a.Win + (ix >> a.upsample)];
-                    if (a.gn_groups) {
-                        const float* st = a.gn_stats + ((int64_t)n * a.gn_groups + ci / cpg) * 2;
-                        v = (v - st[0]) * st[1] * a.gn_gamma[ci] + a.gn_beta[ci];
-                        if (a.gn_silu) v = v / (1.0f + expf(-v));
-                    }
+                praw[it][j] = (pofs[it] >= 0 && ci < a.Cin) ? xn[ci * plane + pofs[it]] : 0.f;
+            }
+        }
+    };
+    load_raw(0);
+    const char* wimg = a.wimg + (int64_t)tco * a.nch * BX_IMG;
+
+    for (int c = 0; c < a.nch; ++c) {
+        const int c0 = c * BX_CK;
+        // retire the raw loads HERE (before the DMA goes out): their wait would otherwise drain the DMA as well
+#pragma unroll
+        for (int it = 0; it < PER_T; ++it)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(praw[it][j]));
+        __syncthreads();   // every wave is done reading the previous chunk's LDS images (and sGN is written)
+        // ---- weight image of this chunk: 76 KiB, 19 x 1-KiB pieces per wave, straight into its LDS layout ----
+        {
+            const uint64_t sa = (uint64_t)(uintptr_t)(wimg + (int64_t)c * BX_IMG);   // wave-uniform: keep it in SGPRs
+            const char* src = reinterpret_cast<const char*>(
+                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(sa >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sa));
+#pragma unroll
+            for (int p = 0; p < BX_IMG / 4096; ++p) {
+                const uint32_t off = (uint32_t)((wave * (BX_IMG / 4096) + p) * 1024);
+                bx_glds16(src, off + lane * 16, lds_base + off);
+            }
+        }
+        // ---- patch: GroupNorm(+SiLU), split into hi / lo, [pixel][channel] planes ----
+#pragma unroll
+        for (int it = 0; it < PER_T; ++it) {
+            const int i = tid + 256 * it;
+            if (i >= ITEMS) continue;
+            const int pix = i % NPIX, q = i / NPIX;
+            bf16x8 vh, vl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = praw[it][j];
+                const int ci = c0 + q * 8 + j;
+                if (a.gn_groups && pofs[it] >= 0 && ci < a.Cin) {
+                    v = __builtin_fmaf(v, sGN[ci], sGN[BX_GN_MAX + ci]);
+                    if (a.gn_silu) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
                 }
                 const bf16 hi = f2bf(v);
                 vh[j] = hi;
@@ -242,7 +297,9 @@ __global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
             *reinterpret_cast<bf16x8*>(sPh + o) = vh;
             *reinterpret_cast<bf16x8*>(sPl + o) = vl;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the weight image has landed
         __syncthreads();
+        if (c + 1 < a.nch) load_raw(c0 + BX_CK);            // in flight under the MFMAs below
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dy = t / 3, dx = t % 3;
@@ -293,16 +350,21 @@ __global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
     }
 }
 
-// w (Cout, Cin, 3, 3) fp32 -> hi / lo bf16 planes laid out [Cout][tap][Cin_pad] (Cin_pad = Cin rounded up to 32, zeros)
-__global__ void conv_pack_bx3_kernel(const float* __restrict__ w, bf16* __restrict__ hi, bf16* __restrict__ lo, int Cout,
-                                     int Cin, int Cin_pad) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)Cout * 9 * Cin_pad) return;
-    const int ci = (int)(i % Cin_pad), t = (int)((i / Cin_pad) % 9), co = (int)(i / ((int64_t)9 * Cin_pad));
-    const float v = ci < Cin ? w[((int64_t)co * Cin + ci) * 9 + t] : 0.f;
+// w (Cout, Cin, 3, 3) fp32 -> LDS-ready images: for every (64-channel co tile, 32-channel chunk) the hi plane then the lo
+// plane, each [co_local 64][BX_WROW bytes] with k = tap * 32 + channel (zeros for channels / output channels past the end)
+__global__ void conv_pack_bx3_kernel(const float* __restrict__ w, char* __restrict__ img, int Cout, int Cin, int nch,
+                                     int tiles_co) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one (tile, chunk, co_local, tap, channel)
+    const int64_t total = (int64_t)tiles_co * nch * TCO * 9 * BX_CK;
+    if (i >= total) return;
+    const int cl = (int)(i % BX_CK), t = (int)((i / BX_CK) % 9), col = (int)((i / (BX_CK * 9)) % TCO);
+    const int c = (int)((i / ((int64_t)BX_CK * 9 * TCO)) % nch), tc = (int)(i / ((int64_t)BX_CK * 9 * TCO * nch));
+    const int co = tc * TCO + col, ci = c * BX_CK + cl;
+    const float v = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * 9 + t] : 0.f;
     const bf16 h = f2bf(v);
-    hi[i] = h;
-    lo[i] = f2bf(v - bf2f(h));
+    char* base = img + ((int64_t)tc * nch + c) * BX_IMG + (int64_t)col * BX_WROW + (t * BX_CK + cl) * 2;
+    *reinterpret_cast<bf16*>(base) = h;
+    *reinterpret_cast<bf16*>(base + BX_W_BYTES) = f2bf(v - bf2f(h));
 }
 
 // ---- GroupNorm statistics: one block per (n, group), two passes (mean, then centred variance) ----
@@ -452,30 +514,40 @@ VGPT_EXPORT int vgpt_conv2d_fwd(const float* x, const float* w, const float* bia
     return launch_conv<3, 2>(a, s);
 }
 
-VGPT_EXPORT int vgpt_conv_pack_weights_bx3(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, void* stream) {
-    VGPT_REQUIRE(w && w_hi && w_lo && Cout > 0 && Cin > 0, VGPT_ERR_INVALID, "vgpt_conv_pack_weights_bx3: bad argument");
-    const int Cin_pad = (Cin + 31) / 32 * 32;
-    const int64_t n = (int64_t)Cout * 9 * Cin_pad;
-    hipLaunchKernelGGL(conv_pack_bx3_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16*)w_hi,
-                       (bf16*)w_lo, Cout, Cin, Cin_pad);
+VGPT_EXPORT int64_t vgpt_conv_bx3_packed_bytes(int Cout, int Cin) {
+    return (int64_t)cdiv(Cout, TCO) * cdiv(Cin, BX_CK) * BX_IMG;
+}
+
+VGPT_EXPORT int vgpt_conv_pack_weights_bx3(const float* w, void* packed, int Cout, int Cin, void* stream) {
+    VGPT_REQUIRE(w && packed && Cout > 0 && Cin > 0, VGPT_ERR_INVALID, "vgpt_conv_pack_weights_bx3: bad argument");
+    const int tiles_co = (int)cdiv(Cout, TCO), nch = (int)cdiv(Cin, BX_CK);
+    hipError_t e = hipMemsetAsync(packed, 0, vgpt_conv_bx3_packed_bytes(Cout, Cin), (hipStream_t)stream);   // row padding
+    if (e != hipSuccess) {
+        vgpt_set_error("vgpt_conv_pack_weights_bx3: memset: %s", hipGetErrorString(e));
+        return VGPT_ERR_HIP;
+    }
+    const int64_t n = (int64_t)tiles_co * nch * TCO * 9 * BX_CK;
+    hipLaunchKernelGGL(conv_pack_bx3_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (char*)packed,
+                       Cout, Cin, nch, tiles_co);
     VGPT_CHECK_LAUNCH("vgpt_conv_pack_weights_bx3");
     return VGPT_OK;
 }
 
-VGPT_EXPORT int vgpt_conv2d_bx3_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* resid,
+VGPT_EXPORT int vgpt_conv2d_bx3_fwd(const float* x, const void* packed, const float* bias, const float* resid,
                                     const float* gn_stats, const float* gn_gamma, const float* gn_beta, float* y, int N,
                                     int Cin, int Hin, int Win, int Cout, int upsample, int gn_groups, int gn_silu,
                                     void* stream) {
-    VGPT_REQUIRE(x && w_hi && w_lo && y, VGPT_ERR_INVALID, "vgpt_conv2d_bx3_fwd: null pointer");
+    VGPT_REQUIRE(x && packed && y, VGPT_ERR_INVALID, "vgpt_conv2d_bx3_fwd: null pointer");
     VGPT_REQUIRE(N >= 0 && Cin > 0 && Hin > 0 && Win > 0 && Cout > 0, VGPT_ERR_INVALID, "vgpt_conv2d_bx3_fwd: bad shape");
     VGPT_REQUIRE(gn_groups == 0 || (gn_stats && gn_gamma && gn_beta && Cin % gn_groups == 0), VGPT_ERR_INVALID,
                  "vgpt_conv2d_bx3_fwd: GroupNorm prologue needs stats/gamma/beta and Cin %% groups == 0");
-    VGPT_REQUIRE((((uintptr_t)w_hi | (uintptr_t)w_lo) & 15) == 0, VGPT_ERR_UNSUPPORTED,
-                 "vgpt_conv2d_bx3_fwd: packed weights must be 16-byte aligned");
+    VGPT_REQUIRE(gn_groups == 0 || Cin <= BX_GN_MAX, VGPT_ERR_UNSUPPORTED,
+                 "vgpt_conv2d_bx3_fwd: at most %d input channels with the GroupNorm prologue", BX_GN_MAX);
+    VGPT_REQUIRE(((uintptr_t)packed & 15) == 0, VGPT_ERR_UNSUPPORTED, "vgpt_conv2d_bx3_fwd: packed weights must be 16-byte aligned");
     if (N == 0) return VGPT_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_bx3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_bx3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_TOTAL);
         if (e != hipSuccess) {
             vgpt_set_error("vgpt_conv2d_bx3_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return VGPT_ERR_HIP;
@@ -483,15 +555,15 @@ VGPT_EXPORT int vgpt_conv2d_bx3_fwd(const float* x, const void* w_hi, const void
         attr_set = true;
     }
     ConvBxArgs a;
-    a.x = x; a.w_hi = (const bf16*)w_hi; a.w_lo = (const bf16*)w_lo; a.bias = bias; a.resid = resid;
+    a.x = x; a.wimg = (const char*)packed; a.bias = bias; a.resid = resid;
     a.gn_stats = gn_stats; a.gn_gamma = gn_gamma; a.gn_beta = gn_beta; a.y = y;
-    a.N = N; a.Cin = Cin; a.Cin_pad = (Cin + 31) / 32 * 32; a.Hin = Hin; a.Win = Win; a.Cout = Cout;
+    a.N = N; a.Cin = Cin; a.nch = (int)cdiv(Cin, BX_CK); a.Hin = Hin; a.Win = Win; a.Cout = Cout;
     a.upsample = upsample ? 1 : 0;
     a.Hout = Hin << a.upsample; a.Wout = Win << a.upsample;
     a.gn_groups = gn_groups; a.gn_silu = gn_silu;
     a.tiles_x = (int)cdiv(a.Wout, TW); a.tiles_y = (int)cdiv(a.Hout, TH); a.tiles_co = (int)cdiv(Cout, TCO);
     const int64_t blocks = (int64_t)a.tiles_x * a.tiles_y * a.tiles_co * N;
-    hipLaunchKernelGGL(conv_bx3_kernel, dim3((unsigned)blocks), dim3(256), BX_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv_bx3_kernel, dim3((unsigned)blocks), dim3(256), BX_LDS_TOTAL, (hipStream_t)stream, a);
     VGPT_CHECK_LAUNCH("vgpt_conv2d_bx3_fwd");
     return VGPT_OK;
 }

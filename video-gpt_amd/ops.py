@@ -506,26 +506,25 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 def conv_pack_bx3(weight: torch.Tensor):
-    """(Cout, Cin, 3, 3) fp32 -> (hi, lo) bf16 planes (Cout, 9, Cin_pad) for conv2d_bx3 (include/vgpt.h)."""
+    """(Cout, Cin, 3, 3) fp32 -> LDS-ready split-bf16 weight images for conv2d_bx3 (include/vgpt.h)."""
     _chk(weight, F32, "conv_pack_bx3.weight")
     Cout, Cin, kh, kw = weight.shape
     if (kh, kw) != (3, 3):
         raise VgptError("conv_pack_bx3: 3x3 kernels only")
-    cp = (Cin + 31) // 32 * 32
-    hi = torch.empty(Cout, 9, cp, dtype=BF16, device=weight.device)
-    lo = torch.empty_like(hi)
-    call("vgpt_conv_pack_weights_bx3", weight.data_ptr(), hi.data_ptr(), lo.data_ptr(), Cout, Cin, _stream())
-    return hi, lo
+    from ._lib import load
+    nbytes = int(load().vgpt_conv_bx3_packed_bytes(Cout, Cin))
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    call("vgpt_conv_pack_weights_bx3", weight.data_ptr(), packed.data_ptr(), Cout, Cin, _stream())
+    return packed, Cout, Cin
 
 
 def conv2d_bx3(x: torch.Tensor, packed, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, gn=None,
                upsample: bool = False, out: Optional[torch.Tensor] = None):
     """3x3 stride-1 convolution with split-bf16 operands on the bf16 MFMA (fp32 in / out); packed = conv_pack_bx3(w)."""
     _chk(x, F32, "conv2d_bx3.x")
-    hi, lo = packed
+    img, cout, cin = packed
     N, Cin, Hin, Win = x.shape
-    cout = hi.shape[0]
-    if hi.shape[2] != (Cin + 31) // 32 * 32:
+    if cin != Cin:
         raise VgptError("conv2d_bx3: packed weights do not match the input channels")
     Ho, Wo = (Hin * 2, Win * 2) if upsample else (Hin, Win)
     if out is None:
@@ -538,8 +537,8 @@ def conv2d_bx3(x: torch.Tensor, packed, bias: Optional[torch.Tensor] = None, res
     groups = silu = 0
     if gn is not None:
         stats, gamma, beta, groups, silu = gn
-    call("vgpt_conv2d_bx3_fwd", x.data_ptr(), hi.data_ptr(), lo.data_ptr(), _ptr(bias), _ptr(resid), _ptr(stats), _ptr(gamma),
-         _ptr(beta), out.data_ptr(), N, Cin, Hin, Win, cout, int(upsample), int(groups), int(silu), _stream())
+    call("vgpt_conv2d_bx3_fwd", x.data_ptr(), img.data_ptr(), _ptr(bias), _ptr(resid), _ptr(stats), _ptr(gamma), _ptr(beta),
+         out.data_ptr(), N, Cin, Hin, Win, cout, int(upsample), int(groups), int(silu), _stream())
     return out
 
 
