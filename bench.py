@@ -329,7 +329,7 @@ def main():
     reuse = eng.S > 0
     if reuse:
         # condition prefix computed once per clip (timed: one prefill per timed region): per-step algorithmic work
-        # is the reduced count of SURVEY.md §8d (34.11 TF at cfg-2), the prefill is added to the total
+        # is the reduced count of SURVEY.md §8d (34.11 TF at cfg-2), the prefill (7.6 TF) is added to the total
         static_tok = C * (N + 2)
         pairs_static = int(batch["attention_mask"][0, :static_tok].sum().item())
         real_tokens_step, pairs_step = real_tokens - static_tok, pairs - pairs_static
@@ -338,7 +338,8 @@ def main():
     flops_linear = 2 * (4 * H * H + 3 * H * I) * real_tokens_step * nl
     flops_attn = 4 * H * pairs_step * nl
     flops_step = flops_linear + flops_attn
-    flops_prefill = (2 * (4 * H * H + 3 * H * I) * real_tokens + 4 * H * pairs) * nl if reuse else 0
+    # the prefill runs the condition rows only (they never see a later row)
+    flops_prefill = (2 * (4 * H * H + 3 * H * I) * static_tok + 4 * H * pairs_static) * nl if reuse else 0
 
     stream = torch.cuda.Stream(device=device)
     use_graph = not args.no_graph

@@ -195,23 +195,27 @@ class StaticDenoiser:
             self.prefill()
 
     def prefill(self):
-        """One full-length forward that leaves every layer's (post-RoPE) q/k/v of the static prefix in
-        qkv_full[l][:S]; the rows >= S written here are overwritten by every step."""
-        m, cfg, H, L = self.model, self.cfg, self.H, self.L
+        """One forward over the static prefix rows [0, S) ONLY -- they never see a later row (that is what makes them
+        step-invariant), so nothing else is needed to produce them -- leaving every layer's (post-RoPE) q/k/v in
+        qkv_full[l][:S].  Rows >= S of qkv_full are written by every step (zero until the first one: the buffer is
+        zero-initialised so that masked keys are finite)."""
+        m, cfg, H, S = self.model, self.cfg, self.H, self.S
         nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         e = lambda *s: torch.empty(*s, dtype=BF16, device=self.dev)
-        hid, nrm, ctx, act = e(1, L, H), e(1, L, H), e(1, L, nq * hd), e(1, L, cfg.intermediate_size)
-        ops.embed_gather(self.input_ids, m.llm.embed_tokens.weight, out=hid)
+        hid, nrm, ctx, act = e(1, S, H), e(1, S, H), e(1, S, nq * hd), e(1, S, cfg.intermediate_size)
+        ops.embed_gather(self.input_ids[:, :S].contiguous(), m.llm.embed_tokens.weight, out=hid)
         if self.cond is not None:
             ops.patch_embed(self.cond, m.input_x_embedder.proj.weight, m.input_x_embedder.proj.bias, m.pos_embed[0],
                             self.cond_rows, hid.view(-1, H), m.pos_embed_max_size)
+        rope = (self.rope[0][:S].contiguous(), self.rope[1][:S].contiguous())
+        seg = ((0, 0, S),)   # includes the pad rows S0..S: no visible key -> zeros, which keeps their K/V finite
         for li, layer in enumerate(m.llm.layers):
             at, mlp = layer.self_attn, layer.mlp
-            qkv = self.qkv_full[li].view(1, L, -1)
+            full = self.qkv_full[li]
             ops.rmsnorm(hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=nrm)
-            ops.linear(nrm, at.qkv_proj.weight, out=qkv)
-            ops.rope_qk_inplace(qkv, self.rope[0], self.rope[1], nq, nk, hd)
-            ops.attention_qkv_range(qkv, self.pm, nq, nk, hd, 0, ctx, segments=self.seg_all)
+            ops.linear(nrm, at.qkv_proj.weight, out=full[:S])
+            ops.rope_qk_inplace(full[:S], rope[0], rope[1], nq, nk, hd)
+            ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, 0, ctx, segments=seg)
             ops.linear(ctx, at.o_proj.weight, residual=hid, out=hid)
             ops.rmsnorm(hid, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon, out=nrm)
             ops.gated_mlp_act(nrm, mlp.gate_up_proj.weight, mlp.act, out=act)
