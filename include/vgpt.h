@@ -148,13 +148,19 @@ int vgpt_attn_blockmask_fwd_qrange(const void* q, const void* k, const void* v, 
  * item_rows selects the kernel: 128 = the 4-wave kernel of vgpt_attn_blockmask_fwd (two workgroups per CU; the default
  * of the Python host), 256 = an 8-wave kernel (head_dim 96 only) whose two wave groups alternate matrix and vector
  * phases under workgroup barriers -- measured slower on MI355X at the cfg-2 shapes and kept selectable.
+ * Key-split items (item_rows 128): a row range whose key set is much longer than the others' may appear as `nparts`
+ * work items with items[.][3] = part | nparts << 8 | pbase << 16 (pbase = number of key slices of all earlier split
+ * items); each walks its slice of the visible key tiles and leaves (unnormalised O, m, l) in split_ws, a merge kernel
+ * launched behind the main one writes the rows.  split_items (n_split, 4) = {batch, row0, nrows, nparts | pbase << 8};
+ * split_ws holds (total key slices) * n_heads * 128 * (head_dim + 4) floats.  n_split = 0: no splitting.
  * vgpt_attn_plan_build fills item_summary and order from bits and items.  vgpt_attn_fwd_plan computes exactly the rows
  * the items cover (same math as vgpt_attn_blockmask_fwd); lse may be NULL. */
 int vgpt_attn_plan_build(const uint32_t* bits, int64_t B, int64_t L, const int32_t* items, int64_t n_items, int item_rows,
                          uint16_t* item_summary, int32_t* order, void* stream);
 int vgpt_attn_fwd_plan(const void* q, const void* k, const void* v, void* o, float* lse, const uint32_t* bits,
                        const int32_t* items, const uint16_t* item_summary, const int32_t* order, int64_t n_items,
-                       int item_rows, int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim, int64_t q_sb,
+                       int item_rows, const int32_t* split_items, int64_t n_split, float* split_ws, int64_t B, int64_t L,
+                       int n_heads, int n_kv_heads, int head_dim, int64_t q_sb,
                        int64_t q_sh, int64_t q_ss, int64_t k_sb, int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
                        int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss, float scale, void* stream);
 

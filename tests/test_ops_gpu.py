@@ -292,7 +292,7 @@ def test_attention_plan_build(ops, B, L, segs, item_rows):
     m = _random_block_mask(B, L, 31)
     m[:, : L // 3, L // 2:] = 0
     pm = ops.pack_mask(torch.from_numpy(m).to(DEV))
-    plan = pm.plan(segs, item_rows)
+    plan = pm.plan(segs, item_rows, False)
     items = plan.items.cpu().numpy()
     want_items = [(b, r, min(item_rows, r1 - r), 0) for b, r0, r1 in (segs or [(b, 0, L) for b in range(B)])
                   for r in range(r0, r1, item_rows)]
@@ -303,6 +303,18 @@ def test_attention_plan_build(ops, B, L, segs, item_rows):
     cnt = np.array([(want[i] != 0).sum() if (want_items[i][2] > 32 or item_rows == 128) else ((want[i] != 0).sum() + 7) // 8
                     for i in range(len(want_items))])
     assert np.array_equal(plan.order.cpu().numpy()[: len(want_items)], np.argsort(-cnt, kind="stable"))
+    if item_rows == 128:   # key-split plan: same rows, long items repeated once per key slice, every slot described
+        sp = pm.plan(segs, 128, True)
+        it2 = sp.items.cpu().numpy()[: sp.n_items]
+        assert sorted({(r[0], r[1], r[2]) for r in it2.tolist()}) == sorted({(t[0], t[1], t[2]) for t in want_items})
+        if sp.split_items is not None:
+            expect_base = 0
+            for b, r0, nr, meta in sp.split_items.cpu().tolist():
+                nparts, pbase = meta & 255, meta >> 8
+                assert pbase == expect_base and nparts >= 2
+                parts = sorted(r[3] & 255 for r in it2.tolist() if (r[3] >> 8) & 255 > 1 and (r[3] >> 16) == pbase)
+                assert parts == list(range(nparts))
+                expect_base += nparts
 
 
 @pytest.mark.parametrize("item_rows,hd", [(128, 96), (256, 96), (128, 128), (128, 64)])
@@ -322,11 +334,11 @@ def test_attention_planned_kernel(ops, B, L, nh, nkv, segs, item_rows, hd):
     dq = qkv.to(DEV, BF)
     legacy = ops.attention_qkv(dq, pm, nh, nkv, hd, variant=2)
     if segs is None:
-        out = ops.attention_qkv(dq, pm, nh, nkv, hd, variant=3 if item_rows == 256 else 0)
+        out = ops.attention_qkv(dq, pm, nh, nkv, hd, variant=3 if item_rows == 256 else 0, split_keys=False)
         covered = [(b, 0, L) for b in range(B)]
     else:
         out = torch.full((B, L, nh * hd), 7.0, dtype=BF, device=DEV)
-        ops.attention_qkv_range(dq, pm, nh, nkv, hd, 0, out, segments=segs, item_rows=item_rows)
+        ops.attention_qkv_range(dq, pm, nh, nkv, hd, 0, out, segments=segs, item_rows=item_rows, split_keys=False)
         covered = list(segs)
     q = qkv[..., : nh * hd].view(B, L, nh, hd).transpose(1, 2)
     k = qkv[..., nh * hd:(nh + nkv) * hd].view(B, L, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
@@ -340,6 +352,19 @@ def test_attention_planned_kernel(ops, B, L, nh, nkv, segs, item_rows, hd):
             if min(item_rows, r1 - r) > 32 or item_rows == 128:   # ordinary item: same per-row operation sequence
                 assert torch.equal(out[b, r:min(r + item_rows, r1)], legacy[b, r:min(r + item_rows, r1)])
     assert bool((out.cpu()[~seen].float() == 7.0).all())   # rows outside the segments are not touched
+    if item_rows == 128:
+        # key-split plan: long items are cut into key slices whose partial (O, m, l) a second kernel merges
+        plan = pm.plan(segs, 128, True)
+        out2 = torch.full((B, L, nh * hd), 7.0, dtype=BF, device=DEV)
+        if segs is None:
+            out2 = ops.attention_qkv(dq, pm, nh, nkv, hd, split_keys=True)
+        else:
+            ops.attention_qkv_range(dq, pm, nh, nkv, hd, 0, out2, segments=segs, split_keys=True)
+        for b, r0, r1 in covered:
+            assert rel_l2(out2[b, r0:r1], ref[b, r0:r1]) < 1e-2
+        assert bool((out2.cpu()[~seen].float() == 7.0).all())
+        if L >= 700:
+            assert plan.split_items is not None and int((plan.split_items[:, 3] & 255).max()) >= 2   # these masks do get split
 
 
 @pytest.mark.parametrize("variant", [0, 1])

@@ -38,6 +38,9 @@ struct AttnArgs {
     const uint16_t* isum;      // n_items x nkt, 2 bits per 32-row slab
     const int32_t* iorder;     // n_items
     int n_items;
+    // items[4i+3] = part | nparts << 8 | pbase << 16: an item may be cut into `nparts` work items that each walk a slice
+    // of its visible key tiles and leave (unnormalised O, m, l) in split_ws (slice index pbase + part) for the merge kernel
+    float* split_ws;
     float* lse;  // optional (B, n_heads, L): base-2 log-sum-exp of the scaled scores, for the backward
     int B, L, n_heads, kv_group;  // kv_group = n_heads / n_kv_heads
     int W;                        // mask words per row
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     int n_tiles_done = 0;
 
     // ---- work item ----
-    int wid = blockIdx.x, head, b, row0, row_last;
+    int wid = blockIdx.x, head, b, row0, row_last, part = 0, nparts = 1, slot = 0;
     const uint8_t* sum8 = nullptr;
     const uint16_t* sum16 = nullptr;
     if (a.items) {
@@ -126,6 +129,10 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         b = a.items[4 * item];
         row0 = a.items[4 * item + 1];
         row_last = row0 + a.items[4 * item + 2] - 1;
+        const int meta = a.items[4 * item + 3];
+        part = meta & 255;
+        nparts = max((meta >> 8) & 255, 1);
+        slot = meta >> 16;
         sum16 = a.isum + (int64_t)item * a.nkt;
         wid = item;
     } else {
@@ -266,15 +273,24 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     __syncthreads();  // every wave is done with the previous list and the staging buffers
     if (wave == 0) {
         const int lim = min(chunk0 + ACT_MAX, a.nkt);
+        auto code_of_tile = [&](int t) { return t < lim ? (sum16 ? (uint32_t)sum16[t] & 0xffu : (uint32_t)sum8[t]) : 0u; };
+        int lo = 0, hi = 0x7fffffff;
+        if (nparts > 1) {   // this work item takes slice `part` of the visible tiles (counted first)
+            int n_all = 0;
+            for (int base = chunk0; base < lim; base += 64) n_all += __popcll(__ballot(code_of_tile(base + lane) != 0));
+            lo = n_all * part / nparts;
+            hi = n_all * (part + 1) / nparts;
+        }
         int n = 0;
         for (int base = chunk0; base < lim; base += 64) {
             const int t = base + lane;
-            const uint32_t c = t < lim ? (sum16 ? (uint32_t)sum16[t] & 0xffu : (uint32_t)sum8[t]) : 0u;
+            const uint32_t c = code_of_tile(t);
             const uint64_t bal = __ballot(c != 0);
-            if (c) alist[1 + n + __popcll(bal & ((1ull << lane) - 1))] = ((uint32_t)t << 8) | c;
+            const int idx = n + __popcll(bal & ((1ull << lane) - 1));
+            if (c && idx >= lo && idx < hi) alist[1 + idx - lo] = ((uint32_t)t << 8) | c;
             n += __popcll(bal);
         }
-        if (lane == 0) alist[0] = (uint32_t)n;
+        if (lane == 0) alist[0] = (uint32_t)(min(n, hi) - min(n, lo));
     }
     __syncthreads();
     const int n_act = __builtin_amdgcn_readfirstlane((int)alist[0]);
@@ -425,6 +441,20 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         t[3] = ((unsigned long long)(unsigned)wid << 32) | (unsigned)n_tiles_done;
     }
     // ---- epilogue: lane holds O^T[d = 32dt + (i&3) + 8(i>>2) + 4h][q = r] ----
+    if (nparts > 1) {   // partial result of a key slice: rows of (D + 4) floats = O (unnormalised), m, l, -, -
+        float* wsr = a.split_ws + ((((int64_t)slot + part) * a.n_heads + head) * 128 + wave * 32 + r) * (D + 4);  // slot = pbase
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<f32x4*>(wsr + dt * 32 + 8 * g4 + 4 * h) =
+                    f32x4{O[dt][4 * g4], O[dt][4 * g4 + 1], O[dt][4 * g4 + 2], O[dt][4 * g4 + 3]};
+        if (h == 0) {
+            wsr[D] = m_i;
+            wsr[D + 1] = l_i;
+        }
+        return;
+    }
     if (a.lse && q_valid && h == 0)
         a.lse[((int64_t)b * a.n_heads + head) * a.L + q_row] = l_i > 0.f ? m_i + __builtin_amdgcn_logf(l_i) : INFINITY;
     if (q_valid) {
@@ -440,6 +470,49 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
                 *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g4 + 4 * h) = o;
             }
     }
+}
+
+// merge of the key-slice partials of split items: one workgroup per (split item, head), thread = (row, half of d)
+template <int D>
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ ws, const int32_t* __restrict__ split_items,
+                                                         bf16* __restrict__ o, float* __restrict__ lse, int n_heads, int L,
+                                                         int64_t o_sb, int64_t o_sh, int64_t o_ss) {
+    const int slot = blockIdx.x / n_heads, head = blockIdx.x % n_heads;
+    const int b = split_items[4 * slot], row0 = split_items[4 * slot + 1], nrows = split_items[4 * slot + 2];
+    const int nparts = split_items[4 * slot + 3] & 255, pbase = split_items[4 * slot + 3] >> 8;
+    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    if (row >= nrows) return;
+    const int64_t pstride = (int64_t)n_heads * 128 * (D + 4);   // between consecutive key slices of one (item, head)
+    const float* base = ws + (((int64_t)pbase * n_heads + head) * 128 + row) * (D + 4);
+    float m_all = -INFINITY;
+    for (int p = 0; p < nparts; ++p) m_all = fmaxf(m_all, base[p * pstride + D]);
+    float l_all = 0.f;
+    float acc[D / 2];
+#pragma unroll
+    for (int d = 0; d < D / 2; ++d) acc[d] = 0.f;
+    for (int p = 0; p < nparts; ++p) {
+        const float* pr = base + p * pstride;
+        const float mp = pr[D];
+        const float f = mp == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mp - m_all);
+        l_all += pr[D + 1] * f;
+#pragma unroll
+        for (int d4 = 0; d4 < D / 8; ++d4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pr + half * (D / 2) + 4 * d4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[4 * d4 + t] += v[t] * f;
+        }
+    }
+    const float inv = l_all > 0.f ? 1.0f / l_all : 0.f;
+    bf16* op = o + b * o_sb + head * o_sh + (int64_t)(row0 + row) * o_ss + half * (D / 2);
+#pragma unroll
+    for (int d4 = 0; d4 < D / 8; ++d4) {
+        bf16x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = f2bf(acc[4 * d4 + t] * inv);
+        *reinterpret_cast<bf16x4*>(op + 4 * d4) = v;
+    }
+    if (lse && half == 0)
+        lse[((int64_t)b * n_heads + head) * L + row0 + row] = l_all > 0.f ? m_all + __builtin_amdgcn_logf(l_all) : INFINITY;
 }
 
 template <int D, bool TR>
@@ -484,6 +557,9 @@ struct ItemPlan {
     const uint16_t* isum;
     const int32_t* order;
     int64_t n_items;
+    const int32_t* split_items;   // n_split x 4: batch, row0, nrows, nparts | pbase << 8 (items cut into key slices), or null
+    int64_t n_split;
+    float* split_ws;              // n_split * n_heads * sum(nparts) * 128 * (head_dim + 4) floats
 };
 
 static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, int64_t q_start,
@@ -533,17 +609,27 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
     a.isum = plan ? plan->isum : nullptr;
     a.iorder = plan ? plan->order : nullptr;
     a.n_items = plan ? (int)plan->n_items : 0;
+    a.split_ws = plan ? plan->split_ws : nullptr;
+    VGPT_REQUIRE(!plan || plan->n_split == 0 || (plan->split_items && plan->split_ws && variant == 0), VGPT_ERR_INVALID,
+                 "vgpt_attn_fwd_plan: split items need their table and workspace");
     const int64_t n_wg = plan ? plan->n_items * n_heads : (int64_t)(a.nqb - a.qb0) * n_heads * B;
     a.trace = n_wg <= g_trace_cap ? g_trace : nullptr;
     hipStream_t s = (hipStream_t)stream;
-#define ATTN_CASE(DD)                                   \
-    case DD:                                            \
-        return variant == 0 ? launch<DD, true>(a, s) : launch<DD, false>(a, s);
+    int rc = VGPT_ERR_UNSUPPORTED;
+#define ATTN_CASE(DD)                                                                     \
+    case DD:                                                                              \
+        rc = variant == 0 ? launch<DD, true>(a, s) : launch<DD, false>(a, s);             \
+        if (rc == VGPT_OK && plan && plan->n_split > 0) {                                 \
+            hipLaunchKernelGGL(attn_merge_kernel<DD>, dim3((unsigned)(plan->n_split * n_heads)), dim3(256), 0, s, \
+                               plan->split_ws, plan->split_items, a.o, a.lse, n_heads, a.L, a.o_sb, a.o_sh, a.o_ss); \
+            VGPT_CHECK_LAUNCH("vgpt_attn_fwd_plan (merge)");                                \
+        }                                                                                 \
+        break;
     switch (head_dim) {
         ATTN_CASE(64) ATTN_CASE(96) ATTN_CASE(128)
     }
 #undef ATTN_CASE
-    return VGPT_ERR_UNSUPPORTED;
+    return rc;
 }
 
 VGPT_EXPORT int vgpt_attn_blockmask_fwd(const void* q, const void* k, const void* v, void* o,
@@ -587,9 +673,9 @@ VGPT_EXPORT int vgpt_attn_blockmask_fwd_qrange(const void* q, const void* k, con
 // 128-row items of a plan on the 4-wave kernel (called by vgpt_attn_fwd_plan, attn_fwd_pp.hip)
 int vgpt_attn_fwd_items128(const void* q, const void* k, const void* v, void* o, float* lse, const uint32_t* bits,
                            const int32_t* items, const uint16_t* item_summary, const int32_t* order, int64_t n_items,
-                           int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim, const int64_t* st, float scale,
-                           void* stream) {
-    const ItemPlan plan = {items, item_summary, order, n_items};
+                           const int32_t* split_items, int64_t n_split, float* split_ws, int64_t B, int64_t L, int n_heads,
+                           int n_kv_heads, int head_dim, const int64_t* st, float scale, void* stream) {
+    const ItemPlan plan = {items, item_summary, order, n_items, split_items, n_split, split_ws};
     return attn_fwd_impl(q, k, v, o, lse, 0, bits, nullptr, nullptr, &plan, B, L, n_heads, n_kv_heads, head_dim, st[0], st[1],
                          st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], scale, 0, stream);
 }

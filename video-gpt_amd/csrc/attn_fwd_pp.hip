@@ -510,7 +510,8 @@ __global__ void item_order_kernel(const int32_t* __restrict__ items, const uint1
         const uint16_t* row = isum + (int64_t)i * nkt;
         int c = 0;
         for (int t = 0; t < nkt; ++t) c += row[t] != 0;
-        cnt[i] = items[4 * i + 2] <= thin_rows ? (c + 7) / 8 : c;  // 8-wave kernel: thin items split their tiles
+        const int nparts = max((items[4 * i + 3] >> 8) & 255, 1);   // key-split work items walk 1/nparts of the tiles
+        cnt[i] = items[4 * i + 2] <= thin_rows ? (c + 7) / 8 : (c + nparts - 1) / nparts;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -533,8 +534,8 @@ void vgpt_attn_pp_set_trace(void* buf, int64_t cap) {
 
 int vgpt_attn_fwd_items128(const void* q, const void* k, const void* v, void* o, float* lse, const uint32_t* bits,
                            const int32_t* items, const uint16_t* item_summary, const int32_t* order, int64_t n_items,
-                           int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim, const int64_t* st, float scale,
-                           void* stream);  // attn_fwd.hip
+                           const int32_t* split_items, int64_t n_split, float* split_ws, int64_t B, int64_t L, int n_heads,
+                           int n_kv_heads, int head_dim, const int64_t* st, float scale, void* stream);  // attn_fwd.hip
 
 VGPT_EXPORT int vgpt_attn_plan_build(const uint32_t* bits, int64_t B, int64_t L, const int32_t* items, int64_t n_items,
                                      int item_rows, uint16_t* item_summary, int32_t* order, void* stream) {
@@ -553,17 +554,19 @@ VGPT_EXPORT int vgpt_attn_plan_build(const uint32_t* bits, int64_t B, int64_t L,
 
 VGPT_EXPORT int vgpt_attn_fwd_plan(const void* q, const void* k, const void* v, void* o, float* lse, const uint32_t* bits,
                                    const int32_t* items, const uint16_t* item_summary, const int32_t* order,
-                                   int64_t n_items, int item_rows, int64_t B, int64_t L, int n_heads, int n_kv_heads,
-                                   int head_dim, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                                   int64_t n_items, int item_rows, const int32_t* split_items, int64_t n_split,
+                                   float* split_ws, int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim,
+                                   int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                                    int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
                                    float scale, void* stream) {
     VGPT_REQUIRE(q && k && v && o && bits && items && item_summary && order, VGPT_ERR_INVALID,
                  "vgpt_attn_fwd_plan: null pointer");
     if (item_rows == 128) {
         const int64_t st[12] = {q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss};
-        return vgpt_attn_fwd_items128(q, k, v, o, lse, bits, items, item_summary, order, n_items, B, L, n_heads, n_kv_heads,
-                                      head_dim, st, scale, stream);
+        return vgpt_attn_fwd_items128(q, k, v, o, lse, bits, items, item_summary, order, n_items, split_items, n_split,
+                                      split_ws, B, L, n_heads, n_kv_heads, head_dim, st, scale, stream);
     }
+    VGPT_REQUIRE(n_split == 0, VGPT_ERR_UNSUPPORTED, "vgpt_attn_fwd_plan: key-split items need item_rows 128");
     VGPT_REQUIRE(item_rows == 256, VGPT_ERR_INVALID, "vgpt_attn_fwd_plan: item_rows must be 128 or 256");
     VGPT_REQUIRE(head_dim == D, VGPT_ERR_UNSUPPORTED,
                  "vgpt_attn_fwd_plan: the 256-row kernel needs head_dim 96 (got %d)", head_dim);

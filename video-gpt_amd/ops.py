@@ -143,8 +143,19 @@ def gated_mlp_act(x: torch.Tensor, w_gate_up: torch.Tensor, act: int = ACT_SILU,
 # ---- attention --------------------------------------------------------------------------------
 
 class AttnPlan:
-    def __init__(self, items, summary, order, n_items, item_rows):
+    def __init__(self, items, summary, order, n_items, item_rows, split_items=None, split_rows=0):
         self.items, self.summary, self.order, self.n_items, self.item_rows = items, summary, order, n_items, item_rows
+        self.split_items, self.split_rows = split_items, split_rows    # key-split slots; total (parts x 128) rows
+        self._ws = {}
+
+    def workspace(self, n_heads: int, head_dim: int):
+        """fp32 scratch of the key-slice partials (include/vgpt.h): allocated once per (heads, head_dim)."""
+        if self.split_items is None:
+            return None
+        k = (n_heads, head_dim)
+        if k not in self._ws:
+            self._ws[k] = torch.empty(self.split_rows * n_heads * (head_dim + 4), dtype=F32, device=self.items.device)
+        return self._ws[k]
 
 
 class PackedMask:
@@ -155,13 +166,16 @@ class PackedMask:
         self._order = {}
         self._plans = {}
 
-    def plan(self, segments=None, item_rows: int = 128) -> "AttnPlan":
-        """Work plan of the head_dim-96 forward kernel (include/vgpt.h, vgpt_attn_plan_build) for the query rows of
+    def plan(self, segments=None, item_rows: int = 128, split_keys: bool = False) -> "AttnPlan":
+        """Work plan of the planned forward kernel (include/vgpt.h, vgpt_attn_plan_build) for the query rows of
         `segments` = ((batch, row_begin, row_end), ...); default: every row, one segment per batch item.  Each
         segment is cut into items of item_rows (128: 4-wave kernel, 256: 8-wave head_dim-96 kernel) rows; cut
-        segments where packed sequences meet."""
+        segments where packed sequences meet.  split_keys (128-row items, off by default): items whose visible key
+        tiles exceed 1.4x the shortest full item's are cut into key slices of about that length, merged by a second
+        kernel.  Measured on the cfg-2 layout it does not pay (the per-work-item overhead and the merge cost more than
+        the better balance returns: 230 vs 200 us per layer); it is there for masks with far more skewed key sets."""
         skey = tuple(tuple(int(v) for v in s_) for s_ in segments) if segments is not None else None
-        key = (skey, item_rows)
+        key = (skey, item_rows, bool(split_keys))
         p = self._plans.get(key)
         if p is None:
             segs = skey if skey is not None else tuple((b, 0, self.L) for b in range(self.B))
@@ -170,15 +184,40 @@ class PackedMask:
                 if not (0 <= b < self.B and 0 <= r0 <= r1 <= self.L):
                     raise VgptError(f"attention plan: bad segment {(b, r0, r1)}")
                 items += [(b, r, min(item_rows, r1 - r), 0) for r in range(r0, r1, item_rows)]
-            n = len(items)
             dev = self.bits.device
-            it = torch.tensor(items, dtype=torch.int32).reshape(n, 4).to(dev)
-            summ = torch.empty(max(n, 1), (self.L + 63) // 64, dtype=torch.int16, device=dev)
-            order = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-            if n:
-                call("vgpt_attn_plan_build", self.bits.data_ptr(), self.B, self.L, it.data_ptr(), n, item_rows,
-                     summ.data_ptr(), order.data_ptr(), _stream())
-            p = self._plans[key] = AttnPlan(it, summ, order, n, item_rows)
+            nkt = (self.L + 63) // 64
+
+            def build(its):
+                n_ = len(its)
+                it_ = torch.tensor(its, dtype=torch.int32).reshape(n_, 4).to(dev)
+                summ_ = torch.empty(max(n_, 1), nkt, dtype=torch.int16, device=dev)
+                order_ = torch.empty(max(n_, 1), dtype=torch.int32, device=dev)
+                if n_:
+                    call("vgpt_attn_plan_build", self.bits.data_ptr(), self.B, self.L, it_.data_ptr(), n_, item_rows,
+                         summ_.data_ptr(), order_.data_ptr(), _stream())
+                return it_, summ_, order_
+            it, summ, order = build(items)
+            split_items, split_ws_floats = None, 0
+            if split_keys and item_rows == 128 and len(items) > 1 and nkt <= 1023:
+                counts = (summ[: len(items)] != 0).sum(1).cpu().tolist()          # one-time, per mask
+                full = [c for c, t in zip(counts, items) if t[2] == item_rows and c > 0]
+                if full:
+                    target = min(full)
+                    final, slots, pbase = [], [], 0
+                    for c, (b, r, nr, _) in zip(counts, items):
+                        nparts = min(int(-(-c // target)) if c >= 1.4 * target else 1, 8)
+                        if nparts > 1 and pbase + nparts < 32768:
+                            slots.append((b, r, nr, nparts | (pbase << 8)))
+                            final += [(b, r, nr, part | (nparts << 8) | (pbase << 16)) for part in range(nparts)]
+                            pbase += nparts
+                        else:
+                            final.append((b, r, nr, 0))
+                    if slots:
+                        items = final
+                        it, summ, order = build(items)
+                        split_items = torch.tensor(slots, dtype=torch.int32).reshape(len(slots), 4).to(dev)
+                        split_ws_floats = pbase * 128
+            p = self._plans[key] = AttnPlan(it, summ, order, len(items), item_rows, split_items, split_ws_floats)
         return p
 
     def order(self, q_start: int = 0) -> torch.Tensor:
@@ -237,7 +276,8 @@ def pack_mask(mask: torch.Tensor) -> PackedMask:
 
 
 def attention_qkv(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: int, head_dim: int,
-                  scale: Optional[float] = None, out: Optional[torch.Tensor] = None, variant: int = 0):
+                  scale: Optional[float] = None, out: Optional[torch.Tensor] = None, variant: int = 0,
+                  split_keys: bool = False):
     """Attention on the fused (B, L, (n_q+2n_kv)*hd) projection buffer (RoPE already applied)."""
     _chk(qkv, BF16, "attention.qkv")
     B, L, width = qkv.shape
@@ -252,7 +292,8 @@ def attention_qkv(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: i
     vq = kq + n_kv_heads * head_dim * es
     sb, ss = L * width, width
     if variant in (0, 3):   # planned launch: 0 = 4-wave kernel on 128-row items, 3 = 8-wave kernel on 256-row items
-        _attn_plan_call(qkv.data_ptr(), kq, vq, out.data_ptr(), None, pm, pm.plan(None, 256 if variant == 3 else 128), B, L,
+        _attn_plan_call(qkv.data_ptr(), kq, vq, out.data_ptr(), None, pm,
+                        pm.plan(None, 256 if variant == 3 else 128, split_keys), B, L,
                         n_heads, n_kv_heads, head_dim,
                         (sb, head_dim, ss) * 3 + (L * n_heads * head_dim, head_dim, n_heads * head_dim), scale)
         return out
@@ -271,14 +312,16 @@ def attention_qkv(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: i
 
 def _attn_plan_call(q, k, v, o, lse, pm, plan, B, L, n_heads, n_kv_heads, head_dim, strides, scale):
     if plan.n_items:
+        ws = plan.workspace(n_heads, head_dim)
         call("vgpt_attn_fwd_plan", q, k, v, o, lse, pm.bits.data_ptr(), plan.items.data_ptr(), plan.summary.data_ptr(),
-             plan.order.data_ptr(), plan.n_items, plan.item_rows, B, L, n_heads, n_kv_heads, head_dim, *strides, float(scale),
-             _stream())
+             plan.order.data_ptr(), plan.n_items, plan.item_rows, _ptr(plan.split_items),
+             0 if plan.split_items is None else plan.split_items.shape[0], _ptr(ws), B, L, n_heads, n_kv_heads, head_dim,
+             *strides, float(scale), _stream())
 
 
 def attention_qkv_range(qkv_full: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: int, head_dim: int,
                         q_start: int, out_active: torch.Tensor, scale: Optional[float] = None, segments=None,
-                        item_rows: int = 128):
+                        item_rows: int = 128, split_keys: bool = False):
     """Attention of query rows [q_start, L) against all L rows of the fused (1, L, 3H-like) buffer; `out_active`
     holds the L - q_start computed rows (condition-prefix reuse, see include/vgpt.h).  segments: optional
     ((0, row_begin, row_end), ...) covering [q_start, L), cut where packed sequences meet."""
@@ -292,7 +335,7 @@ def attention_qkv_range(qkv_full: torch.Tensor, pm: PackedMask, n_heads: int, n_
     kq = qkv_full.data_ptr() + hq * 2
     vq = kq + n_kv_heads * head_dim * 2
     o_base = out_active.data_ptr() - q_start * hq * 2   # absolute-row addressing of the active output buffer
-    plan = pm.plan(segments if segments is not None else ((0, q_start, L),), item_rows)
+    plan = pm.plan(segments if segments is not None else ((0, q_start, L),), item_rows, split_keys)
     _attn_plan_call(qkv_full.data_ptr(), kq, vq, o_base, None, pm, plan, 1, L, n_heads, n_kv_heads, head_dim,
                     (L * width, head_dim, width) * 3 + (L * hq, head_dim, hq), scale)
     return out_active
