@@ -284,7 +284,7 @@ VGPT_EXPORT int vgpt_embed_gather(const int64_t* ids, const void* table, void* o
     VGPT_REQUIRE(rows >= 0 && H > 0 && vocab > 0, VGPT_ERR_INVALID, "vgpt_embed_gather: bad shape");
     VGPT_REQUIRE(H % 8 == 0, VGPT_ERR_UNSUPPORTED, "vgpt_embed_gather: H must be a multiple of 8");
     if (rows == 0) return VGPT_OK;
-    int grid = (int)std::min<int64_t>(cdiv(rows * (H / 8), 256), 256 * 16);
+    int grid = (int)std::min<int64_t>(cdiv(rows * (H / 8), 256), (int64_t)1 << 30);
     hipLaunchKernelGGL(embed_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids,
                        (const bf16*)table, (bf16*)out, rows, (int)H, vocab);
     VGPT_CHECK_LAUNCH("vgpt_embed_gather");

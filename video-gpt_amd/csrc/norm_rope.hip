@@ -201,7 +201,7 @@ VGPT_EXPORT int vgpt_rope_qk_inplace(void* qkv, const float* cos_t, const float*
     const int64_t row_stride = (int64_t)(n_q_heads + 2 * n_kv_heads) * head_dim;
     const int n_rot = n_q_heads + n_kv_heads;  // q heads then k heads are contiguous in qkv
     const int64_t total = tokens * n_rot * (head_dim / 16);
-    int grid = (int)std::min<int64_t>(cdiv(total, 256), 256 * 16);
+    int grid = (int)std::min<int64_t>(cdiv(total, 256), (int64_t)1 << 30);  // one element group per thread streams faster than a capped grid-stride loop
     hipLaunchKernelGGL(rope_qk_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16*)qkv,
                        cos_t, sin_t, tokens, n_rot, head_dim, row_stride);
     VGPT_CHECK_LAUNCH("vgpt_rope_qk_inplace");

