@@ -451,10 +451,14 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const T* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ void sumsq_final_kernel(const float* __restrict__ partial, int n_partial, float* __restrict__ out) {
+// one wave; lane i adds partials i, i+64, ... in order, then a fixed shuffle tree: deterministic, ~5 us instead of the
+// ~40 us of a single thread walking 1024 values
+__global__ __launch_bounds__(64) void sumsq_final_kernel(const float* __restrict__ partial, int n_partial,
+                                                         float* __restrict__ out) {
     float s = 0.f;
-    for (int i = 0; i < n_partial; ++i) s += partial[i];
-    *out += s;
+    for (int i = threadIdx.x; i < n_partial; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *out += s;
 }
 
 // AdamW (torch.optim.AdamW semantics) on fp32 master weights; bf16 model copy refreshed.
@@ -769,7 +773,7 @@ VGPT_EXPORT int vgpt_sumsq(const void* g, int g_f32, float* out, int64_t n, floa
     else
         hipLaunchKernelGGL(sumsq_partial_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)g,
                            partial_ws, n);
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, partial_ws, grid, out);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, grid, out);
     LAUNCH_OK("vgpt_sumsq");
 }
 
