@@ -227,14 +227,33 @@ __global__ __launch_bounds__(256) void matmul_splitk_reduce_kernel(const float* 
 }
 
 // ---- column sums: out[c] (+)= sum_r X[r][c] -------------------------------------------------------
+// block = 32 columns x 32 row lanes; a row lane sums rows lane, lane+32, ... (4 independent chains so the loads
+// overlap), then the 32 lane sums of a column are added in lane order: deterministic.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ out, int64_t R, int C,
-                                                     int64_t ld, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int64_t r = 0; r < R; ++r) s += (float)X[r * ld + c];
-    out[c] = accumulate ? out[c] + s : s;
+__global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ X, float* __restrict__ out, int64_t R, int C,
+                                                      int64_t ld, int accumulate) {
+    __shared__ float red[32][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int64_t r = rl;
+        for (; r + 96 < R; r += 128) {
+            s0 += (float)X[r * ld + c];
+            s1 += (float)X[(r + 32) * ld + c];
+            s2 += (float)X[(r + 64) * ld + c];
+            s3 += (float)X[(r + 96) * ld + c];
+        }
+        for (; r < R; r += 32) s0 += (float)X[r * ld + c];
+    }
+    red[rl][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s += red[i][cl];
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 // ---- loss -------------------------------------------------------------------------------------------
@@ -658,12 +677,12 @@ VGPT_EXPORT int vgpt_matmul_generic(const void* A, int a_f32, int64_t sa_m, int6
 VGPT_EXPORT int vgpt_colsum(const void* X, int x_f32, float* out, int64_t R, int64_t C, int64_t ld, int accumulate,
                             void* stream) {
     VGPT_REQUIRE(X && out && R >= 0 && C > 0, VGPT_ERR_INVALID, "vgpt_colsum: bad argument");
-    dim3 grid((unsigned)cdiv(C, 256));
+    dim3 grid((unsigned)cdiv(C, 32));
     if (x_f32)
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, out, R,
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(1024), 0, (hipStream_t)stream, (const float*)X, out, R,
                            (int)C, ld, accumulate);
     else
-        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)X, out, R, (int)C,
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(1024), 0, (hipStream_t)stream, (const bf16*)X, out, R, (int)C,
                            ld, accumulate);
     LAUNCH_OK("vgpt_colsum");
 }
