@@ -1,0 +1,152 @@
+"""TokenLayout (video-gpt_amd/layout.py): the per-token form of the attention mask.
+
+CPU: its dense expansion equals, bit for bit, the masks dumped from the REFERENCE'S OWN collator
+(tests/golden/ref_collator_*.npz) for all three layouts, and its re-layouts (dropping left pads and concatenating the
+rows; the alignment gap behind the condition prefix) equal the same operations done on the dense tensors
+(engine.pack_left_padded / StaticDenoiser).  GPU: the device expansion (vgpt_mask_build_tokens) equals the packed
+rows of the dense mask, bit for bit, and the sampler gives the same latents from either form."""
+import glob
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_collator import GOLD, load, product_fbtrain, product_inference, product_stage1
+
+LY = importlib.import_module("video-gpt_amd.layout")
+E = importlib.import_module("video-gpt_amd.engine")
+
+
+def names(pat):
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, pat)))
+
+
+def fb_lists(d):
+    flat = d["frame_blocks_flat"].tolist()
+    cut = flat.index(-1)
+    vals, lens = flat[:cut], flat[cut + 1:]
+    out, o = [], 0
+    for n in lens:
+        out.append(vals[o:o + n]); o += n
+    return out
+
+
+def golden_layouts():
+    for name in names("ref_collator_infer_*.npz"):
+        d, mask = load(name)
+        yield name, product_inference(int(d["C"]), int(d["G"]), int(d["N"]), int(d["sp"]), mask_format="layout")["attention_mask"], mask
+    for name in names("ref_collator_stage1_*.npz"):
+        d, mask = load(name)
+        yield name, product_stage1(d["F"].tolist(), int(d["N"]), mask_format="layout")["attention_mask"], mask
+    for name in names("ref_collator_fbtrain_*.npz"):
+        d, mask = load(name)
+        yield name, product_fbtrain(fb_lists(d), int(d["N"]), mask_format="layout")[2], mask
+
+
+CASES = list(golden_layouts())
+
+
+@pytest.mark.parametrize("name,lay,mask", CASES, ids=[c[0] for c in CASES])
+def test_dense_expansion_matches_reference_masks(name, lay, mask):
+    assert isinstance(lay, LY.TokenLayout) and lay.shape == mask.shape
+    assert np.array_equal(lay.to_bool(), mask)
+    a = lay.attr()
+    assert a.dtype == np.int32 and a.shape == (lay.B, lay.L, 2)
+
+
+@pytest.mark.parametrize("name,lay,mask", CASES, ids=[c[0] for c in CASES])
+def test_packing_matches_dense_packing(name, lay, mask):
+    m = torch.from_numpy(mask)
+    pads = E.count_left_pads(m)
+    assert lay.left_pads() == pads
+    B, L, _ = mask.shape
+    ids = torch.arange(B * L).view(B, L)
+    i1, p1, m1, o1 = E.pack_left_padded(ids, ids, m, pads)
+    i2, p2, l2, o2 = E.pack_left_padded(ids, ids, lay, pads)
+    assert torch.equal(i1, i2) and torch.equal(p1, p2) and o1 == o2
+    assert np.array_equal(l2.to_bool(), m1.numpy())
+
+
+def test_prefix_gap_matches_dense_insertion():
+    """cfg-2-shaped case at N=16: C=4 condition blocks, G=8 clip blocks, CFG row packed behind."""
+    lay = product_inference(4, 8, 16, 1, mask_format="layout")["attention_mask"]
+    pads = lay.left_pads()
+    packed, _ = lay.pack(pads)
+    dense = packed.to_bool()[0]
+    S0 = 4 * 18
+    assert packed.prefix_is_static(S0) and not bool(dense[:S0, S0:].any())
+    assert not packed.prefix_is_static(S0 + 5)       # rows of the clip see the rest of the clip
+    npad = 128 - S0
+    g = packed.insert_gap(S0, npad)
+    S, L2 = S0 + npad, packed.L + npad
+    want = np.zeros((L2, L2), dtype=bool)
+    want[:S0, :S0] = dense[:S0, :S0]
+    want[S:, :S0] = dense[S0:, :S0]
+    want[S:, S:] = dense[S0:, S0:]
+    assert np.array_equal(g.to_bool()[0], want)
+    assert not lay.prefix_is_static(S0, row=1)       # the CFG row's pad rows see everything
+
+
+def test_from_plans_rejects_bad_plans():
+    P = importlib.import_module("video-gpt_amd.processor")
+    kinds, _ = P.plan_inference([1, 1])
+    with pytest.raises(AssertionError):
+        LY.TokenLayout.from_plans([(kinds, 6, 0)], 13)
+    with pytest.raises(ValueError):
+        P.LVMCollator(mask_format="dense")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,lay,mask", CASES, ids=[c[0] for c in CASES])
+def test_device_expansion_is_bit_exact(ops, name, lay, mask):
+    dev = "cuda:0"
+    ref = ops.pack_mask(torch.from_numpy(mask).to(dev))
+    pm = lay.packed_mask(dev)
+    assert torch.equal(pm.bits, ref.bits) and torch.equal(pm.summary, ref.summary)
+    packed, _ = lay.pack()
+    ref2 = ops.pack_mask(torch.from_numpy(packed.to_bool()).to(dev))
+    pm2 = packed.packed_mask(dev)
+    assert torch.equal(pm2.bits, ref2.bits) and torch.equal(pm2.summary, ref2.summary)
+
+
+@pytest.mark.gpu
+def test_device_expansion_cfg4_shape_properties(ops):
+    """512^2, F=16 stage-1 layout (L = 31 806): the dense mask would be 1 GB per row, so the
+    check is by properties of the packed rows — visible-pair count against the closed form of the layout, no empty
+    row, nothing visible past L — and by exact comparison on a band of rows expanded on the host."""
+    P = importlib.import_module("video-gpt_amd.processor")
+    F, N = 16, 1024
+    bl = N + 2
+    kinds, _ = P.plan_stage1(2 * F - 1)
+    L = (2 * F - 1) * bl
+    lay = LY.TokenLayout.from_plans([(kinds, bl, 0)], L)
+    pm = lay.packed_mask("cuda:0")
+    assert pm.count_empty_rows() == 0
+    bits = pm.bits[0]                                                   # (L, W) int32
+    W = bits.shape[1]
+    if L % 32:
+        assert int((bits[:, W - 1].to(torch.int64) & 0xffffffff).max()) < (1 << (L % 32))
+    # closed form: a clean block is seen by itself (1 + (bl-1)*(bl-2) + 1 ... counted per key) and fully by later rows
+    clean_self = bl + (bl - 1) * (bl - 2) + 1                           # <img>: bl rows, slots: bl-1 rows each, </img>: 1
+    noisy_self = bl + (bl - 1) + (bl - 2) * (bl - 2)                    # <|diffusion|>, time, image slots
+    total = 0
+    for i, (kd, _) in enumerate(kinds):
+        later = L - (i + 1) * bl
+        total += (clean_self + bl * later) if kd == P.CLEAN else noisy_self
+    # (`later` counts every row behind a clean block, clean or noisy: both see it)
+    pop = 0
+    for r0 in range(0, L, 4096):
+        chunk = bits[r0:r0 + 4096].contiguous().view(torch.uint8)
+        pop += int(torch.from_numpy(np.unpackbits(chunk.cpu().numpy())).sum())
+    assert pop == total
+    band = slice(5 * bl - 3, 5 * bl + 5)                                # rows around a block boundary
+    q = np.arange(L)[:, None]
+    kq, kk = lay.kind[0][band, None], lay.kind[0][None, :]
+    vis = ((kk == LY.CLEAN) & (q[band] >= lay.thr[0][None, :])) | \
+          ((kk == LY.NOISY) & (kq == LY.NOISY) & (lay.grp[0][band, None] == lay.grp[0][None, :]) &
+           (lay.oc[0][band, None] >= lay.oc[0][None, :]))
+    got = np.unpackbits(bits[band].contiguous().view(torch.uint8).cpu().numpy(), axis=-1, bitorder="little")[:, :L]
+    assert np.array_equal(got.astype(bool), vis)

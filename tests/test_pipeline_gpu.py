@@ -75,3 +75,20 @@ def test_cfg_off_mirrors_reference_halving(pipe_case):
               prediction_type="x1", use_img_guidance=False)
     assert len(pipe.prompt_condition_frame_block_autoregressive_inference(**kw)) == 2 + 1   # reference's [:len//2]
     assert len(pipe.prompt_condition_frame_block_autoregressive_inference(halve_without_cfg=False, **kw)) == 2 + 2
+
+
+def test_layout_and_dense_masks_sample_the_same_clip(pipe_case):
+    """The collator's two mask forms (dense bool tensor as in the reference; per-token layout expanded on the device)
+    describe the same mask bit for bit, so the sampled latents are identical."""
+    cfg, vcfg, p, vp, pipe, frames = pipe_case
+    vnoise = [torch.randn(1, 4, 8, 8, generator=torch.Generator("cpu").manual_seed(70 + i)) for i in range(2)]
+    got = {}
+    for fmt in ("layout", "bool"):
+        pipe.mask_format = fmt
+        pipe.prompt_condition_frame_block_autoregressive_inference(
+            input_images=frames, height=64, width=64, gen_nums=[2], num_inference_steps=2, use_img_guidance=True,
+            img_guidance_scale=1.6, seed=7, output_type="pt", prediction_type="x1", generator_device="cpu",
+            vae_noise=vnoise)
+        got[fmt] = torch.cat(pipe.last_samples[0]).clone()
+    pipe.mask_format = "layout"
+    assert torch.equal(got["layout"], got["bool"])

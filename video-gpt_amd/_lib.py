@@ -34,6 +34,7 @@ SIGNATURES = {
     "vgpt_gated_mlp_act_fwd": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
     "vgpt_mask_pack_bool": (c_int, [_P, _P, _I64, _I64, _P]),
     "vgpt_mask_pack_additive": (c_int, [_P, c_int, _P, _I64, _I64, _P]),
+    "vgpt_mask_build_tokens": (c_int, [_P, _P, _I64, _I64, _P]),
     "vgpt_mask_tile_summary": (c_int, [_P, _P, _I64, _I64, _P]),
     "vgpt_mask_count_empty_rows": (c_int, [_P, _P, _I64, _I64, _P]),
     "vgpt_attn_blockmask_fwd": (

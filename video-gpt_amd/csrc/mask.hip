@@ -38,6 +38,36 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const T* __restrict__ ma
     }
 }
 
+// Mask rows straight from per-token attributes (video-gpt_amd/layout.py; the rule of LVM/processor.py:575-731 in closed
+// form): thread = one 32-key word of one query row.  attr[t] = { thr | seq << 24, kind | oc << 2 | grp << 4 }.
+enum { TK_PAD = 0, TK_CLEAN = 1, TK_NOISY = 2, TK_GAP = 3 };
+__global__ __launch_bounds__(256) void mask_tokens_kernel(const uint2* __restrict__ attr, uint32_t* __restrict__ bits,
+                                                          int L, int W, int wchunks) {
+    const int b = blockIdx.y;
+    const int q = (int)(blockIdx.x / (unsigned)wchunks);
+    const int w = (int)(blockIdx.x % (unsigned)wchunks) * 256 + threadIdx.x;
+    if (w >= W) return;
+    const uint2 aq = attr[(int64_t)b * L + q];
+    const uint32_t kq = aq.y & 3u, ocq = (aq.y >> 2) & 3u, gq = aq.y >> 4, sq = aq.x >> 24;
+    const int k0 = w * 32;
+    const int nk = min(32, L - k0);
+    uint32_t word = 0u;
+    if (kq == TK_PAD) {
+        word = nk == 32 ? 0xffffffffu : ((1u << nk) - 1u);  // pad rows see every column of the row
+    } else {
+        const uint2* ak = attr + (int64_t)b * L + k0;
+        for (int j = 0; j < nk; ++j) {
+            const uint2 a = ak[j];
+            const uint32_t kk = a.y & 3u;
+            bool vis = false;
+            if (kk == TK_CLEAN) vis = (a.x >> 24) == sq && (uint32_t)q >= (a.x & 0xffffffu);
+            else if (kk == TK_NOISY) vis = kq == TK_NOISY && (a.y >> 4) == gq && ocq >= ((a.y >> 2) & 3u);
+            word |= (uint32_t)vis << j;
+        }
+    }
+    bits[((int64_t)b * L + q) * W + w] = word;
+}
+
 // block = 4 waves = the four 32-row sub-blocks of one (b, 128-row q block, 64-key tile)
 __global__ __launch_bounds__(256) void mask_summary_kernel(const uint32_t* __restrict__ bits,
                                                            uint8_t* __restrict__ summary, int L,
@@ -139,6 +169,19 @@ VGPT_EXPORT int vgpt_mask_pack_additive(const void* mask, int is_f32, uint32_t* 
         hipLaunchKernelGGL(mask_pack_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const bf16*)mask, bits, B * L, (int)L, W);
     VGPT_CHECK_LAUNCH("vgpt_mask_pack_additive");
+    return VGPT_OK;
+}
+
+VGPT_EXPORT int vgpt_mask_build_tokens(const int32_t* attr, uint32_t* bits, int64_t B, int64_t L, void* stream) {
+    VGPT_REQUIRE(attr && bits, VGPT_ERR_INVALID, "vgpt_mask_build_tokens: null pointer");
+    VGPT_REQUIRE(B >= 0 && B < 65536 && L >= 0 && L < (1 << 24), VGPT_ERR_INVALID, "vgpt_mask_build_tokens: bad shape");
+    VGPT_REQUIRE(((uintptr_t)attr & 7) == 0, VGPT_ERR_UNSUPPORTED, "vgpt_mask_build_tokens: attr must be 8-byte aligned");
+    if (B == 0 || L == 0) return VGPT_OK;
+    const int W = (int)cdiv(L, 32), wchunks = (int)cdiv(W, 256);
+    VGPT_REQUIRE(L * wchunks < (1ll << 31), VGPT_ERR_UNSUPPORTED, "vgpt_mask_build_tokens: L too large");
+    hipLaunchKernelGGL(mask_tokens_kernel, dim3((unsigned)(L * wchunks), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint2*)attr, bits, (int)L, W, wchunks);
+    VGPT_CHECK_LAUNCH("vgpt_mask_build_tokens");
     return VGPT_OK;
 }
 

@@ -18,6 +18,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
+from .layout import TokenLayout
 from .ops import BF16, VgptError
 
 
@@ -32,6 +33,8 @@ def _rows(sizes: Dict[int, list], row_of, span: bool):
 def count_left_pads(attention_mask) -> List[int]:
     """Left-pad length of every row, read off the mask itself: pad rows are the leading all-ones rows
     (LVM/processor.py:726-727); a real first token only sees itself."""
+    if isinstance(attention_mask, TokenLayout):
+        return attention_mask.left_pads()
     B, L, _ = attention_mask.shape
     if L <= 1:
         return [0] * B
@@ -54,6 +57,8 @@ def pack_left_padded(input_ids, position_ids, attention_mask, pads: List[int]):
     M = sum(lens)
     ids = torch.cat([input_ids[b, pads[b]:] for b in range(B)]).view(1, M)
     pos = torch.cat([position_ids[b, pads[b]:] for b in range(B)]).view(1, M)
+    if isinstance(attention_mask, TokenLayout):   # tokens keep their sequence id: block-diagonal by construction
+        return ids.contiguous(), pos.contiguous(), attention_mask.pack(pads)[0], offsets
     mask = torch.zeros(1, M, M, dtype=torch.bool, device=attention_mask.device)
     for b in range(B):
         o, n, p = offsets[b], lens[b], pads[b]
@@ -90,8 +95,11 @@ class StaticDenoiser:
         self.S = 0          # static prefix length in the (padded) layout == first computed row, multiple of 128
         if reuse_condition_prefix and B == 1 and not isinstance(attention_mask, ops.PackedMask):
             t_first = min(row_of(b, t) for b in time_emb_inx.keys() for t in time_emb_inx[b]) - 1
-            m2 = attention_mask[0].to(torch.bool)
-            if t_first >= 128 and not bool(m2[:t_first, t_first:].any()):
+            is_layout = isinstance(attention_mask, TokenLayout)
+            m2 = None if is_layout else attention_mask[0].to(torch.bool)
+            static = t_first >= 128 and (attention_mask.prefix_is_static(t_first) if is_layout
+                                         else not bool(m2[:t_first, t_first:].any()))
+            if static:
                 S0 = t_first
                 S = (S0 + 127) // 128 * 128
                 npad = S - S0
@@ -101,11 +109,14 @@ class StaticDenoiser:
                 position_ids = torch.cat([position_ids[:, :S0], torch.zeros(1, npad, dtype=position_ids.dtype, device=dev0),
                                           position_ids[:, S0:]], dim=1)
                 L2 = L + npad
-                mask2 = torch.zeros(1, L2, L2, dtype=torch.bool, device=m2.device)
-                mask2[0, :S0, :S0] = m2[:S0, :S0]
-                mask2[0, S:, :S0] = m2[S0:, :S0]
-                mask2[0, S:, S:] = m2[S0:, S0:]
-                attention_mask = mask2
+                if is_layout:
+                    attention_mask = attention_mask.insert_gap(S0, npad)
+                else:
+                    mask2 = torch.zeros(1, L2, L2, dtype=torch.bool, device=m2.device)
+                    mask2[0, :S0, :S0] = m2[:S0, :S0]
+                    mask2[0, S:, :S0] = m2[S0:, :S0]
+                    mask2[0, S:, S:] = m2[S0:, S0:]
+                    attention_mask = mask2
                 prev = row_of
                 row_of = lambda b, s, prev=prev, S0=S0, npad=npad: (lambda r: r if r < S0 else r + npad)(prev(b, s))
                 L = L2
@@ -137,7 +148,7 @@ class StaticDenoiser:
 
         # static inputs
         self.input_ids = input_ids.contiguous()
-        self.pm = attention_mask if isinstance(attention_mask, ops.PackedMask) else ops.pack_mask(attention_mask)
+        self.pm = ops.as_packed_mask(attention_mask, dev)
         self.rope = model.llm.rope_tables(position_ids)
         i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
         self.cond = None

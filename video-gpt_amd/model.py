@@ -175,7 +175,7 @@ class Phi3Attention(nn.Module):
         if output_attentions:
             raise VgptError("output_attentions is not supported by the fused attention kernel")
         B, L, _ = hidden_states.shape
-        pm = attention_mask if isinstance(attention_mask, ops.PackedMask) else ops.pack_mask(attention_mask)
+        pm = ops.as_packed_mask(attention_mask, hidden_states.device)
         if rope is None:
             inv = ops.rope_inv_freq(self.head_dim, self.config.rope_theta, hidden_states.device)
             rope = ops.rope_table(position_ids.contiguous(), inv)
@@ -259,8 +259,8 @@ class Phi3Transformer(nn.Module):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
         if inputs_embeds is None:
             inputs_embeds = ops.embed_gather(input_ids.contiguous(), self.embed_tokens.weight)
-        if isinstance(attention_mask, ops.PackedMask):
-            pm = attention_mask
+        if isinstance(attention_mask, ops.PackedMask) or hasattr(attention_mask, "packed_mask"):
+            pm = ops.as_packed_mask(attention_mask, inputs_embeds.device)   # packed already, or a layout.TokenLayout
         elif attention_mask is not None and attention_mask.dim() == 3:
             pm = ops.pack_mask(attention_mask)
         else:  # OmniGen/transformer.py:150-151

@@ -275,6 +275,30 @@ def pack_mask(mask: torch.Tensor) -> PackedMask:
     return PackedMask(bits, summary, B, L)
 
 
+def build_mask_from_layout(attr: torch.Tensor, B: int, L: int) -> PackedMask:
+    """attr: (B, L, 2) int32 token attributes on the GPU (layout.TokenLayout.attr) -> packed rows + tile summary,
+    generated on the device (include/vgpt.h, vgpt_mask_build_tokens); no (B,L,L) tensor exists at any point."""
+    if not attr.is_cuda:
+        raise VgptError("build_mask_from_layout: expected a GPU tensor")
+    if attr.dtype != torch.int32 or tuple(attr.shape) != (B, L, 2) or not attr.is_contiguous():
+        raise VgptError("build_mask_from_layout: attr must be a contiguous (B, L, 2) int32 tensor")
+    bits, summary = _alloc_mask(B, L, attr.device)
+    call("vgpt_mask_build_tokens", attr.data_ptr(), bits.data_ptr(), B, L, _stream())
+    call("vgpt_mask_tile_summary", bits.data_ptr(), summary.data_ptr(), B, L, _stream())
+    return PackedMask(bits, summary, B, L)
+
+
+def as_packed_mask(mask, device=None) -> PackedMask:
+    """PackedMask | layout.TokenLayout | (B,L,L) bool | additive (B,1,L,L) -> PackedMask."""
+    if isinstance(mask, PackedMask):
+        return mask
+    if hasattr(mask, "packed_mask"):
+        if device is None:
+            raise VgptError("as_packed_mask: a TokenLayout needs the target device")
+        return mask.packed_mask(device)
+    return pack_mask(mask)
+
+
 def attention_qkv(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: int, head_dim: int,
                   scale: Optional[float] = None, out: Optional[torch.Tensor] = None, variant: int = 0,
                   split_keys: bool = False):

@@ -39,6 +39,7 @@ class LVMPipeline:
         self.vae.eval()
         self.model_cpu_offload = False
         self.last_latents = None
+        self.mask_format = "layout"   # "bool": have the collator paint the reference's dense (B,L,L) mask instead
 
     @classmethod
     def from_pretrained(cls, model_name, vae_path: str = None, load_llm_ckpt=True):
@@ -133,6 +134,9 @@ class LVMPipeline:
                 prompts, images = [prompt], [list(input_images)]
             if max_input_image_size != self.processor.max_image_size:
                 self.processor = LVMProcessor(self.processor.text_tokenizer, max_image_size=max_input_image_size)
+            # the sampler path never materialises the (B,L,L) mask: the collator hands over per-token attributes and
+            # the device expands them into the packed rows the attention kernel reads (layout.TokenLayout)
+            self.processor.collator.mask_format = self.mask_format
             self.model.to(self.device, dtype)
             input_data = self.processor.prompt_condition_frame_block_inference(
                 prompts, images, height=height, width=width, use_img_cfg=use_img_guidance,

@@ -29,6 +29,8 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
+from .layout import TokenLayout
+
 PAD, CLEAN, NOISY = 0, 1, 2
 
 
@@ -97,7 +99,15 @@ def block_mask(kinds, bl: int, pad: int, out: Optional[np.ndarray] = None) -> np
 # ------------------------------------------------------------------------------------------------
 
 class LVMCollator:
-    def __init__(self, pad_token_id: int = 2, hidden_size: int = 3072, sequence_parallel_size: int = 1):
+    """mask_format "bool" (default): `attention_mask` is the reference's dense (B,L,L) bool tensor; "layout": it is a
+    layout.TokenLayout (8 bytes per token) from which the device generates the packed mask — the model, the engine
+    and the trainer take either."""
+
+    def __init__(self, pad_token_id: int = 2, hidden_size: int = 3072, sequence_parallel_size: int = 1,
+                 mask_format: str = "bool"):
+        if mask_format not in ("bool", "layout"):
+            raise ValueError(f"unknown mask_format {mask_format!r}")
+        self.mask_format = mask_format
         self.pad_token_id = pad_token_id
         self.hidden_size = hidden_size
         self.sequence_parallel_size = sequence_parallel_size
@@ -164,9 +174,14 @@ class LVMCollator:
         return torch.from_numpy(np.stack(rows)), block_ls
 
     # -- masks --
-    @staticmethod
-    def _masks(attention_mask, block_ls, plans):
+    def _masks(self, attention_mask, block_ls, plans):
         seq_len = attention_mask.size(-1)
+        if self.mask_format == "layout":
+            rows = []
+            for i in range(attention_mask.size(0)):
+                valid = int(attention_mask[i].sum())
+                rows.append((plans(i, valid // block_ls[i]), block_ls[i], seq_len - valid))
+            return TokenLayout.from_plans(rows, seq_len)
         out = np.zeros((attention_mask.size(0), seq_len, seq_len), dtype=np.uint8)   # written in place, 0/1 bytes
         for i in range(attention_mask.size(0)):
             valid = int(attention_mask[i].sum())
@@ -286,11 +301,12 @@ class LVMProcessor:
 
     _TAG = re.compile(r"<\|image_\d+\|>")
 
-    def __init__(self, text_tokenizer=None, max_image_size: int = 1024, sequence_parallel_size: int = 1):
+    def __init__(self, text_tokenizer=None, max_image_size: int = 1024, sequence_parallel_size: int = 1,
+                 mask_format: str = "bool"):
         self.text_tokenizer = text_tokenizer if text_tokenizer is not None else SpecialTokenizer()
         self.max_image_size = max_image_size
         self.sequence_parallel_size = sequence_parallel_size
-        self.collator = LVMCollator(sequence_parallel_size=sequence_parallel_size)
+        self.collator = LVMCollator(sequence_parallel_size=sequence_parallel_size, mask_format=mask_format)
 
     @classmethod
     def from_pretrained(cls, model_name, sequence_parallel_size: int = 1):

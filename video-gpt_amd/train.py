@@ -131,7 +131,7 @@ class Stage1Trainer:
             keep[r0:r0 + ntok_x] = 0
         for r0 in t_rows:
             keep[r0] = 0
-        return dict(ids=ids.contiguous(), B=B, L=L, pm=ops.pack_mask(mask), rope=self.model.llm.rope_tables(pos),
+        return dict(ids=ids.contiguous(), B=B, L=L, pm=ops.as_packed_mask(mask, self.dev), rope=self.model.llm.rope_tables(pos),
                     x_rows=i32(x_rows), t_rows=i32(t_rows), c_rows=i32(c_rows) if c_rows else None,
                     keep=keep.to(self.dev), ntok=ntok_x)
 
