@@ -39,33 +39,43 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const T* __restrict__ ma
 }
 
 // Mask rows straight from per-token attributes (video-gpt_amd/layout.py; the rule of LVM/processor.py:575-731 in closed
-// form): thread = one 32-key word of one query row.  attr[t] = { thr | seq << 24, kind | oc << 2 | grp << 4 }.
+// form).  attr[t] = { thr | seq << 24, kind | oc << 2 | grp << 4 }.  Block = 256 consecutive query rows x 4 words
+// (128 keys): the key attributes are the same for every lane (scalar loads), each lane keeps its own row's attributes
+// in registers and writes its 4 words.
 enum { TK_PAD = 0, TK_CLEAN = 1, TK_NOISY = 2, TK_GAP = 3 };
 __global__ __launch_bounds__(256) void mask_tokens_kernel(const uint2* __restrict__ attr, uint32_t* __restrict__ bits,
-                                                          int L, int W, int wchunks) {
+                                                          int L, int W, int wgroups) {
     const int b = blockIdx.y;
-    const int q = (int)(blockIdx.x / (unsigned)wchunks);
-    const int w = (int)(blockIdx.x % (unsigned)wchunks) * 256 + threadIdx.x;
-    if (w >= W) return;
-    const uint2 aq = attr[(int64_t)b * L + q];
+    const int q = (int)(blockIdx.x / (unsigned)wgroups) * 256 + threadIdx.x;
+    const int w0 = (int)(blockIdx.x % (unsigned)wgroups) * 4;
+    const uint2 aq = attr[(int64_t)b * L + min(q, L - 1)];
     const uint32_t kq = aq.y & 3u, ocq = (aq.y >> 2) & 3u, gq = aq.y >> 4, sq = aq.x >> 24;
-    const int k0 = w * 32;
-    const int nk = min(32, L - k0);
-    uint32_t word = 0u;
-    if (kq == TK_PAD) {
-        word = nk == 32 ? 0xffffffffu : ((1u << nk) - 1u);  // pad rows see every column of the row
-    } else {
-        const uint2* ak = attr + (int64_t)b * L + k0;
+    const uint2* ak = attr + (int64_t)b * L;
+    uint32_t word[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k0 = (w0 + i) * 32;
+        const int nk = min(32, L - k0);  // <= 0 for words past the row (not stored)
+        uint32_t wd = 0u;
         for (int j = 0; j < nk; ++j) {
-            const uint2 a = ak[j];
+            const uint2 a = ak[k0 + j];  // wave-uniform address
             const uint32_t kk = a.y & 3u;
-            bool vis = false;
-            if (kk == TK_CLEAN) vis = (a.x >> 24) == sq && (uint32_t)q >= (a.x & 0xffffffu);
-            else if (kk == TK_NOISY) vis = kq == TK_NOISY && (a.y >> 4) == gq && ocq >= ((a.y >> 2) & 3u);
-            word |= (uint32_t)vis << j;
+            const bool clean = kk == TK_CLEAN && (a.x >> 24) == sq && (uint32_t)q >= (a.x & 0xffffffu);
+            const bool noisy = kk == TK_NOISY && kq == TK_NOISY && (a.y >> 4) == gq && ocq >= ((a.y >> 2) & 3u);
+            wd |= (uint32_t)(clean || noisy) << j;
         }
+        if (kq == TK_PAD) wd = nk >= 32 ? 0xffffffffu : (nk > 0 ? (1u << nk) - 1u : 0u);  // pad rows see the whole row
+        word[i] = wd;
     }
-    bits[((int64_t)b * L + q) * W + w] = word;
+    if (q >= L) return;
+    uint32_t* out = bits + ((int64_t)b * L + q) * W + w0;
+    if ((W & 3) == 0) {
+        *reinterpret_cast<uint4*>(out) = uint4{word[0], word[1], word[2], word[3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (w0 + i < W) out[i] = word[i];
+    }
 }
 
 // block = 4 waves = the four 32-row sub-blocks of one (b, 128-row q block, 64-key tile)
@@ -177,10 +187,11 @@ VGPT_EXPORT int vgpt_mask_build_tokens(const int32_t* attr, uint32_t* bits, int6
     VGPT_REQUIRE(B >= 0 && B < 65536 && L >= 0 && L < (1 << 24), VGPT_ERR_INVALID, "vgpt_mask_build_tokens: bad shape");
     VGPT_REQUIRE(((uintptr_t)attr & 7) == 0, VGPT_ERR_UNSUPPORTED, "vgpt_mask_build_tokens: attr must be 8-byte aligned");
     if (B == 0 || L == 0) return VGPT_OK;
-    const int W = (int)cdiv(L, 32), wchunks = (int)cdiv(W, 256);
-    VGPT_REQUIRE(L * wchunks < (1ll << 31), VGPT_ERR_UNSUPPORTED, "vgpt_mask_build_tokens: L too large");
-    hipLaunchKernelGGL(mask_tokens_kernel, dim3((unsigned)(L * wchunks), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
-                       (const uint2*)attr, bits, (int)L, W, wchunks);
+    const int W = (int)cdiv(L, 32), wgroups = (int)cdiv(W, 4);
+    VGPT_REQUIRE(cdiv(L, 256) * wgroups < (1ll << 31), VGPT_ERR_UNSUPPORTED, "vgpt_mask_build_tokens: L too large");
+    VGPT_REQUIRE(((uintptr_t)bits & 15) == 0, VGPT_ERR_UNSUPPORTED, "vgpt_mask_build_tokens: bits must be 16-byte aligned");
+    hipLaunchKernelGGL(mask_tokens_kernel, dim3((unsigned)(cdiv(L, 256) * wgroups), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, (const uint2*)attr, bits, (int)L, W, wgroups);
     VGPT_CHECK_LAUNCH("vgpt_mask_build_tokens");
     return VGPT_OK;
 }
