@@ -27,10 +27,18 @@
 #ifndef VGPT_GEMM_SETPRIO
 #define VGPT_GEMM_SETPRIO 0
 #endif
+// Diagnostics build (make gemm-debug-N, results are garbage): 1 = skip the LDS-DMA staging, 2 = skip the LDS fragment
+// reads, 3 = both.  A COMPILE-time switch: as a run-time flag the skipped reads became conditional, and at the join
+// hipcc's s_waitcnt insertion assumes the shorter path — every MFMA phase then waited for the fragment reads issued
+// right in front of it (lgkmcnt(3..0) instead of (7..4)), exposing the LDS latency twice per k-tile.
+#ifndef VGPT_GEMM_DEBUG_BUILD
+#define VGPT_GEMM_DEBUG_BUILD 0
+#endif
 
 namespace {
 
 constexpr int BK = 64;
+constexpr int kDebug = VGPT_GEMM_DEBUG_BUILD;
 
 // Tile configuration: BM x BN block tile, WM x WN waves, every wave owns (BM/WM) x (BN/WN).
 //   Cfg128: 128x128, 2x2 waves of 64x64   (64 KiB LDS, 2 blocks/CU)  — small problems
@@ -61,7 +69,6 @@ struct GemmArgs {
     int act;   // gated mode
     int I;     // gated mode: intermediate size
     int tiles_m, tiles_n;
-    int debug;  // diagnostics only (VGPT_GEMM_DEBUG): 1 = skip the LDS-DMA staging, 2 = skip the LDS fragment reads
 };
 
 __device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     char* sW = smem + 2 * C::A_BYTES;   // [2][W_BYTES]
 
     auto stage = [&](int buf, int kt) {
-        if (g.debug & 1) return;
+        if constexpr (kDebug & 1) return;
 #pragma unroll
         for (int i = 0; i < C::A_SLABS; ++i)
             a_issue(i, kt, sA + buf * C::A_BYTES + (wave * C::A_SLABS + i) * 1024);
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         // the LAST phase of a tile so the first fragments of tile kt+1 are prefetched under tile kt.
         static_assert(MI == 8 && NI == 4, "pipelined loop is written for the 256x256 / 2x4-wave tile");
         bf16x8 Wf[2][4], Af[2][4];
-        if (g.debug & 2) {
+        if constexpr ((kDebug & 2) != 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                 }
         }
         auto ldW = [&](bf16x8(&dst)[4], int buf, int ks) {
-            if (g.debug & 2) return;
+            if constexpr (kDebug & 2) return;
             if constexpr (WTR) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dst[i] = ld_tr(sW + buf * C::W_BYTES, 2 * BN, ks, wn * 4 + i);
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             }
         };
         auto ldA = [&](bf16x8(&dst)[4], int buf, int ks, int mh) {
-            if (g.debug & 2) return;
+            if constexpr (kDebug & 2) return;
             if constexpr (ATR) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dst[j] = ld_tr(sA + buf * C::A_BYTES, 2 * BM, ks, wm * 8 + mh * 4 + j);
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             if (getenv_prio) __builtin_amdgcn_s_setprio(0);
         };
         auto stage_half = [&](int buf, int kt, int half) {
-            if (g.debug & 1) return;
+            if constexpr (kDebug & 1) return;
 #pragma unroll
             for (int i = 0; i < C::A_SLABS / 2; ++i) {
                 const int ii = half * (C::A_SLABS / 2) + i;
@@ -439,11 +446,6 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     }
     g.tiles_m = (int)cdiv(g.M, C::BM);
     g.tiles_n = (int)cdiv(n_out, MODE == MODE_GATED ? C::BN / 2 : C::BN);
-    {
-        static int dbg = -1;
-        if (dbg < 0) { const char* e = getenv("VGPT_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-        g.debug = dbg;
-    }
     hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>), dim3(g.tiles_m * g.tiles_n), dim3(C::THREADS),
                        C::LDS_BYTES, s, g);
     VGPT_CHECK_LAUNCH(name);
