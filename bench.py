@@ -259,6 +259,8 @@ def main():
                     help="skip the short stage-1 data-parallel training measurement appended to the default line")
     ap.add_argument("--no-prefix-reuse", action="store_true",
                     help="recompute the condition frames at every step exactly as the reference does")
+    ap.add_argument("--no-hoist", action="store_true",
+                    help="keep the <|diffusion|> / time rows of the noisy frames in the per-step row set (engine.py)")
     ap.add_argument("--vae-precision", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="vae / pipeline workloads: arithmetic of the 3x3 convolutions (video-gpt_amd/vae.py)")
     ap.add_argument("--breakdown", action="store_true", help="add per-operator HIP-event times of one eager denoise step")
@@ -304,12 +306,13 @@ def main():
     cfg = full_config(M, args.layers)
     model = build_model(M, cfg, device, seed=0)
     tok = P.SpecialTokenizer(10, 11, 12)
-    proc = P.LVMProcessor(tok)
+    proc = P.LVMProcessor(tok, mask_format="layout")   # per-token mask attributes, as LVMPipeline asks for
     prompt = "".join(f"<img><|image_{i + 1}|></img>" if i < C else f"<|diffusion|><|image_{i + 1}|>" for i in range(C + G))
     prompt_ = "".join(f"<|diffusion|><|image_{i + 1}|>" for i in range(G))
     imgs = [torch.zeros(3, hw[0] * 8, hw[1] * 8) for _ in range(C)]
     batch = proc.prompt_condition_frame_block_inference([prompt, prompt_], [imgs, []], height=hw[0] * 8, width=hw[1] * 8,
                                                         use_img_cfg=True, frame_blocks=[C, G])
+    dense_mask = batch["attention_mask"].to_bool_tensor()   # only to count the visible pairs (algorithmic FLOPs)
     g = torch.Generator("cpu").manual_seed(42 + rank)
     noise = [torch.randn(1, 4, *hw, generator=g) for _ in range(G)]
     z = [n.to(device, BF) for n in noise] * 2
@@ -317,21 +320,22 @@ def main():
     total_steps = args.warmup + args.steps
     sched = S.LVMScheduler(num_steps=max(total_steps, 1), time_shifting_factor=1)
     eng = E.StaticDenoiser(model, batch["input_ids"].to(device), batch["position_ids"].to(device),
-                           batch["attention_mask"].to(device), cond, batch["input_image_sizes"],
+                           batch["attention_mask"], cond, batch["input_image_sizes"],
                            batch["denoise_image_sizes"], batch["time_emb_inx"], len(z), hw, True, 1.6, "x1",
-                           sigma=sched.sigma, reuse_condition_prefix=not args.no_prefix_reuse)
+                           sigma=sched.sigma, reuse_condition_prefix=not args.no_prefix_reuse,
+                           hoist_special_rows=not args.no_hoist)
 
     B, L = batch["input_ids"].shape
     valid = batch["input_ids"] != 2
     real_tokens = int(valid.sum())
     H, I, nl = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
-    pairs = visible_pairs(batch["attention_mask"], valid)
+    pairs = visible_pairs(dense_mask, valid)
     reuse = eng.S > 0
     if reuse:
         # condition prefix computed once per clip (timed: one prefill per timed region): per-step algorithmic work
         # is the reduced count of SURVEY.md §8d (34.11 TF at cfg-2), the prefill (7.6 TF) is added to the total
         static_tok = C * (N + 2)
-        pairs_static = int(batch["attention_mask"][0, :static_tok].sum().item())
+        pairs_static = int(dense_mask[0, :static_tok].sum().item())
         real_tokens_step, pairs_step = real_tokens - static_tok, pairs - pairs_static
     else:
         real_tokens_step, pairs_step = real_tokens, pairs
@@ -353,6 +357,8 @@ def main():
         def timed():
             if reuse:
                 eng.prefill()          # once per clip; inside the timed region
+                if eng.hoist:
+                    eng._time_pass()   # the special rows of every step, also once per clip
             eng.run(args.steps, use_graph=use_graph)
         elapsed = D.timed_region(timed, torch.cuda.synchronize, device)
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
@@ -385,7 +391,9 @@ def main():
             stream.synchronize()
         t_gemm = sum(s.elapsed_time(e) for s, e in ev) * 1e-3
         n_launch = len(ev)
-        alg = 2 * (4 * H * H + H * I) * real_tokens_step * nl  # qkv (3H^2) + o (H^2) + down (HI), computed tokens
+        # qkv (3H^2) + o (H^2) + down (HI) over the rows this forward_step ran (with special-row hoisting the 2 special
+        # tokens of every noisy frame are computed in the per-clip pass instead: n_frames x N rows per step)
+        alg = 2 * (4 * H * H + H * I) * (eng.Ma if reuse else real_tokens_step) * nl
         achieved = alg / t_gemm / 1e12
         traffic = None  # per-launch bytes beyond L2 from the committed PMC passes (profiles/r01_pmc_traffic_v2.json, scripts/pmc_traffic.py)
         try:

@@ -235,6 +235,15 @@ int vgpt_euler_cfg_update(float* z, void* z_model, const void* pred, const float
                           int use_cfg, float cfg_scale, void* stream);
 /* *step += 1 */
 int vgpt_sampler_advance(int32_t* step, void* stream);
+/* dst[l][0:slab_bytes] = src[*step][l][0:slab_bytes] for l < n_layers (step clamped to [0, n_steps)); all sizes and
+ * strides in bytes, multiples of 16.  The engine keeps the post-RoPE q/k/v rows of the time tokens of every denoise
+ * step (they depend on the step only: a time row sees `<|diffusion|>` and time columns, never image columns,
+ * LVM/processor.py:682-731) and drops the current step's rows into the per-layer qkv buffer; the reference recomputes
+ * them inside every model call (LVM/scheduler.py:174 -> LVM/model.py:446-449).  Reads the step from device memory:
+ * capturable. */
+int vgpt_sampler_copy_step_rows(const void* src, void* dst, const int32_t* step, int n_steps, int n_layers,
+                                int64_t slab_bytes, int64_t src_step_stride_bytes, int64_t src_layer_stride_bytes,
+                                int64_t dst_layer_stride_bytes, void* stream);
 /* z_model = bf16(z) */
 int vgpt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 

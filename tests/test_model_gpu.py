@@ -184,3 +184,39 @@ def test_condition_prefix_reuse_matches_full_recompute():
     ref = torch.cat(SC.oracle_sample(cfg, p, batch, z, cond, 3, "x1"))
     assert SC.rel_l2(outs[True], ref) < TOL
     assert SC.rel_l2(outs[True], outs[False]) < 5e-3
+
+
+@pytest.mark.parametrize("use_cfg", [True, False])
+def test_special_row_hoisting_matches_full_recompute(use_cfg):
+    """`<|diffusion|>` rows are step-invariant and time rows depend on the step only (neither sees an image column), so
+    the engine computes them for all steps in one pass and runs only the image rows per step.  Same result as the
+    reference's full recompute, and as prefix reuse alone."""
+    from tests.test_collator import product_inference
+    cfg = R.TINY
+    C, G, hw, steps = 2, 2, (16, 16), 3
+    p, batch, z, cond = SC.build_case(cfg, C=C, G=G, hw=hw, use_cfg=use_cfg)
+    lay = product_inference(C, G, 64, mask_format="layout")["attention_mask"]
+    if not use_cfg:
+        LY = importlib.import_module("video-gpt_amd.layout")
+        lay = LY.TokenLayout(lay.thr[:1], lay.seq[:1], lay.kind[:1], lay.oc[:1], lay.grp[:1])
+    assert torch.equal(lay.to_bool_tensor(), batch["attention_mask"].to(torch.bool))
+    model = SC.build_product_model(cfg, p, DEV)
+    S = importlib.import_module("video-gpt_amd.scheduler")
+    outs = {}
+    for mode in ("hoist", "prefix", "none"):
+        sched = S.LVMScheduler(num_steps=steps)
+        sched.reuse_condition_prefix = mode != "none"
+        sched.hoist_special_rows = mode == "hoist"
+        kw = SC.model_kwargs(batch, cond, DEV, use_cfg=use_cfg)
+        kw["attention_mask"] = lay
+        outs[mode] = torch.cat(sched([x.to(DEV, BF) for x in z], model.frame_block_forward_with_cfg, kw,
+                                     prediction_type="x1"))
+        eng = sched.last_engine
+        assert bool(eng.hoist) == (mode == "hoist")
+        if mode == "hoist":
+            nf = len(z)
+            assert eng.S0 == C * 66 and eng.S == 256 and eng.Ma == nf * 64      # image rows only
+            assert eng.time_qkv.shape[:3] == (steps, cfg.num_hidden_layers, nf)
+    ref = torch.cat(SC.oracle_sample(cfg, p, batch, z, cond, steps, "x1", use_cfg=use_cfg))
+    assert SC.rel_l2(outs["hoist"], ref) < TOL
+    assert SC.rel_l2(outs["hoist"], outs["none"]) < 5e-3 and SC.rel_l2(outs["hoist"], outs["prefix"]) < 5e-3

@@ -57,6 +57,7 @@ SIGNATURES = {
     "vgpt_sampler_set_timesteps": (c_int, [_P, _P, _P, c_int, _P]),
     "vgpt_euler_cfg_update": (c_int, [_P, _P, _P, _P, _P, c_int, _I64, c_int, c_int, c_float, _P]),
     "vgpt_sampler_advance": (c_int, [_P, _P]),
+    "vgpt_sampler_copy_step_rows": (c_int, [_P, _P, _P, c_int, c_int, _I64, _I64, _I64, _I64, _P]),
     "vgpt_cast_f32_to_bf16": (c_int, [_P, _P, _I64, _P]),
     "vgpt_groupnorm_stats": (c_int, [_P, _P, _I64, c_int, c_int, c_int, c_float, _P]),
     "vgpt_conv2d_fwd": (c_int, [_P] * 8 + [c_int] * 11 + [_I64, _I64, _P]),

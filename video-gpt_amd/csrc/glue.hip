@@ -410,6 +410,35 @@ VGPT_EXPORT int vgpt_euler_cfg_update(float* z, void* z_model, const void* pred,
     return VGPT_OK;
 }
 
+// dst[l][0:slab] = src[*step][l][0:slab] for every layer l, in 16-byte units (the time-token rows of the current step)
+__global__ __launch_bounds__(256) void copy_step_slab_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                             const int32_t* __restrict__ step, int n_steps, int64_t slab,
+                                                             int64_t src_step_stride, int64_t src_layer_stride,
+                                                             int64_t dst_layer_stride, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int s = min(max(*step, 0), n_steps - 1);
+    const int64_t l = i / slab, o = i % slab;
+    dst[l * dst_layer_stride + o] = src[s * src_step_stride + l * src_layer_stride + o];
+}
+
+VGPT_EXPORT int vgpt_sampler_copy_step_rows(const void* src, void* dst, const int32_t* step, int n_steps, int n_layers,
+                                            int64_t slab_bytes, int64_t src_step_stride_bytes,
+                                            int64_t src_layer_stride_bytes, int64_t dst_layer_stride_bytes, void* stream) {
+    VGPT_REQUIRE(src && dst && step, VGPT_ERR_INVALID, "vgpt_sampler_copy_step_rows: null pointer");
+    VGPT_REQUIRE(n_steps > 0 && n_layers >= 0 && slab_bytes >= 0, VGPT_ERR_INVALID, "vgpt_sampler_copy_step_rows: bad shape");
+    VGPT_REQUIRE(((slab_bytes | src_step_stride_bytes | src_layer_stride_bytes | dst_layer_stride_bytes) & 15) == 0 &&
+                     (((uintptr_t)src | (uintptr_t)dst) & 15) == 0,
+                 VGPT_ERR_UNSUPPORTED, "vgpt_sampler_copy_step_rows: sizes, strides and pointers must be multiples of 16 bytes");
+    const int64_t slab = slab_bytes / 16, total = slab * n_layers;
+    if (total == 0) return VGPT_OK;
+    hipLaunchKernelGGL(copy_step_slab_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)src, (uint4*)dst, step, n_steps, slab, src_step_stride_bytes / 16,
+                       src_layer_stride_bytes / 16, dst_layer_stride_bytes / 16, total);
+    VGPT_CHECK_LAUNCH("vgpt_sampler_copy_step_rows");
+    return VGPT_OK;
+}
+
 VGPT_EXPORT int vgpt_sampler_advance(int32_t* step, void* stream) {
     VGPT_REQUIRE(step, VGPT_ERR_INVALID, "vgpt_sampler_advance: null pointer");
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);

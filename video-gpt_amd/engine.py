@@ -70,7 +70,7 @@ class StaticDenoiser:
     def __init__(self, model, input_ids, position_ids, attention_mask, input_img_latents, input_image_sizes,
                  denoise_image_sizes, time_emb_inx, n_frames: int, latent_hw, use_img_cfg: bool, img_cfg_scale: float,
                  prediction_type: str = "v", sigma: Optional[torch.Tensor] = None, pack_padding: bool = True,
-                 reuse_condition_prefix: bool = False):
+                 reuse_condition_prefix: bool = False, hoist_special_rows: bool = True):
         model._check_ready()
         self.model = model
         cfg = model.llm.config
@@ -93,13 +93,40 @@ class StaticDenoiser:
         #      step; the reference recomputes them 50x (LVM/scheduler.py:174).  They are computed ONCE (prefill),
         #      their per-layer K/V stay in a full-length qkv buffer, and a step only runs the remaining rows. ----
         self.S = 0          # static prefix length in the (padded) layout == first computed row, multiple of 128
+        self.S0 = 0         # rows the prefill computes (== S without hoisting: the alignment rows ride along)
+        self.hoist = None   # special-row hoisting (below): dict(nf, steps tensors ...) when active
+        hoist_seg = None
         if reuse_condition_prefix and B == 1 and not isinstance(attention_mask, ops.PackedMask):
             t_first = min(row_of(b, t) for b in time_emb_inx.keys() for t in time_emb_inx[b]) - 1
             is_layout = isinstance(attention_mask, TokenLayout)
             m2 = None if is_layout else attention_mask[0].to(torch.bool)
             static = t_first >= 128 and (attention_mask.prefix_is_static(t_first) if is_layout
                                          else not bool(m2[:t_first, t_first:].any()))
-            if static:
+            plan = None
+            if static and hoist_special_rows and is_layout:
+                plan = self._hoist_plan(attention_mask, t_first, L, row_of, denoise_image_sizes, time_emb_inx)
+            if plan is not None:
+                # ---- special-row hoisting: the `<|diffusion|>` row of a noisy frame sees only `<|diffusion|>` columns
+                #      and the condition prefix, its time row only those and the time columns — never an image column
+                #      (LVM/processor.py:682-731) — so the first is step-invariant and the second a function of the step
+                #      index alone.  Both leave the per-step row set: the sequence is re-ordered to
+                #      [prefix | diffusion rows | time rows | gap | image rows], the image rows (n_frames x N: whole
+                #      GEMM / attention tiles) are all a step computes, and the time rows' q/k/v of EVERY step come
+                #      from one batched pass (_time_pass) and are dropped in by vgpt_sampler_copy_step_rows. ----
+                perm, S, inv = plan["perm"], plan["S"], plan["inv"]
+                pt = torch.tensor([p_ if p_ >= 0 else 0 for p_ in perm], dtype=torch.int64, device=input_ids.device)
+                gapm = torch.tensor([p_ < 0 for p_ in perm], dtype=torch.bool, device=input_ids.device)
+                input_ids = torch.where(gapm, input_ids[0, 0], input_ids[0, pt]).view(1, -1)
+                position_ids = torch.where(gapm, torch.zeros_like(position_ids[0, pt]), position_ids[0, pt]).view(1, -1)
+                attention_mask = attention_mask.permute(perm)
+                prev = row_of
+                row_of = lambda b, s, prev=prev, inv=inv: inv[prev(b, s)]
+                L = len(perm)
+                self.S, self.S0 = S, t_first
+                self.hoist = plan
+                hoist_seg = plan["segments"]
+                seq_bounds = None
+            elif static:
                 S0 = t_first
                 S = (S0 + 127) // 128 * 128
                 npad = S - S0
@@ -120,7 +147,7 @@ class StaticDenoiser:
                 prev = row_of
                 row_of = lambda b, s, prev=prev, S0=S0, npad=npad: (lambda r: r if r < S0 else r + npad)(prev(b, s))
                 L = L2
-                self.S = S
+                self.S = self.S0 = S
                 if seq_bounds is not None:
                     sh = lambda r_: r_ if r_ < S0 else r_ + npad
                     seq_bounds = [(sh(a_), sh(e_ - 1) + 1) for a_, e_ in seq_bounds]
@@ -135,6 +162,8 @@ class StaticDenoiser:
             if self.S:
                 cl = sorted({self.S, L, *[a_ for a_, _ in seq_bounds if a_ > self.S]})
                 self.seg_live = tuple((0, a_, e_) for a_, e_ in zip(cl[:-1], cl[1:]) if e_ > a_)
+        if hoist_seg is not None:
+            self.seg_live = hoist_seg
         self.nf = n_frames
         self.h, self.w = latent_hw
         C = model.in_channels
@@ -149,6 +178,8 @@ class StaticDenoiser:
         # static inputs
         self.input_ids = input_ids.contiguous()
         self.pm = ops.as_packed_mask(attention_mask, dev)
+        self.layout = attention_mask if isinstance(attention_mask, TokenLayout) else None
+        self.position_ids = position_ids
         self.rope = model.llm.rope_tables(position_ids)
         i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
         self.cond = None
@@ -169,7 +200,8 @@ class StaticDenoiser:
         S = self.S
         self.Ma = B * L - S   # rows computed per step
         if S:
-            self.x_rows_a, self.t_rows_a = i32([r - S for r in x_rows]), i32([r - S for r in t_rows])
+            self.x_rows_a = i32([r - S for r in x_rows])
+            self.t_rows_a = None if self.hoist else i32([r - S for r in t_rows])
             self.ids_a = self.input_ids[:, S:].contiguous()
             self.rope_a = (self.rope[0][S:].contiguous(), self.rope[1][S:].contiguous())
 
@@ -202,15 +234,18 @@ class StaticDenoiser:
         self.temb = e(n_frames, H)
         self.mod = e(n_frames, 2 * H)
         self.graph = None
+        self.time_qkv = None   # hoisting: (steps, layers, n_frames, 3H) q/k/v rows of the time tokens of every step
         if S:
             self.prefill()
+            if self.hoist and self.sigma is not None:
+                self._time_pass()
 
     def prefill(self):
         """One forward over the static prefix rows [0, S) ONLY -- they never see a later row (that is what makes them
         step-invariant), so nothing else is needed to produce them -- leaving every layer's (post-RoPE) q/k/v in
         qkv_full[l][:S].  Rows >= S of qkv_full are written by every step (zero until the first one: the buffer is
         zero-initialised so that masked keys are finite)."""
-        m, cfg, H, S = self.model, self.cfg, self.H, self.S
+        m, cfg, H, S = self.model, self.cfg, self.H, self.S0
         nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         e = lambda *s: torch.empty(*s, dtype=BF16, device=self.dev)
         hid, nrm, ctx, act = e(1, S, H), e(1, S, H), e(1, S, nq * hd), e(1, S, cfg.intermediate_size)
@@ -236,6 +271,108 @@ class StaticDenoiser:
     def set_sigma(self, sigma: torch.Tensor):
         self.sigma = sigma.to(self.dev, torch.float32).contiguous()
         self.num_steps = self.sigma.numel() - 1
+        if getattr(self, "hoist", None) and getattr(self, "qkv_full", None) is not None:
+            self._time_pass()
+
+    # ---- special-row hoisting ------------------------------------------------------------------------------------
+    @staticmethod
+    def _hoist_plan(layout: TokenLayout, S0: int, L: int, row_of, denoise_image_sizes, time_emb_inx):
+        """Re-ordering [prefix | diffusion rows | time rows | gap | image rows] of a packed next-clip sequence, or None
+        when the rows behind the prefix are not exactly whole noisy frames (then only the prefix is reused)."""
+        from .layout import NOISY
+        x_old = _rows(denoise_image_sizes, row_of, True)
+        t_old = _rows(time_emb_inx, row_of, False)
+        ntoks = {it[1] - it[0] for b in denoise_image_sizes.keys() for it in denoise_image_sizes[b]}
+        nf = len(x_old)
+        if nf == 0 or len(t_old) != nf or len(ntoks) != 1:
+            return None
+        ntok = ntoks.pop()
+        if any(t != x - 1 for t, x in zip(t_old, x_old)):
+            return None
+        d_old = [t - 1 for t in t_old]
+        rows = sorted(d_old + t_old + [x + j for x in x_old for j in range(ntok)])
+        if rows != list(range(S0, L)) or not bool((layout.kind[0, S0:] == NOISY).all()):
+            return None
+        # the special rows must really be the offset-0 / offset-1 tokens of their frames (what makes them image-blind)
+        if not (bool((layout.oc[0, d_old] == 0).all()) and bool((layout.oc[0, t_old] == 1).all())
+                and bool((layout.oc[0, [x + j for x in x_old for j in range(ntok)]] == 2).all())):
+            return None
+        S = (S0 + 2 * nf + 127) // 128 * 128
+        perm = list(range(S0)) + d_old + t_old + [-1] * (S - S0 - 2 * nf) + [x + j for x in x_old for j in range(ntok)]
+        inv = {o: i for i, o in enumerate(perm) if o >= 0}
+        # image rows of one sequence form one segment of the attention plan
+        seqs = [int(layout.seq[0, x]) for x in x_old]
+        segs, f0 = [], 0
+        for f in range(1, nf + 1):
+            if f == nf or seqs[f] != seqs[f0]:
+                segs.append((0, S + f0 * ntok, S + f * ntok))
+                f0 = f
+        return dict(perm=perm, inv=inv, S=S, nf=nf, ntok=ntok, segments=tuple(segs))
+
+    def _time_pass(self):
+        """q/k/v rows of the `<|diffusion|>` and time tokens for EVERY denoise step in one batched forward: sequence
+        [prefix (K/V from the prefill) | gap | per step: n_frames diffusion rows, n_frames time rows], each step's
+        rows forming their own clip group so that steps do not see each other.  Leaves the diffusion rows' q/k/v
+        (step-invariant) in qkv_full and the time rows' in time_qkv[step]."""
+        m, cfg, H, dev = self.model, self.cfg, self.H, self.dev
+        nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        W3 = (nq + 2 * nk) * hd
+        S0, nf, T = self.S0, self.hoist["nf"], self.num_steps
+        lay = self.layout
+        P0 = (S0 + 127) // 128 * 128                     # first special row of the pass
+        n_sp = 2 * nf
+        Lp = P0 + T * n_sp
+        import numpy as np
+        idx = np.concatenate([np.arange(S0), np.full(P0 - S0, -1), np.tile(np.arange(S0, S0 + n_sp), T)])
+        lp = lay.permute(idx)
+        grp = lp.grp.copy()
+        base = int(lay.grp.max()) + 1
+        step_of = np.repeat(np.arange(T), n_sp)
+        old = grp[0, P0:]
+        uniq = {g: i for i, g in enumerate(sorted(set(old.tolist())))}
+        grp[0, P0:] = base + step_of * len(uniq) + np.array([uniq[g] for g in old.tolist()])
+        lp = lp.with_groups(grp)
+        pm = lp.packed_mask(dev)
+        e = lambda *s_, dt=BF16: torch.empty(*s_, dtype=dt, device=dev)
+        Ms = T * n_sp
+        hid, nrm, ctx, act = e(1, Ms, H), e(1, Ms, H), e(1, Ms, nq * hd), e(1, Ms, cfg.intermediate_size)
+        # inputs: token embedding of `<|diffusion|>` for the diffusion rows, time_token(sigma_s) for the time rows
+        ids = self.input_ids[0, S0:S0 + n_sp].repeat(T).view(1, Ms).contiguous()
+        ops.embed_gather(ids, m.llm.embed_tokens.weight, out=hid)
+        # time_token(sigma_s): one value per step (every frame of a step carries the same t, LVM/scheduler.py:169),
+        # through the same small-M kernels as the per-step path (at most 32 rows per call), then broadcast to the rows
+        ts = self.sigma[:T].contiguous()
+        sin, tt_h, tt_o = e(T, 256), e(T, H), e(T, H)
+        ops.timestep_sinusoid(ts, m.time_token.freqs(dev), out=sin)
+        tt = m.time_token.mlp
+        for c in range(0, T, 32):
+            ops.linear_small(sin[c:c + 32], tt[0].weight, tt[0].bias, post_act=ops.ACT_SILU, out=tt_h[c:c + 32])
+            ops.linear_small(tt_h[c:c + 32], tt[2].weight, tt[2].bias, out=tt_o[c:c + 32])
+        hid.view(T, n_sp, H)[:, nf:] = tt_o[:, None, :]
+        pos = torch.cat([self.position_ids[0, :S0], torch.zeros(P0 - S0, dtype=self.position_ids.dtype, device=dev),
+                         self.position_ids[0, S0:S0 + n_sp].repeat(T)]).view(1, Lp)
+        rope = m.llm.rope_tables(pos)
+        rope_s = (rope[0][P0:].contiguous(), rope[1][P0:].contiguous())
+        buf = torch.zeros(Lp, W3, dtype=BF16, device=dev)
+        self.time_qkv = e(T, cfg.num_hidden_layers, nf, W3)
+        seg = ((0, P0, Lp),)
+        for li, layer in enumerate(m.llm.layers):
+            at, mlp = layer.self_attn, layer.mlp
+            full = self.qkv_full[li]
+            buf[:S0].copy_(full[:S0])
+            ops.rmsnorm(hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=nrm)
+            ops.linear(nrm, at.qkv_proj.weight, out=buf[P0:])
+            ops.rope_qk_inplace(buf[P0:], rope_s[0], rope_s[1], nq, nk, hd)
+            ops.attention_qkv_range(buf.view(1, Lp, -1), pm, nq, nk, hd, P0, ctx, segments=seg)
+            ops.linear(ctx, at.o_proj.weight, residual=hid, out=hid)
+            ops.rmsnorm(hid, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon, out=nrm)
+            ops.gated_mlp_act(nrm, mlp.gate_up_proj.weight, mlp.act, out=act)
+            ops.linear(act, mlp.down_proj.weight, residual=hid, out=hid)
+            sp = buf[P0:].view(T, n_sp, W3)
+            full[S0:S0 + nf].copy_(sp[0, :nf])                   # diffusion rows: the same at every step
+            self.time_qkv[:, li].copy_(sp[:, nf:])
+        self.time_dst = self.qkv_full[:, S0 + nf:S0 + 2 * nf]    # (layers, nf, 3H) view the step copy writes
+        torch.cuda.current_stream().synchronize()
 
     def set_latents(self, z: torch.Tensor):
         """z: (n_frames, C, h, w) any float dtype; becomes the fp32 sampler state."""
@@ -256,9 +393,14 @@ class StaticDenoiser:
             ops.patch_embed(self.cond, m.input_x_embedder.proj.weight, m.input_x_embedder.proj.bias, pos,
                             self.cond_rows, seq2d, m.pos_embed_max_size)
         ops.timestep_sinusoid(self.ts, m.time_token.freqs(self.dev), out=self.temb_sin)
-        tt = m.time_token.mlp
-        ops.linear_small(self.temb_sin, tt[0].weight, tt[0].bias, post_act=ops.ACT_SILU, out=self.tt_h)
-        ops.linear_small(self.tt_h, tt[2].weight, tt[2].bias, out=seq2d, out_row=t_rows, ldo=H)
+        if self.hoist:
+            if self.time_qkv is None:
+                raise VgptError("StaticDenoiser: set_sigma() must run before the first step")
+            ops.sampler_copy_step_rows(self.time_qkv, self.time_dst, self.step)
+        else:
+            tt = m.time_token.mlp
+            ops.linear_small(self.temb_sin, tt[0].weight, tt[0].bias, post_act=ops.ACT_SILU, out=self.tt_h)
+            ops.linear_small(self.tt_h, tt[2].weight, tt[2].bias, out=seq2d, out_row=t_rows, ldo=H)
         ops.patch_embed(self.z_model, m.x_embedder.proj.weight, m.x_embedder.proj.bias, pos, x_rows, seq2d,
                         m.pos_embed_max_size)
         nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim

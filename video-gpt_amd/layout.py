@@ -146,6 +146,28 @@ class TokenLayout:
         thr = np.where(self.thr >= at, self.thr + n, self.thr)
         return TokenLayout(ins(thr, 0), ins(self.seq, GAP_SEQ), ins(self.kind, GAP), ins(self.oc, 0), ins(self.grp, 0))
 
+    def permute(self, perm) -> "TokenLayout":
+        """Tokens re-ordered: new position i holds old token perm[i]; perm[i] == -1 inserts a GAP token.  Only valid
+        when every CLEAN token keeps its position (their visibility is a threshold in sequence order) and every
+        non-CLEAN token stays behind all CLEAN ones — the engine moves NOISY rows among themselves."""
+        perm = np.asarray(perm, dtype=np.int64)
+        keep = perm >= 0
+        src = np.where(keep, perm, 0)
+        clean_old = np.nonzero((self.kind == CLEAN).any(axis=0))[0]
+        if clean_old.size:
+            last = int(clean_old.max())
+            if not np.array_equal(perm[: last + 1], np.arange(last + 1)):
+                raise ValueError("TokenLayout.permute: CLEAN tokens (and everything before the last one) must stay in place")
+
+        def take(a, fill):
+            return np.where(keep[None, :], a[:, src], fill)
+        return TokenLayout(take(self.thr, 0), take(self.seq, GAP_SEQ), take(self.kind, GAP), take(self.oc, 0),
+                           take(self.grp, 0))
+
+    def with_groups(self, grp) -> "TokenLayout":
+        """Same tokens with other clip-group ids for the NOISY ones (engine: one group per denoise step)."""
+        return TokenLayout(self.thr, self.seq, self.kind, self.oc, grp)
+
     def prefix_is_static(self, t_first: int, row: int = 0) -> bool:
         """True when no row before t_first can see a column at or behind it — the rows of the condition prefix are
         then the same at every denoise step."""

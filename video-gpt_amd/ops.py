@@ -484,6 +484,18 @@ def euler_cfg_update(z: torch.Tensor, z_model: torch.Tensor, pred: torch.Tensor,
          step.data_ptr(), nf, z.numel() // nf, pred_type, int(use_cfg), float(cfg_scale), _stream())
 
 
+def sampler_copy_step_rows(src: torch.Tensor, dst: torch.Tensor, step: torch.Tensor):
+    """src: (n_steps, n_layers, rows, W) contiguous; dst: a (n_layers, rows, W) VIEW whose rows are contiguous (layer
+    stride arbitrary).  dst[l] = src[*step][l]."""
+    n_steps, n_layers, rows, W = src.shape
+    if not src.is_contiguous() or dst.shape != src.shape[1:] or dst.stride(2) != 1 or dst.stride(1) != W \
+            or dst.dtype != src.dtype:
+        raise VgptError("sampler_copy_step_rows: bad operand layout")
+    es = src.element_size()
+    call("vgpt_sampler_copy_step_rows", src.data_ptr(), dst.data_ptr(), step.data_ptr(), n_steps, n_layers,
+         rows * W * es, n_layers * rows * W * es, rows * W * es, dst.stride(0) * es, _stream())
+
+
 def sampler_advance(step: torch.Tensor):
     call("vgpt_sampler_advance", step.data_ptr(), _stream())
 
