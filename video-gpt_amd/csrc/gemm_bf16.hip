@@ -55,6 +55,10 @@ struct TileCfg {
 };
 using Cfg128 = TileCfg<128, 128, 2, 2>;
 using Cfg256 = TileCfg<256, 256, 2, 4>;
+// 256 x 192: same loop with 3 instead of 4 n sub-tiles per wave (wave tile 128 x 48).  For problems whose 256-tile
+// grid fills the last round badly: M = 4096 rows x N = 3072 is 192 tiles of 256 x 256 (a 75 % round) but exactly 256
+// tiles of 256 x 192; x N = 9216 it is 2.25 rounds against 3 full rounds of 0.75-size tiles.
+using Cfg192 = TileCfg<256, 192, 2, 4>;
 
 enum { MODE_PLAIN = 0, MODE_GATED = 1 };
 
@@ -290,26 +294,27 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         // of phase p+1 are read from LDS while phase p's MFMAs run (two register sets), the next tile's
         // DMA is issued in two halves right after the per-tile barrier, and that barrier sits in front of
         // the LAST phase of a tile so the first fragments of tile kt+1 are prefetched under tile kt.
-        static_assert(MI == 8 && NI == 4, "pipelined loop is written for the 256x256 / 2x4-wave tile");
-        bf16x8 Wf[2][4], Af[2][4];
+        static_assert(MI == 8 && (NI == 4 || NI == 3), "pipelined loop is written for the 2x4-wave tiles of 128 x 64 / 128 x 48");
+        bf16x8 Wf[2][NI], Af[2][4];
         if constexpr ((kDebug & 2) != 0) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    Wf[u][i] = bf16x8{(bf16)1.f, (bf16)0.5f, (bf16)-1.f, (bf16)2.f, (bf16)1.f, (bf16)0.5f, (bf16)-1.f, (bf16)2.f};
-                    Af[u][i] = Wf[u][i];
-                }
+                for (int i = 0; i < 4; ++i)
+                    Af[u][i] = bf16x8{(bf16)1.f, (bf16)0.5f, (bf16)-1.f, (bf16)2.f, (bf16)1.f, (bf16)0.5f, (bf16)-1.f, (bf16)2.f};
+#pragma unroll
+                for (int i = 0; i < NI; ++i) Wf[u][i] = Af[u][0];
+            }
         }
-        auto ldW = [&](bf16x8(&dst)[4], int buf, int ks) {
+        auto ldW = [&](bf16x8(&dst)[NI], int buf, int ks) {
             if constexpr (kDebug & 2) return;
             if constexpr (WTR) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[i] = ld_tr(sW + buf * C::W_BYTES, 2 * BN, ks, wn * 4 + i);
+                for (int i = 0; i < NI; ++i) dst[i] = ld_tr(sW + buf * C::W_BYTES, 2 * BN, ks, wn * NI + i);
             } else {
                 const char* b = sW + buf * C::W_BYTES + w_base + ((ks * 4 + fk) ^ sw) * 16;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(b + i * 2048);
+                for (int i = 0; i < NI; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(b + i * 2048);
             }
         };
         auto ldA = [&](bf16x8(&dst)[4], int buf, int ks, int mh) {
@@ -323,11 +328,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                 for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(b + j * 2048);
             }
         };
-        auto mma = [&](const bf16x8(&wf)[4], const bf16x8(&af)[4], auto mh) {
+        auto mma = [&](const bf16x8(&wf)[NI], const bf16x8(&af)[4], auto mh) {
             constexpr int MH = decltype(mh)::value;
             if (getenv_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][MH * 4 + j] =
@@ -342,10 +347,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                 a_issue(ii, kt, sA + buf * C::A_BYTES + (wave * C::A_SLABS + ii) * 1024);
             }
 #pragma unroll
-            for (int i = 0; i < C::W_SLABS / 2; ++i) {
-                const int ii = half * (C::W_SLABS / 2) + i;
-                w_issue(ii, kt, sW + buf * C::W_BYTES + (wave * C::W_SLABS + ii) * 1024);
-            }
+            for (int ii = 0; ii < C::W_SLABS; ++ii)   // first half: slabs [0, W_SLABS/2), second: the rest
+                if ((ii >= C::W_SLABS / 2) == (half != 0))
+                    w_issue(ii, kt, sW + buf * C::W_BYTES + (wave * C::W_SLABS + ii) * 1024);
         };
         using H0 = std::integral_constant<int, 0>;
         using H1 = std::integral_constant<int, 1>;
@@ -463,6 +467,27 @@ int forced_tile() {
     return v;
 }
 
+// Launch plan of a big-tile GEMM: the big-tile kernel (one block per CU, so T tiles take ceil(T/256) rounds) gets either
+// everything or — when the last round would be badly filled — only the m-tile rows that make full rounds, and the
+// 128x128 kernel (2 blocks/CU, 4x smaller tiles) runs the remaining rows behind it.
+struct BigPlan {
+    int64_t rows_big;  // rows given to the big-tile kernel (M: no split)
+    double cost;       // estimated time in units of "one column of a 256-row tile round"
+};
+BigPlan plan_big(int64_t M, int64_t n_out, int bn_out) {
+    constexpr int CUS = 256;
+    const int64_t tiles_n = cdiv(n_out, bn_out), tiles_m = cdiv(M, 256), T = tiles_m * tiles_n;
+    const int64_t full = T / CUS, rem = T % CUS;
+    // a round of the 128-tile kernel (512 tiles) measured at ~1.15x the time of half a 256x256 round
+    auto small = [&](int64_t rows) { return (double)cdiv(cdiv(rows, 128) * cdiv(n_out, 128), 2 * CUS) * 128.0 * 1.15; };
+    if (full >= 1 && rem > 0 && rem < (CUS * 85) / 100) {
+        const int64_t rows_big = (full * CUS) / tiles_n;
+        if (rows_big >= 1 && rows_big < tiles_m)
+            return {rows_big * 256, (double)cdiv(rows_big * tiles_n, CUS) * bn_out + small(M - rows_big * 256)};
+    }
+    return {M, (double)cdiv(T, CUS) * bn_out};
+}
+
 template <int MODE, bool ATR = false, bool WTR = false>
 int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const int f = forced_tile();
@@ -470,30 +495,38 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const int64_t tiles_n = cdiv(n_out, MODE == MODE_GATED ? 128 : 256);
     const int64_t tiles_m = cdiv(g.M, 256);
     const int64_t big_tiles = tiles_m * tiles_n;
-    const bool use256 = f == 256 || f == 257 || (f != 128 && big_tiles >= 128);
+    const bool use256 = f == 256 || f == 257 || f == 192 || (f != 128 && big_tiles >= 128);
     if (!use256) return launch_cfg<MODE, Cfg128, false, ATR, WTR>(g, n_out, s, name);
     if (f == 257) return launch_cfg<MODE, Cfg256, false, ATR, WTR>(g, n_out, s, name);
-    // Wave quantisation: the 256-tile kernel runs one block per CU, so a grid of T tiles takes ceil(T/256) rounds.
-    // When the last round would be badly filled, give the big-tile kernel only the m-tile rows that make full
-    // rounds and run the remaining rows with the 128x128 kernel (2 blocks/CU, 4x smaller tiles) behind it.
-    constexpr int CUS = 256;
-    const int64_t full_rounds = big_tiles / CUS, rem = big_tiles % CUS;
-    if (f == 0 && full_rounds >= 1 && rem > 0 && rem < (CUS * 85) / 100) {
-        const int64_t rows_big = (full_rounds * CUS) / tiles_n;  // m-tile rows that fit in the full rounds
-        if (rows_big >= 1 && rows_big < tiles_m) {
-            GemmArgs g1 = g, g2 = g;
-            const int64_t m1 = rows_big * 256;
-            g1.M = (int)m1;
-            g2.M = g.M - (int)m1;
-            g2.A = ATR ? g.A + m1 : g.A + m1 * g.lda;  // a transposed A keeps m along its columns
-            g2.C = g.C + m1 * g.ldc;
-            if (g.epi == VGPT_EPI_RESID) g2.extra = g.extra + m1 * g.ldr;
-            int rc = launch_cfg<MODE, Cfg256, true, ATR, WTR>(g1, n_out, s, name);
-            if (rc != VGPT_OK) return rc;
-            return launch_cfg<MODE, Cfg128, false, ATR, WTR>(g2, n_out, s, name);
-        }
+    BigPlan p256 = plan_big(g.M, n_out, MODE == MODE_GATED ? 128 : 256);
+    if (f == 256) p256.rows_big = g.M;
+    bool use192 = false;
+    BigPlan p = p256;
+    if constexpr (MODE == MODE_PLAIN && !ATR && !WTR) {
+        // 256 x 192 tiles when their rounds fit the problem clearly better (its loop moves ~15 % more operand bytes per
+        // FLOP, so a small estimated gain is not taken)
+        BigPlan p192 = plan_big(g.M, n_out, 192);
+        if (f == 192) p192.rows_big = g.M;
+        use192 = f == 192 || (f == 0 && p192.cost < 0.93 * p256.cost);
+        if (use192) p = p192;
     }
-    return launch_cfg<MODE, Cfg256, true, ATR, WTR>(g, n_out, s, name);
+    auto big = [&](const GemmArgs& ga) {
+        if constexpr (MODE == MODE_PLAIN && !ATR && !WTR) {
+            if (use192) return launch_cfg<MODE, Cfg192, true, ATR, WTR>(ga, n_out, s, name);
+        }
+        return launch_cfg<MODE, Cfg256, true, ATR, WTR>(ga, n_out, s, name);
+    };
+    if (p.rows_big >= g.M) return big(g);
+    GemmArgs g1 = g, g2 = g;
+    const int64_t m1 = p.rows_big;
+    g1.M = (int)m1;
+    g2.M = g.M - (int)m1;
+    g2.A = ATR ? g.A + m1 : g.A + m1 * g.lda;  // a transposed A keeps m along its columns
+    g2.C = g.C + m1 * g.ldc;
+    if (g.epi == VGPT_EPI_RESID) g2.extra = g.extra + m1 * g.ldr;
+    int rc = big(g1);
+    if (rc != VGPT_OK) return rc;
+    return launch_cfg<MODE, Cfg128, false, ATR, WTR>(g2, n_out, s, name);
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
