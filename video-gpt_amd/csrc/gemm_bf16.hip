@@ -482,8 +482,10 @@ BigPlan plan_big(int64_t M, int64_t n_out, int bn_out) {
     auto small = [&](int64_t rows) { return (double)cdiv(cdiv(rows, 128) * cdiv(n_out, 128), 2 * CUS) * 128.0 * 1.15; };
     if (full >= 1 && rem > 0 && rem < (CUS * 85) / 100) {
         const int64_t rows_big = (full * CUS) / tiles_n;
-        if (rows_big >= 1 && rows_big < tiles_m)
-            return {rows_big * 256, (double)cdiv(rows_big * tiles_n, CUS) * bn_out + small(M - rows_big * 256)};
+        if (rows_big >= 1 && rows_big < tiles_m) {
+            const double split = (double)cdiv(rows_big * tiles_n, CUS) * bn_out + small(M - rows_big * 256);
+            if (split < (double)cdiv(T, CUS) * bn_out) return {rows_big * 256, split};
+        }
     }
     return {M, (double)cdiv(T, CUS) * bn_out};
 }

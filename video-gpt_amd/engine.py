@@ -426,11 +426,15 @@ class StaticDenoiser:
             ops.gated_mlp_act(self.nrm, mlp.gate_up_proj.weight, mlp.act, out=self.act)
             ops.linear(self.act, mlp.down_proj.weight, residual=self.hid, out=self.hid)
         ops.rmsnorm(self.hid, m.llm.norm.weight, m.llm.norm.variance_epsilon, out=self.nrm)
+        # t_embedder + adaLN modulation: every frame of a step carries the same t (LVM/scheduler.py:169), so one row is
+        # computed and broadcast (the small-M kernel re-reads its input rows for every output column)
         te = m.t_embedder.mlp
-        ops.linear_small(self.temb_sin, te[0].weight, te[0].bias, post_act=ops.ACT_SILU, out=self.te_h)
-        ops.linear_small(self.te_h, te[2].weight, te[2].bias, out=self.temb)
+        ops.linear_small(self.temb_sin[:1], te[0].weight, te[0].bias, post_act=ops.ACT_SILU, out=self.te_h[:1])
+        ops.linear_small(self.te_h[:1], te[2].weight, te[2].bias, out=self.temb[:1])
         ada = m.final_layer.adaLN_modulation[1]
-        ops.linear_small(self.temb, ada.weight, ada.bias, pre_act=ops.ACT_SILU, out=self.mod)
+        ops.linear_small(self.temb[:1], ada.weight, ada.bias, pre_act=ops.ACT_SILU, out=self.mod[:1])
+        if self.nf > 1:
+            self.mod[1:].copy_(self.mod[:1].expand(self.nf - 1, -1))
         ops.final_layer(self.nrm.view(-1, H), x_rows, self.mod, m.final_layer.linear.weight,
                         m.final_layer.linear.bias, self.pred)
 
