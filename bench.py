@@ -403,9 +403,18 @@ def main():
                         traffic = rec["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
+        mfma_busy = None  # matrix-pipe busy fraction of that kernel from the committed SQ counter pass (scripts/pmc_mfma.py)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")) as f:
+                recs = [(rec["launches"], rec["mfma_busy_frac"]) for name, rec in json.load(f)["kernels"].items()
+                        if "gemm_bf16_kernel<0" in name and "TileCfg<256" in name]
+                if recs:
+                    mfma_busy = round(sum(n * v for n, v in recs) / sum(n for n, _ in recs), 4)
+        except Exception:
+            mfma_busy = None
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<MODE_PLAIN> (qkv_proj/o_proj/down_proj)",
                 "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "mfma_busy_pmc": mfma_busy,
                 "launches": n_launch, "avg_launch_us": round(t_gemm / max(n_launch, 1) * 1e6, 1),
                 "alg_flops_per_launch": alg / max(n_launch, 1),
                 "whole_step": {"alg_tflop": round(flops_step / 1e12, 2), "prefill_tflop_once": round(flops_prefill / 1e12, 2),
