@@ -154,42 +154,55 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_dx_kernel(const bf16* __restr
     }
 }
 
-// grid (ceil(H/8/128), strips): thread = 8 columns, loops over its strip of rows four at a time (independent
-// loads in flight; a one-row-at-a-time loop ran at the latency of a load per row, ~1 TB/s)
-__global__ __launch_bounds__(128) void rmsnorm_bwd_dw_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+// grid (ceil(H/8/128), strips), block = 128 column groups (8 columns each) x 4 row lanes: a row lane walks rows
+// lane, lane+4, ... of the strip four at a time (independent loads in flight), the four lanes of a column group are
+// added through LDS and one atomic per column and strip goes out (same-address atomics serialise: few strips).
+__global__ __launch_bounds__(512) void rmsnorm_bwd_dw_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                              const float* __restrict__ rstd, float* __restrict__ dw,
                                                              int64_t rows, int H, int rows_per_strip) {
-    const int off = (blockIdx.x * 128 + threadIdx.x) * 8;
-    if (off >= H) return;
+    __shared__ float red[3][128][9];
+    const int cg = threadIdx.x & 127, rl = threadIdx.x >> 7;
+    const int off = (blockIdx.x * 128 + cg) * 8;
+    const bool live = off < H;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_strip;
     const int64_t r1 = r0 + rows_per_strip < rows ? r0 + rows_per_strip : rows;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    int64_t r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        bf16x8 xb[4], db[4];
-        float rs[4];
+    if (live) {
+        int64_t r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            bf16x8 xb[4], db[4];
+            float rs[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            xb[u] = *reinterpret_cast<const bf16x8*>(x + (r + u) * H + off);
-            db[u] = *reinterpret_cast<const bf16x8*>(dy + (r + u) * H + off);
-            rs[u] = rstd[r + u];
+            for (int u = 0; u < 4; ++u) {
+                xb[u] = *reinterpret_cast<const bf16x8*>(x + (r + 4 * u) * H + off);
+                db[u] = *reinterpret_cast<const bf16x8*>(dy + (r + 4 * u) * H + off);
+                rs[u] = rstd[r + 4 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += bf2f(db[u][j]) * bf2f(xb[u][j]) * rs[u];
         }
+        for (; r < r1; r += 4) {
+            const bf16x8 xb = *reinterpret_cast<const bf16x8*>(x + r * H + off);
+            const bf16x8 db = *reinterpret_cast<const bf16x8*>(dy + r * H + off);
+            const float rs = rstd[r];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += bf2f(db[u][j]) * bf2f(xb[u][j]) * rs[u];
+            for (int j = 0; j < 8; ++j) acc[j] += bf2f(db[j]) * bf2f(xb[j]) * rs;
+        }
     }
-    for (; r < r1; ++r) {
-        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(x + r * H + off);
-        const bf16x8 db = *reinterpret_cast<const bf16x8*>(dy + r * H + off);
-        const float rs = rstd[r];
+    if (rl > 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += bf2f(db[j]) * bf2f(xb[j]) * rs;
+        for (int j = 0; j < 8; ++j) red[rl - 1][cg][j] = acc[j];
     }
+    __syncthreads();
+    if (rl == 0 && live) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(dw + off + j, acc[j]);
+        for (int j = 0; j < 8; ++j)
+            atomicAdd(dw + off + j, acc[j] + red[0][cg][j] + red[1][cg][j] + red[2][cg][j]);
+    }
 }
 
 // ---- generic strided matmul for the small heads: C = alpha * A B (+ C), one thread per output ------
@@ -629,9 +642,9 @@ VGPT_EXPORT int vgpt_rmsnorm_bwd(const void* x, const void* w, const void* dy, c
         break;
     switch ((int)cdiv(H, 512)) { RB_CASE(1) RB_CASE(2) RB_CASE(3) RB_CASE(4) RB_CASE(5) RB_CASE(6) RB_CASE(7) RB_CASE(8) }
 #undef RB_CASE
-    const int strips = (int)std::min<int64_t>(rows, 512);
+    const int strips = (int)std::min<int64_t>(cdiv(rows, 4), 128);
     const int rps = (int)cdiv(rows, strips);
-    hipLaunchKernelGGL(rmsnorm_bwd_dw_kernel, dim3((unsigned)cdiv(H / 8, 128), (unsigned)cdiv(rows, rps)), dim3(128), 0, s,
+    hipLaunchKernelGGL(rmsnorm_bwd_dw_kernel, dim3((unsigned)cdiv(H / 8, 128), (unsigned)cdiv(rows, rps)), dim3(512), 0, s,
                        (const bf16*)x, (const bf16*)dy, rstd_ws, dw, rows, (int)H, rps);
     LAUNCH_OK("vgpt_rmsnorm_bwd");
 }
