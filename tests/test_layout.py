@@ -150,3 +150,34 @@ def test_device_expansion_cfg4_shape_properties(ops):
            (lay.oc[0][band, None] >= lay.oc[0][None, :]))
     got = np.unpackbits(bits[band].contiguous().view(torch.uint8).cpu().numpy(), axis=-1, bitorder="little")[:, :L]
     assert np.array_equal(got.astype(bool), vis)
+
+
+def test_hoist_plan_permutation_matches_dense_permutation():
+    """engine.StaticDenoiser._hoist_plan: the re-ordering [prefix | <|diffusion|> rows | time rows | gap | image rows] of
+    a packed next-clip sequence is a pure permutation of tokens: the permuted layout expands to the dense mask with
+    rows and columns permuted (gap rows / columns empty), and every frame's rows land where the plan says."""
+    C, G, N = 2, 3, 16
+    bl = N + 2
+    batch = product_inference(C, G, N, 1, mask_format="layout")
+    lay, offs = batch["attention_mask"].pack()
+    pads = batch["attention_mask"].left_pads()
+    row_of = lambda b, s: offs[b] + s - pads[b]
+    S0 = C * bl
+    plan = E.StaticDenoiser._hoist_plan(lay, S0, lay.L, row_of, batch["denoise_image_sizes"], batch["time_emb_inx"])
+    assert plan is not None and plan["nf"] == 2 * G and plan["ntok"] == N and plan["S"] == 128
+    perm = np.array(plan["perm"])
+    assert sorted(perm[perm >= 0].tolist()) == list(range(lay.L))          # a permutation (plus gap rows)
+    dense = lay.to_bool()[0]
+    got = lay.permute(perm).to_bool()[0]
+    keep = perm >= 0
+    assert np.array_equal(got[np.ix_(keep, keep)], dense[np.ix_(perm[keep], perm[keep])])
+    assert not got[~keep].any() and not got[:, ~keep].any()
+    # special rows never see an image column; image rows see their clip's special columns
+    nf, S = plan["nf"], plan["S"]
+    assert not got[S0:S0 + 2 * nf, S:].any()
+    assert got[S:S + N, S0:S0 + G].all() and got[S:S + N, S0 + nf:S0 + nf + G].all()
+    # the plan's segments: one per sequence, covering the image rows
+    assert plan["segments"] == ((0, S, S + G * N), (0, S + G * N, S + 2 * G * N))
+    # a layout whose tail is not whole noisy frames is refused
+    bad = {0: batch["denoise_image_sizes"][0][:-1], 1: batch["denoise_image_sizes"][1]}
+    assert E.StaticDenoiser._hoist_plan(lay, S0, lay.L, row_of, bad, batch["time_emb_inx"]) is None
