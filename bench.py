@@ -395,12 +395,13 @@ def main():
         # tokens of every noisy frame are computed in the per-clip pass instead: n_frames x N rows per step)
         alg = 2 * (4 * H * H + H * I) * (eng.Ma if reuse else real_tokens_step) * nl
         achieved = alg / t_gemm / 1e12
-        traffic = None  # per-launch bytes beyond L2 from the committed PMC passes (profiles/r01_pmc_traffic_v2.json, scripts/pmc_traffic.py)
+        traffic = None  # per-launch bytes beyond L2 of that kernel from the committed PMC passes (scripts/pmc_traffic.py)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v2.json")) as f:
-                for name, rec in json.load(f)["kernels"].items():
-                    if "gemm_bf16_kernel<0" in name:
-                        traffic = rec["traffic_bytes_per_launch"]
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v3.json")) as f:
+                recs = [(rec["launches"], rec["traffic_bytes_per_launch"]) for name, rec in json.load(f)["kernels"].items()
+                        if "gemm_bf16_kernel<0" in name and "TileCfg<256" in name]
+                if recs:
+                    traffic = int(sum(n * v for n, v in recs) / sum(n for n, _ in recs))
         except Exception:
             traffic = None
         mfma_busy = None  # matrix-pipe busy fraction of that kernel from the committed SQ counter pass (scripts/pmc_mfma.py)
