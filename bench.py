@@ -475,7 +475,9 @@ def main():
                                        f"{real_tokens} real tokens), Phi-3-mini-class denoiser {nl} layers, x1 prediction, "
                                        "hipGraph sampler step" + ("" if nl == 32 else " [DEBUG layer count: INVALID]"),
                            "global_batch": world, "parallelism": f"replicas x{world}", "graph": use_graph,
-                           "condition_prefix_reuse": reuse, "tokens_computed_per_step": real_tokens_step,
+                           "condition_prefix_reuse": reuse, "special_row_hoisting": bool(eng.hoist),
+                           "tokens_computed_per_step": int(eng.Ma) if reuse else real_tokens_step,
+                           "tokens_counted_per_step": real_tokens_step,
                            "finite": finite},
                 "roofline": roof, "stage1_train": stage1}
         if breakdown:

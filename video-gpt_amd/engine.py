@@ -354,7 +354,10 @@ class StaticDenoiser:
         rope = m.llm.rope_tables(pos)
         rope_s = (rope[0][P0:].contiguous(), rope[1][P0:].contiguous())
         buf = torch.zeros(Lp, W3, dtype=BF16, device=dev)
-        self.time_qkv = e(T, cfg.num_hidden_layers, nf, W3)
+        shape = (T, cfg.num_hidden_layers, nf, W3)
+        if self.time_qkv is None or tuple(self.time_qkv.shape) != shape:
+            self.time_qkv = e(*shape)      # a captured graph reads this buffer: re-allocating invalidates it
+            self.graph = None
         seg = ((0, P0, Lp),)
         for li, layer in enumerate(m.llm.layers):
             at, mlp = layer.self_attn, layer.mlp
