@@ -81,6 +81,42 @@ def test_sampler_graph_equals_eager_and_layouts_agree(mods, cfg2):
     assert torch.isfinite(ref).all() and r_reuse < 2e-2 and r_pack < 2e-2
 
 
+def test_special_row_hoisting_at_full_size(mods, cfg2):
+    """cfg-2 geometry with the collator's per-token layout: hoisting leaves 16 x 256 = 4096 image rows per step, its
+    graph replay equals its eager launches bit for bit, and the result equals prefix reuse alone and the full
+    recompute up to the layout noise floor measured above."""
+    cfg, model, batch, z, cond, hw = cfg2
+    LY = importlib.import_module("video-gpt_amd.layout")
+    P = mods["processor"]
+    kinds_c, _ = P.plan_inference([4, 8])
+    kinds_u, _ = P.plan_inference([0, 8])
+    lay = LY.TokenLayout.from_plans([(kinds_c, 258, 0), (kinds_u, 258, 4 * 258)], 3096)
+    assert torch.equal(lay.to_bool_tensor(), batch["attention_mask"].to(torch.bool))   # the collator's dense mask, bit for bit
+    b2 = dict(batch); b2["attention_mask"] = lay
+    c2 = (cfg, model, b2, z, cond, hw)
+
+    def eng_(**kw):
+        sched = mods["scheduler"].LVMScheduler(num_steps=3, time_shifting_factor=1)
+        e = mods["engine"].StaticDenoiser(model, b2["input_ids"].to(DEV), b2["position_ids"].to(DEV), lay, cond,
+                                          b2["input_image_sizes"], b2["denoise_image_sizes"], b2["time_emb_inx"], len(z), hw,
+                                          True, 1.6, "x1", sigma=sched.sigma, **kw)
+        e.set_latents(torch.cat(z, dim=0))
+        return e
+    e_h = eng_(reuse_condition_prefix=True)
+    assert e_h.hoist and e_h.S0 == 1032 and e_h.S == 1152 and e_h.Ma == 4096 and e_h.L == 5248
+    assert e_h.seg_live == ((0, 1152, 3200), (0, 3200, 5248))
+    assert tuple(e_h.time_qkv.shape) == (3, 2, 16, 9216)
+    hoist = _run(e_h, use_graph=False)
+    assert torch.equal(_run(eng_(reuse_condition_prefix=True), use_graph=True), hoist)
+    prefix = _run(eng_(reuse_condition_prefix=True, hoist_special_rows=False), use_graph=False)
+    full = _run(eng_(reuse_condition_prefix=False), use_graph=False)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    print(f"hoisting vs prefix reuse: {rel(hoist, prefix):.2e}; vs full recompute: {rel(hoist, full):.2e}")
+    assert torch.isfinite(hoist).all() and rel(hoist, prefix) < 2e-2 and rel(hoist, full) < 2e-2
+    # the dense-mask engine of the other tests and the layout engine without hoisting run the same launches
+    assert torch.equal(prefix, _run(_engine(mods, cfg2, reuse_condition_prefix=True), use_graph=False))
+
+
 def test_attention_plan_equals_aligned_kernel_on_engine_layout(mods, cfg2):
     ops = mods["ops"]
     eng = _engine(mods, cfg2, reuse_condition_prefix=True)
