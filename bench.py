@@ -455,6 +455,7 @@ def main():
 
     # ---- second half of the BASELINE metric: stage-1 train samples/sec at this GPU count (data parallel over RCCL),
     #      a short run (1 warm-up + 3 steps) on the same model; reported inside the same JSON line ----
+    hoisted, rows_per_step = bool(eng.hoist), int(eng.Ma) if reuse else real_tokens_step
     stage1 = None
     if not args.no_stage1 and args.layers == 32:
         del eng
@@ -475,15 +476,15 @@ def main():
                                        f"{real_tokens} real tokens), Phi-3-mini-class denoiser {nl} layers, x1 prediction, "
                                        "hipGraph sampler step" + ("" if nl == 32 else " [DEBUG layer count: INVALID]"),
                            "global_batch": world, "parallelism": f"replicas x{world}", "graph": use_graph,
-                           "condition_prefix_reuse": reuse, "special_row_hoisting": bool(eng.hoist),
-                           "tokens_computed_per_step": int(eng.Ma) if reuse else real_tokens_step,
+                           "condition_prefix_reuse": reuse, "special_row_hoisting": hoisted,
+                           "tokens_computed_per_step": rows_per_step,
                            "tokens_counted_per_step": real_tokens_step,
                            "finite": finite},
                 "roofline": roof, "stage1_train": stage1}
         if breakdown:
             line["breakdown_ms_per_step"] = breakdown
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(cfg, batch)
+            line["cpu_baseline"] = cpu_baseline(cfg, dict(batch, attention_mask=dense_mask))
         print(json.dumps(line), flush=True)
     if world > 1:
         D.barrier()
