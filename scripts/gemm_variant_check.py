@@ -1,6 +1,6 @@
 """Developer probe (GPU): correctness (against fp64 on the same bf16 inputs) and rate of vgpt_gemm_bf16 /
-vgpt_gated_mlp_act_fwd under VGPT_GEMM_TILE (0 = launch plan, 256 / 192 = forced big tile, 259 = the 4-wave variant with
-128 x 128 wave tiles)."""
+vgpt_gated_mlp_act_fwd under VGPT_GEMM_TILE (0 = launch plan, 256 / 192 = forced big tile; experimental kernel variants
+were A/B-tested with it under further tile codes)."""
 import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
