@@ -79,4 +79,25 @@ def run_smoke(device="cuda:0", steps=2, tol=3e-2, verbose=True):
         print(f"smoke: tiny next-clip denoise, {steps} steps, rel-L2 vs CPU oracle = {err:.3e} (tol {tol})")
     if not err < tol:
         raise AssertionError(f"smoke parity failed: rel-L2 {err} >= {tol}")
+    # the same through the default product path of LVMPipeline: per-token mask layout (mask expanded on the device),
+    # cached condition prefix, special rows hoisted out of the per-step row set
+    P = importlib.import_module("video-gpt_amd.processor")
+    LY = importlib.import_module("video-gpt_amd.layout")
+    C, G, hw = 2, 2, (16, 16)
+    bl = (hw[0] // 2) * (hw[1] // 2) + 2
+    p2, batch2, z2, cond2 = build_case(cfg, C=C, G=G, hw=hw)
+    lay = LY.TokenLayout.from_plans([(P.plan_inference([C, G])[0], bl, 0), (P.plan_inference([0, G])[0], bl, C * bl)],
+                                    (C + G) * bl)
+    model2 = build_product_model(cfg, p2, device)
+    kw2 = model_kwargs(batch2, cond2, device)
+    kw2["attention_mask"] = lay
+    sched2 = S.LVMScheduler(num_steps=steps, time_shifting_factor=1)
+    out2 = sched2([t.to(device, BF) for t in z2], model2.frame_block_forward_with_cfg, kw2, prediction_type="x1")
+    torch.cuda.synchronize()
+    err2 = rel_l2(torch.cat(out2), torch.cat(oracle_sample(cfg, p2, batch2, z2, cond2, steps, "x1")))
+    if verbose:
+        print(f"smoke: same with the token-layout mask, cached prefix and hoisted special rows "
+              f"(hoisted={bool(sched2.last_engine.hoist)}): rel-L2 = {err2:.3e}")
+    if not (err2 < tol and sched2.last_engine.hoist):
+        raise AssertionError(f"smoke parity failed on the hoisted path: rel-L2 {err2} (tol {tol})")
     return err
