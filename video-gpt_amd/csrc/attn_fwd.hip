@@ -392,16 +392,24 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             const float m_new = fmaxf(m_i, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_i - m_use);
-            float rsp[4] = {0.f, 0.f, 0.f, 0.f};
+            // two values per VALU instruction where the ISA has a packed fp32 form (v_pk_fma_f32, v_pk_add_f32):
+            // accumulator registers 2j, 2j+1 are an aligned pair; same per-element arithmetic and summation order
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 sc2 = {a.scale_log2e, a.scale_log2e}, nm2 = {-m_use, -m_use};
+            f32x2 rsp[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kb][i], a.scale_log2e, -m_use));
-                    S[kb][i] = p;
-                    rsp[i & 3] += p;
+                for (int i = 0; i < 16; i += 2) {
+                    f32x2 t = {S[kb][i], S[kb][i + 1]};
+                    t = __builtin_elementwise_fma(t, sc2, nm2);
+                    t[0] = __builtin_amdgcn_exp2f(t[0]);
+                    t[1] = __builtin_amdgcn_exp2f(t[1]);
+                    S[kb][i] = t[0];
+                    S[kb][i + 1] = t[1];
+                    rsp[(i >> 1) & 1] += t;
                 }
-            const float rs = half_sum((rsp[0] + rsp[1]) + (rsp[2] + rsp[3]));
+            const float rs = half_sum((rsp[0][0] + rsp[0][1]) + (rsp[1][0] + rsp[1][1]));
             l_i = l_i * alpha + rs;
             // rescale the accumulator only when some row's running max moved (wave-uniform branch)
             if (__any(m_new != m_i)) {
