@@ -21,7 +21,7 @@ from typing import List, Optional, Union
 
 import torch
 
-from . import ops
+from . import ops, ops_train
 from .model import LVM
 from .processor import LVMProcessor
 from .scheduler import LVMScheduler
@@ -161,7 +161,11 @@ class LVMPipeline:
                 self.last_latents.append(lat)
                 if k > 0:  # re-noise the re-encoded condition frames (pipeline.py:496-497); 16 KB blend, torch RNG
                     c = clean_image_noise_level
-                    lat = ((1 - c) * lat.float() + c * torch.randn_like(lat.float())).to(dtype)
+                    # (1 - c) * lat + c * noise through the HIP lerp kernel (fp32 in, bf16 out); the noise is torch's RNG
+                    noise = torch.randn(lat.shape, device=lat.device, dtype=torch.float32)
+                    cvec = torch.full((lat.shape[0],), float(c), device=lat.device, dtype=torch.float32)
+                    lat = ops_train.lerp_frames(noise, lat.float().contiguous(), cvec,
+                                                 torch.empty(lat.shape, device=lat.device, dtype=torch.bfloat16)).to(dtype)
                 input_img_latents.append(lat)
 
             model_kwargs = dict(
