@@ -224,3 +224,21 @@ def test_special_row_hoisting_matches_full_recompute(use_cfg, C, G, hw):
     ref = torch.cat(SC.oracle_sample(cfg, p, batch, z, cond, steps, "x1", use_cfg=use_cfg))
     assert SC.rel_l2(outs["hoist"], ref) < TOL
     assert SC.rel_l2(outs["hoist"], outs["none"]) < 5e-3 and SC.rel_l2(outs["hoist"], outs["prefix"]) < 5e-3
+
+
+def test_scheduler_noise_level_premix():
+    """LVM/scheduler.py:162-163: z <- noise_level * z + (1 - noise_level) * randn before the first step (HIP lerp kernel,
+    torch's generator for the noise) == sampling from latents mixed the same way beforehand."""
+    cfg = R.TINY
+    p, batch, z, cond = SC.build_case(cfg)
+    model = SC.build_product_model(cfg, p, DEV)
+    S = importlib.import_module("video-gpt_amd.scheduler")
+    zs = [x.to(DEV, BF) for x in z]
+    torch.manual_seed(5)
+    a = torch.cat(S.LVMScheduler(num_steps=2)(zs, model.frame_block_forward_with_cfg, SC.model_kwargs(batch, cond, DEV),
+                                              prediction_type="x1", noise_level=0.3))
+    torch.manual_seed(5)
+    mixed = [(f.float() * 0.3 + torch.randn_like(f).float() * 0.7).to(BF) for f in zs]
+    b = torch.cat(S.LVMScheduler(num_steps=2)(mixed, model.frame_block_forward_with_cfg, SC.model_kwargs(batch, cond, DEV),
+                                              prediction_type="x1"))
+    assert SC.rel_l2(a, b) < 1e-2

@@ -68,7 +68,14 @@ class LVMScheduler:
             raise VgptError("LVMScheduler runs on the MI355X HIP path only (latents must be on the GPU)")
         out_dtype = frames[0].dtype
         if noise_level is not None:  # LVM/scheduler.py:162-163 (RNG stays torch's)
-            frames = [f * noise_level + torch.randn_like(f) * (1 - noise_level) for f in frames]
+            from . import ops_train   # noise_level * f + (1 - noise_level) * randn through the HIP lerp kernel
+            mixed = []
+            for f in frames:
+                t = torch.full((f.shape[0],), float(noise_level), device=f.device, dtype=torch.float32)
+                o = torch.empty(f.shape, device=f.device, dtype=torch.bfloat16)
+                mixed.append(ops_train.lerp_frames(f.float().contiguous(), torch.randn_like(f).float().contiguous(), t, o)
+                             .to(out_dtype))
+            frames = mixed
 
         engine = self._fast_path_engine(frames, func, model_kwargs, prediction_type) if is_list else None
         if engine is not None:
