@@ -375,43 +375,66 @@ template <int NCH>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict__ dv, const float* __restrict__ xhat,
                                                          const float* __restrict__ rstd_in, const bf16* __restrict__ mod,
                                                          const int32_t* __restrict__ dst_row, bf16* __restrict__ dhidden,
-                                                         float* __restrict__ dmod, int ntok, int H) {
+                                                         float* __restrict__ dmod, int ntok, int H, int tok_per_wave) {
+    // a wave walks tok_per_wave tokens of one frame and keeps its dshift / dscale sums in registers: one atomic per
+    // column and wave instead of one per element (256 same-address atomics per frame and column serialised: ~1 ms)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int f = blockIdx.y, t = blockIdx.x * 4 + wave;
-    if (t >= ntok) return;
-    const int64_t irow = ((int64_t)f * ntok + t);
+    const int f = blockIdx.y;
     const bf16* scale = mod + (int64_t)f * 2 * H + H;
-    float g[NCH][8], xh[NCH][8];
-    float s1 = 0.f, s2 = 0.f;
+    float dsh[NCH][8], dsc[NCH][8];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int off = (c * 64 + lane) * 8;
-        if (off < H) {
-            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dv + irow * H + off);
-            const bf16x8 sc = *reinterpret_cast<const bf16x8*>(scale + off);
+    for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float df = bf2f(d[j]);
-                xh[c][j] = xhat[irow * H + off + j];
-                g[c][j] = df * (1.0f + bf2f(sc[j]));
-                s1 += g[c][j];
-                s2 += g[c][j] * xh[c][j];
-                atomicAdd(dmod + (int64_t)f * 2 * H + off + j, df);               // dshift
-                atomicAdd(dmod + (int64_t)f * 2 * H + H + off + j, df * xh[c][j]);  // dscale
+        for (int j = 0; j < 8; ++j) dsh[c][j] = dsc[c][j] = 0.f;
+    const int t0 = (blockIdx.x * 4 + wave) * tok_per_wave;
+    for (int t = t0; t < min(t0 + tok_per_wave, ntok); ++t) {
+        const int64_t irow = ((int64_t)f * ntok + t);
+        float g[NCH][8], xh[NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int off = (c * 64 + lane) * 8;
+            if (off < H) {
+                const bf16x8 d = *reinterpret_cast<const bf16x8*>(dv + irow * H + off);
+                const bf16x8 sc = *reinterpret_cast<const bf16x8*>(scale + off);
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xhat + irow * H + off);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(xhat + irow * H + off + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float df = bf2f(d[j]);
+                    xh[c][j] = j < 4 ? x0[j & 3] : x1[j & 3];
+                    g[c][j] = df * (1.0f + bf2f(sc[j]));
+                    s1 += g[c][j];
+                    s2 += g[c][j] * xh[c][j];
+                    dsh[c][j] += df;
+                    dsc[c][j] += df * xh[c][j];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+        const float rstd = rstd_in[irow];
+        bf16* o = dhidden + ((int64_t)dst_row[f] + t) * H;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int off = (c * 64 + lane) * 8;
+            if (off < H) {
+                bf16x8 ob;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ob[j] = f2bf(rstd * (g[c][j] - m1 - xh[c][j] * m2));
+                *reinterpret_cast<bf16x8*>(o + off) = ob;
             }
         }
     }
-    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
-    const float rstd = rstd_in[irow];
-    bf16* o = dhidden + ((int64_t)dst_row[f] + t) * H;
+    if (t0 >= ntok) return;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int off = (c * 64 + lane) * 8;
         if (off < H) {
-            bf16x8 ob;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ob[j] = f2bf(rstd * (g[c][j] - m1 - xh[c][j] * m2));
-            *reinterpret_cast<bf16x8*>(o + off) = ob;
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(dmod + (int64_t)f * 2 * H + off + j, dsh[c][j]);      // dshift
+                atomicAdd(dmod + (int64_t)f * 2 * H + H + off + j, dsc[c][j]);  // dscale
+            }
         }
     }
 }
@@ -759,12 +782,14 @@ VGPT_EXPORT int vgpt_ln_mod_bwd(const void* dv, const float* xhat, const float* 
     VGPT_REQUIRE(dv && xhat && rstd && mod && dst_row && dhidden && dmod, VGPT_ERR_INVALID, "vgpt_ln_mod_bwd: null pointer");
     VGPT_REQUIRE(n_frames >= 0 && ntok > 0 && H % 8 == 0 && H <= 4096, VGPT_ERR_UNSUPPORTED, "vgpt_ln_mod_bwd: bad shape");
     if (n_frames == 0) return VGPT_OK;
-    dim3 grid((unsigned)cdiv(ntok, 4), n_frames);
+    // tokens per wave: enough waves to fill the chip, as few atomics per column as that allows
+    const int tpw = (int)std::max<int64_t>(1, std::min<int64_t>(16, (int64_t)n_frames * ntok / (256 * 4)));
+    dim3 grid((unsigned)cdiv(ntok, 4 * tpw), n_frames);
     hipStream_t s = (hipStream_t)stream;
 #define LB_CASE(N)                                                                                              \
     case N:                                                                                                     \
         hipLaunchKernelGGL(ln_mod_bwd_kernel<N>, grid, dim3(256), 0, s, (const bf16*)dv, xhat, rstd,            \
-                           (const bf16*)mod, dst_row, (bf16*)dhidden, dmod, ntok, (int)H);                      \
+                           (const bf16*)mod, dst_row, (bf16*)dhidden, dmod, ntok, (int)H, tpw);                 \
         break;
     switch ((int)cdiv(H, 512)) { LB_CASE(1) LB_CASE(2) LB_CASE(3) LB_CASE(4) LB_CASE(5) LB_CASE(6) LB_CASE(7) LB_CASE(8) }
 #undef LB_CASE
