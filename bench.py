@@ -361,6 +361,17 @@ def main():
                     eng._time_pass()   # the special rows of every step, also once per clip
             eng.run(args.steps, use_graph=use_graph)
         elapsed = D.timed_region(timed, torch.cuda.synchronize, device)
+        # the per-clip passes alone, once more (reported beside the timed number, never subtracted from it): with
+        # --steps other than the scheduler's 50 their share of a step differs from a real clip's
+        setup_s = 0.0
+        if reuse:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.prefill()
+            if eng.hoist:
+                eng._time_pass()
+            torch.cuda.synchronize()
+            setup_s = time.perf_counter() - t0
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     value = world * G * N * args.steps / elapsed
     finite = bool(torch.isfinite(eng.z).all().item())
@@ -479,6 +490,8 @@ def main():
                            "condition_prefix_reuse": reuse, "special_row_hoisting": hoisted,
                            "tokens_computed_per_step": rows_per_step,
                            "tokens_counted_per_step": real_tokens_step,
+                           "per_clip_setup_ms": round(setup_s * 1e3, 2),
+                           "ms_per_step_of_a_50_step_clip": round(((elapsed - setup_s) / max(args.steps, 1) * 50 + setup_s) / 50 * 1e3, 3),
                            "finite": finite},
                 "roofline": roof, "stage1_train": stage1}
         if breakdown:
