@@ -245,7 +245,10 @@ class StaticDenoiser:
         step-invariant), so nothing else is needed to produce them -- leaving every layer's (post-RoPE) q/k/v in
         qkv_full[l][:S].  Rows >= S of qkv_full are written by every step (zero until the first one: the buffer is
         zero-initialised so that masked keys are finite)."""
-        m, cfg, H, S = self.model, self.cfg, self.H, self.S0
+        m, cfg, H = self.model, self.cfg, self.H
+        # with hoisting the step-invariant `<|diffusion|>` rows (right behind the prefix) are computed here as well: they
+        # see the prefix and each other, nothing else
+        S = self.S0 + (self.hoist["nf"] if self.hoist else 0)
         nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         e = lambda *s: torch.empty(*s, dtype=BF16, device=self.dev)
         hid, nrm, ctx, act = e(1, S, H), e(1, S, H), e(1, S, nq * hd), e(1, S, cfg.intermediate_size)
@@ -310,35 +313,35 @@ class StaticDenoiser:
         return dict(perm=perm, inv=inv, S=S, nf=nf, ntok=ntok, segments=tuple(segs))
 
     def _time_pass(self):
-        """q/k/v rows of the `<|diffusion|>` and time tokens for EVERY denoise step in one batched forward: sequence
-        [prefix (K/V from the prefill) | gap | per step: n_frames diffusion rows, n_frames time rows], each step's
-        rows forming their own clip group so that steps do not see each other.  Leaves the diffusion rows' q/k/v
-        (step-invariant) in qkv_full and the time rows' in time_qkv[step]."""
+        """q/k/v rows of the time tokens for EVERY denoise step in one batched forward.  A time row sees the condition
+        prefix, the `<|diffusion|>` columns of its clip (both step-invariant: K/V from the prefill) and the time columns
+        of its own step.  Sequence of the pass: [prefix | gap | per step a COPY of the diffusion rows' K/V (keys only,
+        never queries) | gap | per step the n_frames time rows (the only rows computed)], every step's copies and time
+        rows forming their own clip group so that steps do not see each other.  Leaves time_qkv[step]."""
+        import numpy as np
         m, cfg, H, dev = self.model, self.cfg, self.H, self.dev
         nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         W3 = (nq + 2 * nk) * hd
         S0, nf, T = self.S0, self.hoist["nf"], self.num_steps
         lay = self.layout
-        P0 = (S0 + 127) // 128 * 128                     # first special row of the pass
-        n_sp = 2 * nf
-        Lp = P0 + T * n_sp
-        import numpy as np
-        idx = np.concatenate([np.arange(S0), np.full(P0 - S0, -1), np.tile(np.arange(S0, S0 + n_sp), T)])
+        P0 = (S0 + 127) // 128 * 128                     # first diffusion-key copy
+        P1 = (P0 + T * nf + 127) // 128 * 128            # first time row
+        Lp = P1 + T * nf
+        idx = np.concatenate([np.arange(S0), np.full(P0 - S0, -1), np.tile(np.arange(S0, S0 + nf), T),
+                              np.full(P1 - P0 - T * nf, -1), np.tile(np.arange(S0 + nf, S0 + 2 * nf), T)])
         lp = lay.permute(idx)
         grp = lp.grp.copy()
         base = int(lay.grp.max()) + 1
-        step_of = np.repeat(np.arange(T), n_sp)
-        old = grp[0, P0:]
-        uniq = {g: i for i, g in enumerate(sorted(set(old.tolist())))}
-        grp[0, P0:] = base + step_of * len(uniq) + np.array([uniq[g] for g in old.tolist()])
+        step_of = np.repeat(np.arange(T), nf)
+        for lo in (P0, P1):                               # one clip group per (clip, step), shared by copies and time rows
+            old = grp[0, lo:lo + T * nf]
+            uniq = {g: i for i, g in enumerate(sorted(set(lay.grp[0, S0:S0 + 2 * nf].tolist())))}
+            grp[0, lo:lo + T * nf] = base + step_of * len(uniq) + np.array([uniq[g] for g in old.tolist()])
         lp = lp.with_groups(grp)
         pm = lp.packed_mask(dev)
         e = lambda *s_, dt=BF16: torch.empty(*s_, dtype=dt, device=dev)
-        Ms = T * n_sp
+        Ms = T * nf
         hid, nrm, ctx, act = e(1, Ms, H), e(1, Ms, H), e(1, Ms, nq * hd), e(1, Ms, cfg.intermediate_size)
-        # inputs: token embedding of `<|diffusion|>` for the diffusion rows, time_token(sigma_s) for the time rows
-        ids = self.input_ids[0, S0:S0 + n_sp].repeat(T).view(1, Ms).contiguous()
-        ops.embed_gather(ids, m.llm.embed_tokens.weight, out=hid)
         # time_token(sigma_s): one value per step (every frame of a step carries the same t, LVM/scheduler.py:169),
         # through the same small-M kernels as the per-step path (at most 32 rows per call), then broadcast to the rows
         ts = self.sigma[:T].contiguous()
@@ -348,32 +351,32 @@ class StaticDenoiser:
         for c in range(0, T, 32):
             ops.linear_small(sin[c:c + 32], tt[0].weight, tt[0].bias, post_act=ops.ACT_SILU, out=tt_h[c:c + 32])
             ops.linear_small(tt_h[c:c + 32], tt[2].weight, tt[2].bias, out=tt_o[c:c + 32])
-        hid.view(T, n_sp, H)[:, nf:] = tt_o[:, None, :]
-        pos = torch.cat([self.position_ids[0, :S0], torch.zeros(P0 - S0, dtype=self.position_ids.dtype, device=dev),
-                         self.position_ids[0, S0:S0 + n_sp].repeat(T)]).view(1, Lp)
+        hid.view(T, nf, H)[:] = tt_o[:, None, :]
+        zpos = lambda n_: torch.zeros(n_, dtype=self.position_ids.dtype, device=dev)
+        pos = torch.cat([self.position_ids[0, :S0], zpos(P0 - S0), self.position_ids[0, S0:S0 + nf].repeat(T),
+                         zpos(P1 - P0 - T * nf), self.position_ids[0, S0 + nf:S0 + 2 * nf].repeat(T)]).view(1, Lp)
         rope = m.llm.rope_tables(pos)
-        rope_s = (rope[0][P0:].contiguous(), rope[1][P0:].contiguous())
+        rope_s = (rope[0][P1:].contiguous(), rope[1][P1:].contiguous())
         buf = torch.zeros(Lp, W3, dtype=BF16, device=dev)
         shape = (T, cfg.num_hidden_layers, nf, W3)
         if self.time_qkv is None or tuple(self.time_qkv.shape) != shape:
             self.time_qkv = e(*shape)      # a captured graph reads this buffer: re-allocating invalidates it
             self.graph = None
-        seg = ((0, P0, Lp),)
+        seg = ((0, P1, Lp),)
         for li, layer in enumerate(m.llm.layers):
             at, mlp = layer.self_attn, layer.mlp
             full = self.qkv_full[li]
             buf[:S0].copy_(full[:S0])
+            buf[P0:P0 + T * nf].view(T, nf, W3).copy_(full[S0:S0 + nf].unsqueeze(0).expand(T, nf, W3))
             ops.rmsnorm(hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=nrm)
-            ops.linear(nrm, at.qkv_proj.weight, out=buf[P0:])
-            ops.rope_qk_inplace(buf[P0:], rope_s[0], rope_s[1], nq, nk, hd)
-            ops.attention_qkv_range(buf.view(1, Lp, -1), pm, nq, nk, hd, P0, ctx, segments=seg)
+            ops.linear(nrm, at.qkv_proj.weight, out=buf[P1:])
+            ops.rope_qk_inplace(buf[P1:], rope_s[0], rope_s[1], nq, nk, hd)
+            ops.attention_qkv_range(buf.view(1, Lp, -1), pm, nq, nk, hd, P1, ctx, segments=seg)
             ops.linear(ctx, at.o_proj.weight, residual=hid, out=hid)
             ops.rmsnorm(hid, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon, out=nrm)
             ops.gated_mlp_act(nrm, mlp.gate_up_proj.weight, mlp.act, out=act)
             ops.linear(act, mlp.down_proj.weight, residual=hid, out=hid)
-            sp = buf[P0:].view(T, n_sp, W3)
-            full[S0:S0 + nf].copy_(sp[0, :nf])                   # diffusion rows: the same at every step
-            self.time_qkv[:, li].copy_(sp[:, nf:])
+            self.time_qkv[:, li].copy_(buf[P1:].view(T, nf, W3))
         self.time_dst = self.qkv_full[:, S0 + nf:S0 + 2 * nf]    # (layers, nf, 3H) view the step copy writes
         torch.cuda.current_stream().synchronize()
 
