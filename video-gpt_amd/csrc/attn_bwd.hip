@@ -100,8 +100,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
                                                          int64_t do_sh, int64_t do_ss) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)B * n_heads * L) return;
-    const int q = (int)(idx % L);
-    const int hd = (int)((idx / L) % n_heads);
+    // head fastest: the 64 lanes of a wave read 64 consecutive 192-byte head slices (two whole token rows of the
+    // (B, L, heads*d) layout) instead of 64 slices 6 KB apart
+    const int hd = (int)(idx % n_heads);
+    const int q = (int)((idx / n_heads) % L);
     const int b = (int)(idx / ((int64_t)L * n_heads));
     const bf16* op = o + b * o_sb + hd * o_sh + (int64_t)q * o_ss;
     const bf16* dp = dout + b * do_sb + hd * do_sh + (int64_t)q * do_ss;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += bf2f(a[j]) * bf2f(d[j]);
     }
-    delta[idx] = s;
+    delta[((int64_t)b * n_heads + hd) * L + q] = s;
 }
 
 // ------------------------------------------------------------------------------------------------------
