@@ -355,23 +355,18 @@ def main():
         stream.synchronize()
         # barrier + synchronize on both sides, MAX over ranks (dist_utils.timed_region)
         def timed():
-            if reuse:
-                eng.prefill()          # once per clip; inside the timed region
-                if eng.hoist:
-                    eng._time_pass()   # the special rows of every step, also once per clip
+            eng.per_clip_setup()       # prefill + special rows + adaLN table: once per clip, inside the timed region
+            eng.steps_taken = args.warmup
             eng.run(args.steps, use_graph=use_graph)
         elapsed = D.timed_region(timed, torch.cuda.synchronize, device)
         # the per-clip passes alone, once more (reported beside the timed number, never subtracted from it): with
         # --steps other than the scheduler's 50 their share of a step differs from a real clip's
         setup_s = 0.0
-        if reuse:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            eng.prefill()
-            if eng.hoist:
-                eng._time_pass()
-            torch.cuda.synchronize()
-            setup_s = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.per_clip_setup()
+        torch.cuda.synchronize()
+        setup_s = time.perf_counter() - t0
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     value = world * G * N * args.steps / elapsed
     finite = bool(torch.isfinite(eng.z).all().item())
@@ -391,14 +386,26 @@ def main():
             ev.append((s, e))
             return out
 
+        orig_qkv = ops.linear_qkv_rope
+
+        def timed_qkv(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(stream)
+            out = orig_qkv(*a, **k)
+            e.record(stream)
+            ev.append((s, e))
+            return out
+
         with torch.cuda.stream(stream):
             ops.linear = timed_linear
+            ops.linear_qkv_rope = timed_qkv
             try:
                 eng.step.zero_()
                 ops.sampler_set_timesteps(eng.sigma, eng.step, eng.ts)
-                eng.forward_step()
+                eng.forward_step(from_tables=True)
             finally:
                 ops.linear = orig_linear
+                ops.linear_qkv_rope = orig_qkv
             stream.synchronize()
         t_gemm = sum(s.elapsed_time(e) for s, e in ev) * 1e-3
         n_launch = len(ev)
@@ -424,7 +431,7 @@ def main():
                     mfma_busy = round(sum(n * v for n, v in recs) / sum(n for n, _ in recs), 4)
         except Exception:
             mfma_busy = None
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<MODE_PLAIN> (qkv_proj/o_proj/down_proj)",
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<MODE_PLAIN | MODE_ROPE> (qkv_proj with the RoPE epilogue, o_proj, down_proj)",
                 "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "mfma_busy_pmc": mfma_busy,
                 "launches": n_launch, "avg_launch_us": round(t_gemm / max(n_launch, 1) * 1e6, 1),
@@ -435,7 +442,7 @@ def main():
 
     breakdown = None
     if rank == 0 and args.breakdown:
-        names = ["linear", "gated_mlp_act", "attention_qkv", "attention_qkv_range", "rmsnorm", "rope_qk_inplace"]
+        names = ["linear", "linear_qkv_rope", "gated_mlp_act", "attention_qkv", "attention_qkv_range", "rmsnorm", "rope_qk_inplace"]
         evs = {n: [] for n in names}
         saved = {n: getattr(ops, n) for n in names}
 
@@ -457,7 +464,7 @@ def main():
                         evs[n].clear()
                     eng.step.zero_()
                     ops.sampler_set_timesteps(eng.sigma, eng.step, eng.ts)
-                    eng.forward_step()
+                    eng.forward_step(from_tables=True)
             finally:
                 for n in names:
                     setattr(ops, n, saved[n])

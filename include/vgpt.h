@@ -56,11 +56,13 @@ int vgpt_abi_version(void);
 int vgpt_rmsnorm_fwd(const void* x, const void* w, void* y, int64_t rows, int64_t H, float eps,
                      void* stream);
 
-/* Phi3RotaryEmbedding.forward (cos/sin table): cos/sin[t][i] = f(pos[t] * inv_freq[i]),
+/* Phi3RotaryEmbedding.forward (cos/sin table): cos/sin[t][i] = scale * f(pos[t] * inv_freq[i]),
  * i < half; rounded to bf16 and stored back as fp32 when round_bf16 != 0 (the
- * reference casts cos/sin to the model dtype, LVM/transform/sdpa_transform.py:52). */
+ * reference casts cos/sin to the model dtype, LVM/transform/sdpa_transform.py:52).  scale = 1 for
+ * plain RoPE; for rope_scaling "su"/"longrope" checkpoints the caller passes the rescaled inv_freq
+ * (short / long factors) and the attention factor as `scale` (HF Phi3LongRoPEScaledRotaryEmbedding). */
 int vgpt_rope_table(const int64_t* position_ids, const float* inv_freq, float* cos_out,
-                    float* sin_out, int64_t tokens, int half, int round_bf16, void* stream);
+                    float* sin_out, int64_t tokens, int half, int round_bf16, float scale, void* stream);
 
 /* apply_rotary_pos_emb on the q and k parts of a fused qkv buffer, in place
  * (LVM/transform/sdpa_transform.py:53). qkv: (tokens, (n_q+2*n_kv)*hd) bf16;
@@ -76,6 +78,16 @@ int vgpt_rope_qk_inplace(void* qkv, const float* cos_t, const float* sin_t, int6
 int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void* extra, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int epilogue,
                    void* stream);
+
+/* qkv_proj followed by apply_rotary_pos_emb in one kernel (LVM/transform/sdpa_transform.py:39,52-53): C = A W^T rounded
+ * to bf16 (the Linear's output), then columns [0, n_rot_heads * head_dim) -- the q heads followed by the k heads --
+ * rotated per token: out[d] = x[d] cos[d] - x[d + hd/2] sin[d], out[d + hd/2] = x[d + hd/2] cos[d] + x[d] sin[d] with
+ * cos / sin (M, head_dim / 2) fp32 from vgpt_rope_table (row m = token m of A); the remaining columns (v) are stored
+ * unrotated.  Same result as vgpt_gemm_bf16 + vgpt_rope_qk_inplace without writing and re-reading q and k.
+ * N % 16 == 0, head_dim % 16 == 0, K % 64 == 0. */
+int vgpt_gemm_bf16_rope(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t, int64_t M,
+                        int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int n_rot_heads, int head_dim,
+                        void* stream);
 /* The same product with operands stored transposed, for the backward of the Linear layers without materialising a
  * transpose (the reference gets these from torch.autograd: dX = dY W, dW = dY^T X):
  *   w_transposed: W is stored (K, N) row-major (ldw = its row stride)   -> dX[M,N'] = dY[M,K'] W[K',N']
@@ -223,15 +235,17 @@ int vgpt_final_layer_fwd(const void* hidden, const int32_t* src_row, const void*
 
 /* ---- sampler (LVM/scheduler.py:161-208) ---------------------------------- */
 
-/* timesteps[i] = sigma[*step] for i < n (scheduler.py:169). */
-int vgpt_sampler_set_timesteps(const float* sigma, const int32_t* step, float* timesteps, int n,
+/* timesteps[i] = sigma[*step] for i < n (scheduler.py:169).  sigma holds n_steps + 1 entries; with *step outside
+ * [0, n_steps] nothing is written (a graph replayed past the end of the table must not read beyond it). */
+int vgpt_sampler_set_timesteps(const float* sigma, const int32_t* step, int n_steps, float* timesteps, int n,
                                void* stream);
 /* One Euler step with optional x1->v conversion and image CFG (scheduler.py:178-204).
  * z: (n_frames, elems) fp32 state, z_model: same shape bf16 copy handed to the model,
  * pred: (n_frames, elems) bf16. With use_cfg the first half of the frames is the
- * conditional branch, the second half the unconditional one. */
+ * conditional branch, the second half the unconditional one.  sigma holds n_steps + 1 entries; with *step outside
+ * [0, n_steps) the state is left untouched. */
 int vgpt_euler_cfg_update(float* z, void* z_model, const void* pred, const float* sigma,
-                          const int32_t* step, int n_frames, int64_t elems, int pred_type,
+                          const int32_t* step, int n_steps, int n_frames, int64_t elems, int pred_type,
                           int use_cfg, float cfg_scale, void* stream);
 /* *step += 1 */
 int vgpt_sampler_advance(int32_t* step, void* stream);

@@ -155,3 +155,215 @@ def reference_frame_block_training_batch(frame_blocks_list, N: int, sp: int = 1)
     coll = ns.LVMCollator(pad_token_id=2, hidden_size=8, sequence_parallel_size=sp)
     ids, pos, mask, pixel_values, sizes, fb = coll.process_mllm_input_frame_block_training(rows)
     return dict(input_ids=ids, position_ids=pos, attention_mask=mask, image_sizes=sizes, frame_blocks=fb)
+
+
+# ------------------------------------------------------------------------------------------------
+# LVM-owned glue executed from the reference's own source (SURVEY §8a rows 3,4,5,9,10,11,15,16):
+# LVM / LVMTraining (LVM/model.py:157-566, 569-857), Phi3Transformer.forward (OmniGen/transformer.py:35-232),
+# new_forward / new_attn_forward / replace_attention (LVM/transform/sdpa_transform.py:12-169),
+# training_losses_x1_noise_input + samplers (LVM/train_helper/loss.py:73-250), broadcast_data (LVM/utils.py:177-311).
+#
+# What is NOT the reference here (third-party pins absent from the container):
+#   * transformers==4.47.1 Phi3RMSNorm / Phi3MLP / Phi3RotaryEmbedding / apply_rotary_pos_emb / repeat_kv come from the
+#     INSTALLED transformers (5.x: same formulas; adapters below only restore the 4.47.1 call signatures the reference
+#     uses), and the 4.47.1 decoder-layer glue `x + attn(norm(x))`, `h + mlp(norm(h))` is `_DecoderLayer447`;
+#   * deepspeed==0.15.2 DistributedAttention / _SeqAllToAll are world-size-1 identities (`_DistributedAttention`,
+#     `_SeqAllToAllIdentity`); torch.distributed is the real one on a 1-rank gloo group.
+# ------------------------------------------------------------------------------------------------
+
+def _single_rank_group():
+    """1-rank gloo group: LVM.forward all-gathers unconditionally (LVM/model.py:371-377) and the loss
+    broadcasts its noise (LVM/train_helper/loss.py:150,168-172), so the reference needs a process group."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", store=dist.HashStore(), rank=0, world_size=1)
+    return dist
+
+
+def _hf():
+    from transformers import Phi3Config
+    from transformers.models.phi3 import modeling_phi3 as M
+    return Phi3Config, M
+
+
+class _SeqAllToAllIdentity:
+    """deepspeed.sequence.layer._SeqAllToAll at sequence-parallel size 1: the all-to-all is the identity."""
+
+    @staticmethod
+    def apply(group, x, scatter_idx, gather_idx, batch_dim_idx, stream, handles, kind):
+        return x
+
+
+class _DistributedAttention(torch.nn.Module):
+    """Attribute surface of deepspeed 0.15.2 DistributedAttention that new_attn_forward reads."""
+
+    def __init__(self, local_attention, sequence_process_group, scatter_idx=2, gather_idx=1, sp_stream=None):
+        super().__init__()
+        self.local_attn = local_attention
+        self.spg = sequence_process_group
+        self.scatter_idx, self.gather_idx = scatter_idx, gather_idx
+        self.sp_overlap_comm = False
+        self.overlap_handles = None
+        self.sp_stream = sp_stream
+
+    def layer_sync(self, layer):
+        return None
+
+
+def hf_config(cfg):
+    """Installed-transformers Phi3Config for an oracle.restate.Phi3Cfg."""
+    Phi3Config, _ = _hf()
+    return Phi3Config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                      num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                      num_key_value_heads=cfg.num_key_value_heads, rms_norm_eps=cfg.rms_norm_eps,
+                      hidden_act=cfg.hidden_act, pad_token_id=cfg.pad_token_id, eos_token_id=None, bos_token_id=None,
+                      rope_parameters={"rope_theta": cfg.rope_theta, "rope_type": "default"})
+
+
+def lvm_reference_classes():
+    """Returns a namespace with the reference's LVM, LVMTraining, Phi3Transformer, replace_attention,
+    training_losses_x1_noise_input (and hccl_info) — reference code, executable on CPU at world size 1."""
+    Phi3Config, M = _hf()
+    from transformers.modeling_outputs import BaseModelOutputWithPast
+    from transformers.cache_utils import Cache, DynamicCache
+    from transformers.utils import logging as hf_logging
+    from types import MethodType
+    from typing import Any
+    import random
+    dist = _single_rank_group()
+    hccl_info = types.SimpleNamespace(world_size=1, rank=0, group=None)
+    nn = torch.nn
+
+    class _Rotary447(nn.Module):
+        """4.47.1 call form `rotary_emb(x, position_ids, seq_len=None)` over the installed Phi3RotaryEmbedding."""
+
+        def __init__(self, config):
+            super().__init__()
+            self.inner = M.Phi3RotaryEmbedding(config)
+
+        def forward(self, x, position_ids, seq_len=None):
+            return self.inner(x, position_ids)
+
+    def apply_rotary_pos_emb(q, k, cos, sin, position_ids=None, unsqueeze_dim=1):
+        """4.47.1 signature (position_ids is deprecated and unused there as well)."""
+        return M.apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=unsqueeze_dim)
+
+    class Phi3SdpaAttention(nn.Module):
+        """Module attributes of transformers 4.47.1 Phi3Attention that new_forward reads; no forward of its own."""
+
+        def __init__(self, config, layer_idx):
+            super().__init__()
+            self.config, self.layer_idx = config, layer_idx
+            self.attention_dropout = config.attention_dropout
+            self.hidden_size = config.hidden_size
+            self.num_heads = config.num_attention_heads
+            self.head_dim = self.hidden_size // self.num_heads
+            self.num_key_value_heads = config.num_key_value_heads
+            self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+            op_size = self.num_heads * self.head_dim + 2 * (self.num_key_value_heads * self.head_dim)
+            self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
+            self.qkv_proj = nn.Linear(self.hidden_size, op_size, bias=False)
+            self.rotary_emb = _Rotary447(config)
+
+    class _DecoderLayer447(nn.Module):
+        """transformers 4.47.1 Phi3DecoderLayer.forward (third-party glue, restated): returns a tuple."""
+
+        def __init__(self, config, layer_idx):
+            super().__init__()
+            self.self_attn = Phi3SdpaAttention(config, layer_idx)
+            self.mlp = M.Phi3MLP(config)
+            self.input_layernorm = M.Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+            self.post_attention_layernorm = M.Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+        def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
+                    output_attentions=False, use_cache=False, cache_position=None):
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+            attn, _, present = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask,
+                                              position_ids=position_ids, past_key_value=past_key_value,
+                                              output_attentions=output_attentions, use_cache=use_cache,
+                                              cache_position=cache_position)
+            hidden_states = residual + attn
+            residual = hidden_states
+            hidden_states = self.mlp(self.post_attention_layernorm(hidden_states))
+            return (residual + hidden_states,)
+
+    class Phi3Model(nn.Module):
+        """Module tree of transformers Phi3Model (embed_tokens, layers, norm) without its forward."""
+
+        def __init__(self, config):
+            super().__init__()
+            self.config = config
+            self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, config.pad_token_id)
+            self.layers = nn.ModuleList([_DecoderLayer447(config, i) for i in range(config.num_hidden_layers)])
+            self.norm = M.Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+            self.gradient_checkpointing = False
+            self._gradient_checkpointing_func = (
+                lambda fn, *a: torch.utils.checkpoint.checkpoint(fn, *a, use_reentrant=False))
+
+    tr = _extract("OmniGen/transformer.py", ["Phi3Transformer"],
+                  extra_ns={"Phi3Model": Phi3Model, "torch_npu": None, "logger": hf_logging.get_logger("reference"),
+                            "Cache": Cache, "DynamicCache": DynamicCache,
+                            "BaseModelOutputWithPast": BaseModelOutputWithPast})
+    sd = _extract("LVM/transform/sdpa_transform.py", ["new_forward", "new_attn_forward", "replace_attention"],
+                  extra_ns={"Phi3SdpaAttention": Phi3SdpaAttention, "DistributedAttention": _DistributedAttention,
+                            "_SeqAllToAll": _SeqAllToAllIdentity, "hccl_info": hccl_info, "MethodType": MethodType,
+                            "apply_rotary_pos_emb": apply_rotary_pos_emb, "repeat_kv": M.repeat_kv, "Tensor": torch.Tensor,
+                            "Any": Any, "Cache": Cache, "logger": hf_logging.get_logger("reference")})
+
+    class PeftAdapterMixin:  # diffusers.loaders.PeftAdapterMixin: LoRA plumbing only, no arithmetic
+        pass
+
+    from safetensors.torch import load_file
+    md = _extract("LVM/model.py", ["modulate", "TimestepEmbedder", "FinalLayer", "get_2d_sincos_pos_embed",
+                                   "get_2d_sincos_pos_embed_from_grid", "get_1d_sincos_pos_embed_from_grid",
+                                   "PatchEmbedMR", "LVM", "LVMTraining"],
+                  extra_ns={"PeftAdapterMixin": PeftAdapterMixin, "Phi3Config": Phi3Config,
+                            "Phi3Transformer": tr.Phi3Transformer, "hccl_info": hccl_info, "dist": dist, "os": os,
+                            "snapshot_download": None, "load_file": load_file})
+    ut = _extract("LVM/utils.py", ["_broadcast_tensor", "is_numeric_sequence", "broadcast_data"],
+                  extra_ns={"dist": dist})
+    ls = _extract("LVM/train_helper/loss.py",
+                  ["sample_x0", "sample_timestep", "sample_exp_timestep", "sample_frame_block_timestep",
+                   "sample_timestep_max_noise", "training_losses_x1_noise_input", "mean_flat"],
+                  extra_ns={"dist": dist, "hccl_info": hccl_info, "broadcast_data": ut.broadcast_data, "random": random})
+    return types.SimpleNamespace(LVM=md.LVM, LVMTraining=md.LVMTraining, Phi3Transformer=tr.Phi3Transformer,
+                                 replace_attention=sd.replace_attention, new_forward=sd.new_forward,
+                                 training_losses_x1_noise_input=ls.training_losses_x1_noise_input,
+                                 sample_frame_block_timestep=ls.sample_frame_block_timestep, hccl_info=hccl_info)
+
+
+def build_reference_model(cfg, params, cls_name="LVM"):
+    """Reference LVM / LVMTraining with the oracle's seeded parameters (same state_dict keys, strict) and the
+    reference's own attention seam installed (replace_attention, LVM/inference/...inference.py:70)."""
+    ns = lvm_reference_classes()
+    model = getattr(ns, cls_name)(hf_config(cfg), patch_size=cfg.patch_size, in_channels=cfg.in_channels,
+                                  pe_interpolation=cfg.pe_interpolation, pos_embed_max_size=cfg.pos_embed_max_size)
+    sd = {k: v for k, v in params.items()}
+    own = model.state_dict()
+    extra = [k for k in own if k not in sd]
+    # the only keys the oracle dict lacks are the rotary inv_freq buffers of the installed transformers module
+    assert all("rotary_emb" in k for k in extra), extra
+    model.load_state_dict(sd, strict=False)
+    assert not [k for k in sd if k not in own], [k for k in sd if k not in own]
+    ns.replace_attention(model.llm)
+    return model.eval(), ns
+
+
+def reference_single_target_batch(n_images: int, side: int, out_hw, use_cfg: bool = True, sp: int = 1, via="call"):
+    """LVMProcessor.__call__ / prompt_condition_inference (LVM/processor.py:282-364) + LVMCollator.__call__ (:943-962) for
+    one instruction `<img><|image_i|></img>...` with `n_images` condition images of side x side pixels (what
+    LVMPipeline.__call__ builds, LVM/pipeline.py:220-238)."""
+    ns = collator_classes()
+    proc = types.SimpleNamespace(text_tokenizer=StubTokenizer(), process_image=lambda x: x)
+    P = ns.LVMProcessor
+    proc.add_prefix_instruction = lambda prompt: P.add_prefix_instruction(proc, prompt)
+    proc.process_multi_modal_prompt = lambda text, imgs: P.process_multi_modal_prompt(proc, text, imgs)
+    proc.collator = ns.LVMCollator(pad_token_id=2, hidden_size=8, sequence_parallel_size=sp)
+    prompt = "".join(f"<img><|image_{i + 1}|></img>" for i in range(n_images))
+    images = [torch.zeros(3, side, side) for _ in range(n_images)] if n_images else None
+    if via == "call":
+        return P.__call__(proc, [prompt], [images] if images is not None else None, height=out_hw[0], width=out_hw[1],
+                          use_img_cfg=use_cfg)
+    return P.prompt_condition_inference(proc, [prompt, ""], [images, None] if images is not None else None,
+                                        height=out_hw[0], width=out_hw[1], use_img_cfg=use_cfg)

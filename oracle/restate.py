@@ -127,12 +127,26 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     return weight * xf.to(dt)
 
 
-def rope_cos_sin(position_ids: torch.Tensor, head_dim: int, theta: float, dtype):
-    """HF Phi3RotaryEmbedding.forward: inv_freq = 1/theta^(2i/d), fp32 freqs, emb=[f|f], cast to dtype."""
-    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+def rope_cos_sin(position_ids: torch.Tensor, head_dim: int, theta: float, dtype, rope_scaling=None,
+                 max_position_embeddings: int = 4096, original_max_position_embeddings: Optional[int] = None):
+    """HF Phi3RotaryEmbedding.forward: inv_freq = 1/theta^(2i/d), fp32 freqs, emb=[f|f], cast to dtype.
+    rope_scaling {"type": "su"|"longrope", short_factor, long_factor} = HF 4.47.1 Phi3LongRoPEScaledRotaryEmbedding:
+    inv_freq = 1/(ext * theta^(2i/d)) with ext = long_factor when max(position_ids)+1 > original_max else short_factor,
+    cos / sin scaled by sqrt(1 + ln(max/orig)/ln(orig)) when max > orig."""
+    shape = torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim
+    scale = 1.0
+    if rope_scaling is None:
+        inv_freq = 1.0 / (theta ** shape)
+    else:
+        orig = original_max_position_embeddings or max_position_embeddings
+        long = int(position_ids.max()) + 1 > orig
+        ext = torch.tensor(rope_scaling["long_factor" if long else "short_factor"], dtype=torch.float32)
+        inv_freq = 1.0 / (ext * theta ** shape)
+        f = max_position_embeddings / orig
+        scale = 1.0 if f <= 1.0 else math.sqrt(1 + math.log(f) / math.log(orig))
     freqs = position_ids[:, :, None].float() * inv_freq[None, None, :]
     emb = torch.cat((freqs, freqs), dim=-1)
-    return emb.cos().to(dtype), emb.sin().to(dtype)
+    return (emb.cos() * scale).to(dtype), (emb.sin() * scale).to(dtype)
 
 
 def rotate_half(x: torch.Tensor) -> torch.Tensor:

@@ -37,7 +37,7 @@ def flat_sizes(d):
     for b, items in d.items():
         for it in items:
             rows.append([b, *it] if isinstance(it, (list, tuple)) else [b, it])
-    return np.asarray(rows, dtype=np.int64).reshape(len(rows), -1)
+    return np.asarray(rows, dtype=np.int64).reshape(len(rows), -1) if rows else np.zeros((0, 3), dtype=np.int64)
 
 
 def save_batch(name, batch, extra=None):
@@ -64,6 +64,17 @@ def collator_vectors():
         flat = np.asarray([x for fb in fbl for x in fb] + [-1] + [len(fb) for fb in fbl])
         save_batch(f"ref_collator_fbtrain_{'x'.join(str(len(f)) for f in fbl)}N{N}.npz", b,
                    dict(frame_blocks_flat=flat, N=N))
+
+    # single-target path (LVMPipeline.__call__): LVMProcessor.__call__ / prompt_condition_inference + LVMCollator.__call__
+    for n_img, side, hw, cfg_on, sp, via in [(2, 64, (64, 64), True, 1, "call"), (0, 64, (32, 64), True, 1, "call"),
+                                             (3, 32, (64, 64), True, 4, "cond"), (1, 64, (64, 32), False, 1, "call")]:
+        b = X.reference_single_target_batch(n_img, side, hw, cfg_on, sp, via)
+        bits, shape = pack_mask(b["attention_mask"])
+        d = dict(input_ids=b["input_ids"].numpy(), position_ids=b["position_ids"].numpy(), mask_bits=bits, mask_shape=shape,
+                 input_image_sizes=flat_sizes(b["input_image_sizes"]),
+                 padding_lens=np.asarray([0 if p is None else p.shape[1] for p in b["padding_images"]]),
+                 n_pixel_values=len(b["input_pixel_values"]))
+        np.savez_compressed(os.path.join(OUT, f"ref_collator_call_I{n_img}s{side}o{hw[0]}x{hw[1]}cfg{int(cfg_on)}sp{sp}{via}.npz"), **d)
 
 
 def scheduler_vectors():
@@ -126,6 +137,126 @@ def leaf_vectors():
     np.savez_compressed(os.path.join(OUT, "ref_leaf_modules.npz"), **out)
 
 
+def lvm_glue_vectors():
+    """The REFERENCE'S OWN LVM (LVM/model.py:157-566) over its own Phi3Transformer.forward (OmniGen/transformer.py:71-232)
+    and attention seam (LVM/transform/sdpa_transform.py:12-169), executed by oracle/extract_reference.py on the tiny
+    next-clip case of tests/smoke_case.py; sampled with the reference's own LVMScheduler (LVM/scheduler.py:119-208)."""
+    from tests import smoke_case as SC
+    from tests import glue_cases as GC
+    cfg = R.TINY
+    p, batch, z, cond = SC.build_case(cfg)
+    model, ns = X.build_reference_model(cfg, p, "LVM")
+    okw = {k: batch[k] for k in GC.BATCH_KEYS}
+    out = {}
+    t = torch.full((len(z),), 0.3)
+    Sched = X.scheduler_class()
+    with torch.no_grad():
+        for pt in ("x1", "v"):
+            o, cache = model.frame_block_forward_with_cfg([x.clone() for x in z], t, input_img_latents=cond, use_img_cfg=True,
+                                                          img_cfg_scale=1.6, past_key_values=None, use_kv_cache=False,
+                                                          offload_model=False, vae=None, prediction_type=pt, **okw)
+            out[f"fwd_{pt}"] = torch.cat(o).numpy()
+            kw = dict(okw, input_img_latents=cond, use_img_cfg=True, img_cfg_scale=1.6, use_kv_cache=False,
+                      offload_model=False, vae=None)
+            s = Sched(num_steps=3, time_shifting_factor=1)
+            zs = s([x.clone() for x in z], model.frame_block_forward_with_cfg, kw, use_kv_cache=False, prediction_type=pt)
+            out[f"sample3_{pt}"] = torch.cat(zs).numpy()
+        # CFG off (single row), 'v'
+        p1, batch1, z1, cond1 = SC.build_case(cfg, use_cfg=False)
+        okw1 = {k: batch1[k] for k in GC.BATCH_KEYS}
+        o, _ = model.frame_block_forward_with_cfg([x.clone() for x in z1], torch.full((len(z1),), 0.6), input_img_latents=cond1,
+                                                  use_img_cfg=False, img_cfg_scale=1.6, past_key_values=None,
+                                                  use_kv_cache=False, offload_model=False, vae=None, prediction_type="v", **okw1)
+        out["fwd_nocfg_v"] = torch.cat(o).numpy()
+        # Phi3Transformer.forward alone: 3-D bool mask -> additive mask, layer loop, final norm
+        g = torch.Generator("cpu").manual_seed(5)
+        B, L = batch["input_ids"].shape
+        emb = (torch.randn(B, L, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).float()
+        out["llm_hidden"] = model.llm(inputs_embeds=emb, attention_mask=batch["attention_mask"],
+                                      position_ids=batch["position_ids"]).last_hidden_state.numpy()
+        try:
+            model.llm(inputs_embeds=emb, attention_mask=torch.ones(B, L), position_ids=batch["position_ids"])
+            out["mask2d_error"] = np.asarray("")
+        except Exception as e:  # the reference's own exception text
+            out["mask2d_error"] = np.asarray(str(e))
+        # LVM.forward / forward_with_cfg (single target)
+        c = GC.single_target_case(cfg)
+        o, _ = model.forward(c["x"], c["t"], c["ids"], c["lat"], c["sizes"], c["mask"], c["pos"])
+        out["single_fwd"] = o.numpy()
+        o, _ = model.forward_with_cfg(c["x"], c["t"], c["ids"], c["lat"], c["sizes"], c["mask"], c["pos"], True, 1.6, None,
+                                      False, False, prediction_type="v")
+        out["single_cfg_v"] = o.numpy()
+        Lc, N = c["Lc"], c["N"]
+        o = model.forward(c["x"], c["t"], None, None, None, c["mask"][:, Lc:, Lc:].contiguous(),
+                          c["pos"][:, : N + 1].contiguous(), return_past_key_values=False)
+        out["single_nocond"] = o.numpy()
+    np.savez_compressed(os.path.join(OUT, "ref_lvm_glue_tiny.npz"), **out)
+
+
+def _run_reference_loss(model, ns, x1, clean, batch, seed, frame_blocks=None):
+    """training_losses_x1_noise_input (LVM/train_helper/loss.py:128-243) on the reference LVMTraining; the noise / times
+    it draws from torch's (and python's) global RNG are recovered by replaying the same draws after the same seed."""
+    import random
+    from tests import glue_cases as GC
+    x1l, cl = list(x1.split(1)), list(clean.split(1))
+    torch.manual_seed(seed); random.seed(seed)
+    x0 = [torch.randn_like(a) for a in x1l]                                   # sample_x0(x1)            loss.py:155
+    if frame_blocks is None:
+        t = torch.rand(len(x1l))                                             # sample_timestep          :160
+    else:
+        t = torch.tensor([v for b in frame_blocks for fb in frame_blocks[b] for v in [random.random()] * fb])  # :162
+    x0i = [torch.randn_like(a) for a in cl]                                   # sample_x0(inputs)        :164
+    ti = 0.9 + (1 - 0.9) * torch.rand(len(cl))                                # sample_timestep_max_noise :166
+    seen = {}
+    inner = model.forward
+
+    def spy(xt, tt, **kw):
+        seen["xt"], seen["t"], seen["inp"] = [a.clone() for a in xt], tt.clone(), [a.clone() for a in kw["input_img_latents"]]
+        res = inner(xt, tt, **kw)
+        seen["pred"] = [a.detach().clone() for a in res]
+        return res
+    model.forward = spy
+    kw = {k: batch[k] for k in GC.BATCH_KEYS}
+    kw.update(input_img_latents=[a.clone() for a in cl], return_past_key_values=False)
+    torch.manual_seed(seed); random.seed(seed)
+    model.zero_grad()
+    terms = ns.training_losses_x1_noise_input(model, [a.clone() for a in x1l], kw, frame_blocks=frame_blocks, device="cpu")
+    model.forward = inner
+    terms["loss"].mean().backward()                                           # train_x1_stage1_noiseinput.py:378-380
+    assert torch.equal(seen["t"], t)
+    for i in range(len(x1l)):
+        assert torch.equal(seen["xt"][i], t[i] * x1l[i] + (1 - t[i]) * x0[i])
+    for i in range(len(cl)):
+        assert torch.equal(seen["inp"][i], ti[i] * cl[i] + (1 - ti[i]) * x0i[i])
+    out = dict(x0=torch.cat(x0).numpy(), t=t.numpy(), x0_in=torch.cat(x0i).numpy(), t_in=ti.numpy(),
+               xt=torch.cat(seen["xt"]).numpy(), pred=torch.cat(seen["pred"]).numpy(), loss=terms["loss"].detach().numpy())
+    for name, prm in model.named_parameters():
+        if prm.grad is not None:
+            out["gnorm." + name] = np.asarray(float(prm.grad.double().norm()))
+            out["grad." + name] = GC.sampled_grad(prm.grad)
+        else:
+            out["gnorm." + name] = np.asarray(-1.0)
+    return out
+
+
+def loss_vectors():
+    """The reference's LVMTraining.forward (LVM/model.py:752-845) + stage-1 loss and every parameter gradient
+    (torch autograd through reference code), stage-1 layout and stage-2+ frame-block layout."""
+    from tests import glue_cases as GC
+    cfg = R.TINY
+    p, batch, x1, x0, t, clean, x0i, ti = GC.stage1_case(cfg)
+    model, ns = X.build_reference_model(cfg, p, "LVMTraining")
+    model.train()
+    np.savez_compressed(os.path.join(OUT, "ref_loss_stage1_tiny.npz"), **_run_reference_loss(model, ns, x1, clean, batch, 123))
+    fb = GC.frame_block_training_batch()
+    nd = sum(len(v) for v in fb["denoise_image_sizes"].values())
+    nc = sum(len(v) for v in fb["input_image_sizes"].values())
+    gen = torch.Generator("cpu").manual_seed(21)
+    x1b, cleanb = torch.randn(nd, 4, 8, 8, generator=gen), torch.randn(nc, 4, 8, 8, generator=gen)
+    out = _run_reference_loss(model, ns, x1b, cleanb, fb, 321, frame_blocks=fb["frame_blocks"])
+    np.savez_compressed(os.path.join(OUT, "ref_loss_fbtrain_tiny.npz"), **out)
+
+
 def oracle_e2e_vectors():
     """Tiny next-clip case (tests/smoke_case.py) frozen from the restatement."""
     from tests import smoke_case as SC
@@ -152,6 +283,8 @@ if __name__ == "__main__":
     collator_vectors()
     scheduler_vectors()
     leaf_vectors()
+    lvm_glue_vectors()
+    loss_vectors()
     oracle_e2e_vectors()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

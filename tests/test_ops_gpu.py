@@ -72,6 +72,38 @@ def test_rope(ops, hd, nh, nkv):
     assert torch.equal(out[..., (nh + nkv) * hd:], qkv[..., (nh + nkv) * hd:])  # v untouched
 
 
+@pytest.mark.parametrize("M,K,hd,nh,nkv", [(77, 192, 96, 2, 2), (300, 128, 64, 3, 1), (515, 64, 128, 4, 2),
+                                            # 128-tile kernel with m tail; 256x192 / 256x256 tiles (qkv of cfg-2: 4096 x 9216)
+                                            (4096, 192, 96, 32, 32), (4100, 64, 96, 32, 32), (5160, 128, 96, 32, 32)])
+def test_qkv_gemm_with_fused_rope(ops, M, K, hd, nh, nkv):
+    """vgpt_gemm_bf16_rope (qkv_proj + apply_rotary_pos_emb, sdpa_transform.py:39,52-53) vs the oracle's Linear (rounded
+    to bf16) + apply_rope, and vs the two-kernel path (GEMM, then vgpt_rope_qk_inplace) it replaces."""
+    N = (nh + 2 * nkv) * hd
+    x = bf(torch.randn(M, K, generator=g(31)))
+    w = bf(torch.randn(N, K, generator=g(32)) * 0.1)
+    pos = torch.randint(0, 3100, (1, M), generator=g(33))
+    cos, sin = ops.rope_table(pos.to(DEV), ops.rope_inv_freq(hd, 10000.0, DEV))
+    fused = ops.linear_qkv_rope(x.to(DEV, BF), w.to(DEV, BF), cos, sin, nh, nkv, hd)
+    two = ops.rope_qk_inplace(ops.linear(x.to(DEV, BF), w.to(DEV, BF)), cos, sin, nh, nkv, hd)
+    # same arithmetic on the same bf16-rounded product; the compilers may contract a*c - b*s differently: <= 1 bf16 ulp
+    d = (fused.float() - two.float()).abs()
+    assert float((d / (two.float().abs() + 1e-3)).max()) <= 2 ** -7
+    assert rel_l2(fused, two) < 1e-3
+    assert torch.equal(fused[:, (nh + nkv) * hd:], two[:, (nh + nkv) * hd:])          # v columns: plain GEMM output
+    qkv = bf(x.double() @ w.double().t()).float()[None]
+    rc, rs = R.rope_cos_sin(pos, hd, 10000.0, BF)
+    q = qkv[..., : nh * hd].view(1, M, nh, hd).transpose(1, 2)
+    k = qkv[..., nh * hd:(nh + nkv) * hd].view(1, M, nkv, hd).transpose(1, 2)
+    rq, rk = R.apply_rope(q, k, rc.float(), rs.float())
+    out = fused.cpu().float()[None]
+    assert rel_l2(out[..., : nh * hd], rq.transpose(1, 2).reshape(1, M, -1)) < 6e-3
+    assert rel_l2(out[..., nh * hd:(nh + nkv) * hd], rk.transpose(1, 2).reshape(1, M, -1)) < 6e-3
+    # empty input and shape errors
+    assert ops.linear_qkv_rope(torch.empty(0, K, device=DEV, dtype=BF), w.to(DEV, BF), cos[:0], sin[:0], nh, nkv, hd).shape == (0, N)
+    with pytest.raises(Exception):
+        ops.linear_qkv_rope(x.to(DEV, BF), w.to(DEV, BF)[:-8], cos, sin, nh, nkv, hd)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 576, 192), (128, 128, 64), (1, 4, 64), (258, 3072, 3072),
                                    (1000, 192, 512), (6192, 3072, 1024),
                                    # large grids take the 256x256-tile kernel (m tail / n tail)

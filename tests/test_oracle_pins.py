@@ -149,3 +149,102 @@ def test_zero_init_heads_make_default_model_output_zero():
                                    num_attention_heads=1), pos_embed_max_size=8)
     assert float(m.final_layer.linear.weight.abs().sum()) == 0 and float(m.x_embedder.proj.weight.abs().sum()) == 0
     assert float(M.LVM(m.llm.config, pos_embed_max_size=8).x_embedder.proj.weight.abs().sum()) > 0
+
+
+# ---- LVM-owned glue: the restatement vs vectors produced by EXECUTING the reference's own LVM / LVMTraining /
+#      Phi3Transformer.forward / new_forward / LVMScheduler / training_losses_x1_noise_input
+#      (tests/make_golden.py::lvm_glue_vectors, loss_vectors through oracle/extract_reference.py) -------------------
+
+from tests import glue_cases as GC  # noqa: E402
+
+GLUE_TOL = 1e-5
+
+
+def test_restatement_matches_reference_lvm_forward_paths():
+    """LVM.frame_block_forward[_with_cfg] (LVM/model.py:399-566), Phi3Transformer.forward incl. the mask -> additive
+    conversion (OmniGen/transformer.py:128-214), the attention seam (sdpa_transform.py:12-91) and the 3-step sampler."""
+    d = GC.load("ref_lvm_glue_tiny.npz")
+    cfg = R.TINY
+    p, batch, z, cond = SC.build_case(cfg)
+    okw = {k: batch[k] for k in GC.BATCH_KEYS}
+    t = torch.full((len(z),), 0.3)
+    for pt in ("x1", "v"):
+        fwd = torch.cat(R.frame_block_forward_with_cfg(p, cfg, z, t, True, 1.6, pt, input_img_latents=cond, **okw))
+        assert float((fwd - T(d[f"fwd_{pt}"])).abs().max()) <= GLUE_TOL
+        smp = torch.cat(SC.oracle_sample(cfg, p, batch, z, cond, 3, pt))
+        assert float((smp - T(d[f"sample3_{pt}"])).abs().max()) <= GLUE_TOL
+    p1, batch1, z1, cond1 = SC.build_case(cfg, use_cfg=False)
+    okw1 = {k: batch1[k] for k in GC.BATCH_KEYS}
+    f1 = torch.cat(R.frame_block_forward_with_cfg(p1, cfg, z1, torch.full((len(z1),), 0.6), False, 1.6, "v",
+                                                  input_img_latents=cond1, **okw1))
+    assert float((f1 - T(d["fwd_nocfg_v"])).abs().max()) <= GLUE_TOL
+    g = torch.Generator("cpu").manual_seed(5)
+    B, L = batch["input_ids"].shape
+    emb = (torch.randn(B, L, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).float()
+    hid = R.transformer(p, cfg, emb, batch["attention_mask"], batch["position_ids"])
+    assert float((hid - T(d["llm_hidden"])).abs().max()) <= GLUE_TOL
+    assert str(d["mask2d_error"]) == "attention_mask parameter was unavailable or invalid"
+    with pytest.raises(Exception, match=str(d["mask2d_error"])):
+        R.transformer(p, cfg, emb, torch.ones(B, L), batch["position_ids"])
+
+
+def test_restatement_matches_reference_single_target_forward():
+    """LVM.forward / forward_with_cfg (LVM/model.py:330-397, 504-516)."""
+    d = GC.load("ref_lvm_glue_tiny.npz")
+    cfg = R.TINY
+    p, _, _, _ = SC.build_case(cfg)
+    c = GC.single_target_case(cfg)
+    ref = R.lvm_forward(p, cfg, c["x"], c["t"], c["ids"], c["lat"], c["sizes"], c["mask"], c["pos"])
+    assert float((ref - T(d["single_fwd"])).abs().max()) <= GLUE_TOL
+    cc = ref[1:2] + 1.6 * (ref[0:1] - ref[1:2])
+    assert float((torch.cat([cc, cc]) - T(d["single_cfg_v"])).abs().max()) <= GLUE_TOL
+    Lc, N = c["Lc"], c["N"]
+    r3 = R.lvm_forward(p, cfg, c["x"], c["t"], None, None, None, c["mask"][:, Lc:, Lc:], c["pos"][:, : N + 1])
+    assert float((r3 - T(d["single_nocond"])).abs().max()) <= GLUE_TOL
+
+
+def _loss_case(name):
+    cfg = R.TINY
+    d = GC.load(name)
+    if "stage1" in name:
+        p, batch, x1, _, _, clean, _, _ = GC.stage1_case(cfg)
+    else:
+        p = GC.stage1_case(cfg)[0]
+        batch = GC.frame_block_training_batch()
+        nd = sum(len(v) for v in batch["denoise_image_sizes"].values())
+        nc = sum(len(v) for v in batch["input_image_sizes"].values())
+        gen = torch.Generator("cpu").manual_seed(21)
+        x1, clean = torch.randn(nd, 4, 8, 8, generator=gen), torch.randn(nc, 4, 8, 8, generator=gen)
+    return cfg, d, p, batch, x1, clean
+
+
+@pytest.mark.parametrize("name", ["ref_loss_stage1_tiny.npz", "ref_loss_fbtrain_tiny.npz"])
+def test_restatement_matches_reference_loss_and_gradients(name):
+    """LVMTraining.forward (LVM/model.py:752-845) + training_losses_x1_noise_input (loss.py:128-243): xt, prediction,
+    per-frame loss and every parameter gradient of loss.mean() (train_x1_stage1_noiseinput.py:378-380)."""
+    cfg, d, p, batch, x1, clean = _loss_case(name)
+    pr = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in p.items()}
+    loss, xt = R.stage1_loss(pr, cfg, list(x1.split(1)), list(T(d["x0"]).split(1)), T(d["t"]), list(clean.split(1)),
+                             list(T(d["x0_in"]).split(1)), T(d["t_in"]), batch)
+    assert torch.equal(torch.cat(xt), T(d["xt"]))
+    assert float((loss.detach() - T(d["loss"])).abs().max()) <= GLUE_TOL
+    if "fbtrain" in name:      # one t per frame block (loss.py:105-113)
+        t, k = T(d["t"]), 0
+        for b in batch["frame_blocks"]:
+            for fb in batch["frame_blocks"][b]:
+                assert len(set(t[k:k + fb].tolist())) == 1
+                k += fb
+    loss.mean().backward()
+    checked = 0
+    for key in d.files:
+        if not key.startswith("grad."):
+            continue
+        name_ = key[5:]
+        if "rotary_emb" in name_:
+            continue
+        gr = pr[name_].grad
+        ref_norm = float(d["gnorm." + name_])
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-7, name_
+        assert np.abs(GC.sampled_grad(gr) - d[key]).max() <= 1e-5 * max(1.0, float(np.abs(d[key]).max())), name_
+        checked += 1
+    assert checked == len([k for k in pr if k != "pos_embed"])

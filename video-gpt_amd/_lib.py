@@ -27,9 +27,10 @@ SIGNATURES = {
     "vgpt_last_error": (c_char_p, []),
     "vgpt_abi_version": (c_int, []),
     "vgpt_rmsnorm_fwd": (c_int, [_P, _P, _P, _I64, _I64, c_float, _P]),
-    "vgpt_rope_table": (c_int, [_P, _P, _P, _P, _I64, c_int, c_int, _P]),
+    "vgpt_rope_table": (c_int, [_P, _P, _P, _P, _I64, c_int, c_int, c_float, _P]),
     "vgpt_rope_qk_inplace": (c_int, [_P, _P, _P, _I64, c_int, c_int, c_int, _P]),
     "vgpt_gemm_bf16": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
+    "vgpt_gemm_bf16_rope": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_int, _P]),
     "vgpt_gemm_bf16_tr": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_int, c_int, _P]),
     "vgpt_gated_mlp_act_fwd": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
     "vgpt_mask_pack_bool": (c_int, [_P, _P, _I64, _I64, _P]),
@@ -54,8 +55,8 @@ SIGNATURES = {
     "vgpt_timestep_sinusoid": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "vgpt_linear_small": (c_int, [_P, _P, _P, _P, _P, c_int, _I64, _I64, _I64, _I64, c_int, c_int, _P]),
     "vgpt_final_layer_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64, c_float, _P]),
-    "vgpt_sampler_set_timesteps": (c_int, [_P, _P, _P, c_int, _P]),
-    "vgpt_euler_cfg_update": (c_int, [_P, _P, _P, _P, _P, c_int, _I64, c_int, c_int, c_float, _P]),
+    "vgpt_sampler_set_timesteps": (c_int, [_P, _P, c_int, _P, c_int, _P]),
+    "vgpt_euler_cfg_update": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _I64, c_int, c_int, c_float, _P]),
     "vgpt_sampler_advance": (c_int, [_P, _P]),
     "vgpt_sampler_copy_step_rows": (c_int, [_P, _P, _P, c_int, c_int, _I64, _I64, _I64, _I64, _P]),
     "vgpt_cast_f32_to_bf16": (c_int, [_P, _P, _I64, _P]),

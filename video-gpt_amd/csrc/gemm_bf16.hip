@@ -60,7 +60,7 @@ using Cfg256 = TileCfg<256, 256, 2, 4>;
 // tiles of 256 x 192; x N = 9216 it is 2.25 rounds against 3 full rounds of 0.75-size tiles.
 using Cfg192 = TileCfg<256, 192, 2, 4>;
 
-enum { MODE_PLAIN = 0, MODE_GATED = 1 };
+enum { MODE_PLAIN = 0, MODE_GATED = 1, MODE_ROPE = 2 };
 
 struct GemmArgs {
     const bf16* A;
@@ -73,6 +73,11 @@ struct GemmArgs {
     int act;   // gated mode
     int I;     // gated mode: intermediate size
     int tiles_m, tiles_n;
+    // MODE_ROPE (qkv_proj + apply_rotary_pos_emb): columns [0, rope_cols) are heads of head_dim columns rotated with the
+    // per-token tables cos / sin (M, head_dim / 2) fp32; the remaining columns (V) are plain
+    const float* rope_cos;
+    const float* rope_sin;
+    int rope_cols, head_dim;
 };
 
 __device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
@@ -123,6 +128,15 @@ __device__ __forceinline__ int w_row_of_slot(int n0, int s, int I) {
     return n0 + s;
 }
 
+// MODE_ROPE: output column behind n-slot `gs` (global slot index).  Inside the rotated region every 16-slot MFMA
+// sub-tile holds 8 (d, d + head_dim/2) pairs of one head -- slots 0..7 the lower-half columns, 8..15 their partners --
+// so the partner of the 4 columns a lane holds lives in lane ^ 32 (one v_permlane32_swap in the epilogue).
+__device__ __forceinline__ int rope_col_of_slot(int gs, int rope_cols, int head_dim) {
+    if (gs >= rope_cols) return gs;
+    const int u = gs >> 4, w = gs & 15, per = head_dim >> 4;
+    return (u / per) * head_dim + (u % per) * 8 + (w & 7) + ((w & 8) ? (head_dim >> 1) : 0);
+}
+
 constexpr bool getenv_prio = VGPT_GEMM_SETPRIO;
 
 // ATR / WTR: the operand is stored with the reduction index as its ROW index (A as [K][M], W as [K][N]) -- the dX and
@@ -133,6 +147,7 @@ constexpr bool getenv_prio = VGPT_GEMM_SETPRIO;
 template <int MODE, typename C, bool PIPE, bool ATR = false, bool WTR = false>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     static_assert(!(ATR || WTR) || MODE == MODE_PLAIN, "transposed operands: plain kernel only");
+    constexpr bool ROPE = MODE == MODE_ROPE;
     constexpr int BM = C::BM, BN = C::BN, MI = C::MI, NI = C::NI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     const char* a_org = reinterpret_cast<const char*>(ATR ? g.A + m0 : g.A + (int64_t)m0 * g.lda);
     const char* w_org;
     if constexpr (WTR) w_org = reinterpret_cast<const char*>(g.W + n0);
-    else if constexpr (MODE == MODE_GATED) w_org = reinterpret_cast<const char*>(g.W);
+    else if constexpr (MODE == MODE_GATED || ROPE) w_org = reinterpret_cast<const char*>(g.W);
     else w_org = reinterpret_cast<const char*>(g.W + (int64_t)n0 * g.ldw);
 #pragma unroll
     for (int i = 0; i < C::A_SLABS; ++i) {
@@ -193,7 +208,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             w_off[i] = tr_off(g.ldw, wave * C::W_SLABS + i, n0, g.N, BN);
         } else {
             const int r = (wave * C::W_SLABS + i) * 8 + srow;
-            const int wr = min(w_row_of_slot<MODE>(n0, r, g.I), n_rows_w - 1) - (MODE == MODE_GATED ? 0 : n0);
+            int wr;
+            if constexpr (ROPE) wr = min(rope_col_of_slot(n0 + r, g.rope_cols, g.head_dim), n_rows_w - 1);
+            else wr = min(w_row_of_slot<MODE>(n0, r, g.I), n_rows_w - 1) - (MODE == MODE_GATED ? 0 : n0);
             w_off[i] = (uint32_t)(wr * (int)g.ldw + schunk * 8) * 2u;
         }
     }
@@ -392,7 +409,43 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
 
     // ---- epilogue: lane holds m = lane&15, n = (lane>>4)*4 + reg of each 16x16 sub-tile ----
     const int em = lane & 15, en = (lane >> 4) * 4;
-    if (MODE == MODE_PLAIN) {
+    if constexpr (ROPE) {
+        // Linear output rounded to bf16 (what the reference's qkv_proj returns), then q*cos + rotate_half(q)*sin in
+        // fp32 and one more rounding -- the arithmetic of vgpt_rope_qk_inplace on the stored tensor, without the store
+        // and reload.  N % 16 == 0 (checked on the host), so lane and lane ^ 32 are in range together.
+        const int half = g.head_dim >> 1;
+        const bool upper = (lane & 32) != 0;
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+            const int m = m0 + wm * (MI * 16) + j * 16 + em;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int gs = n0 + wn * (NI * 16) + i * 16 + en;
+                if (gs >= g.N) continue;
+                const int n = rope_col_of_slot(gs, g.rope_cols, g.head_dim);
+                f32x4 v = acc[i][j];
+                bf16x4 o;
+                if (gs < g.rope_cols) {
+                    const int d = (n % g.head_dim) - (upper ? half : 0);
+                    const f32x4 cs = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)m * half + d);
+                    const f32x4 sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)m * half + d);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float own = bf2f(f2bf(v[t]));
+                        auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
+                        const float other = __uint_as_float(upper ? sw2[0] : sw2[1]);
+                        // lower half: a*cos - b*sin; upper half: b*cos + a*sin  (rotate_half(x) = [-x2 | x1])
+                        o[t] = f2bf(upper ? own * cs[t] + other * sn[t] : own * cs[t] - other * sn[t]);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = f2bf(v[t]);
+                }
+                *reinterpret_cast<bf16x4*>(g.C + (int64_t)m * g.ldc + n) = o;
+            }
+        }
+    } else if (MODE == MODE_PLAIN) {
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
             const int m = m0 + wm * (MI * 16) + j * 16 + em;
@@ -506,7 +559,7 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     if (f == 256) p256.rows_big = g.M;
     bool use192 = false;
     BigPlan p = p256;
-    if constexpr (MODE == MODE_PLAIN && !ATR && !WTR) {
+    if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
         // 256 x 192 tiles when their rounds fit the problem clearly better (its loop moves ~15 % more operand bytes per
         // FLOP, so a small estimated gain is not taken)
         BigPlan p192 = plan_big(g.M, n_out, 192);
@@ -515,7 +568,7 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
         if (use192) p = p192;
     }
     auto big = [&](const GemmArgs& ga) {
-        if constexpr (MODE == MODE_PLAIN && !ATR && !WTR) {
+        if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
             if (use192) return launch_cfg<MODE, Cfg192, true, ATR, WTR>(ga, n_out, s, name);
         }
         return launch_cfg<MODE, Cfg256, true, ATR, WTR>(ga, n_out, s, name);
@@ -528,6 +581,10 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     g2.A = ATR ? g.A + m1 : g.A + m1 * g.lda;  // a transposed A keeps m along its columns
     g2.C = g.C + m1 * g.ldc;
     if (g.epi == VGPT_EPI_RESID) g2.extra = g.extra + m1 * g.ldr;
+    if (MODE == MODE_ROPE) {
+        g2.rope_cos = g.rope_cos + m1 * (g.head_dim / 2);
+        g2.rope_sin = g.rope_sin + m1 * (g.head_dim / 2);
+    }
     int rc = big(g1);
     if (rc != VGPT_OK) return rc;
     return launch_cfg<MODE, Cfg128, false, ATR, WTR>(g2, n_out, s, name);
@@ -562,6 +619,7 @@ VGPT_EXPORT int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
     g.epi = epilogue; g.act = VGPT_ACT_NONE; g.I = 0;
     g.tiles_m = g.tiles_n = 0;
+    g.rope_cos = g.rope_sin = nullptr; g.rope_cols = g.head_dim = 0;
     return launch<MODE_PLAIN>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16");
 }
 
@@ -595,6 +653,7 @@ VGPT_EXPORT int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const v
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
     g.epi = epilogue; g.act = VGPT_ACT_NONE; g.I = 0;
     g.tiles_m = g.tiles_n = 0;
+    g.rope_cos = g.rope_sin = nullptr; g.rope_cols = g.head_dim = 0;
     if (a_transposed) return launch<MODE_PLAIN, true, true>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_tr");
     return launch<MODE_PLAIN, false, true>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_tr");
 }
@@ -622,5 +681,32 @@ VGPT_EXPORT int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, voi
     g.lda = lda; g.ldw = ldw; g.ldc = ldo; g.ldr = 0;
     g.epi = VGPT_EPI_NONE; g.act = act; g.I = (int)I;
     g.tiles_m = g.tiles_n = 0;
+    g.rope_cos = g.rope_sin = nullptr; g.rope_cols = g.head_dim = 0;
     return launch<MODE_GATED>(g, I, (hipStream_t)stream, "vgpt_gated_mlp_act_fwd");
+}
+
+VGPT_EXPORT int vgpt_gemm_bf16_rope(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t,
+                                    int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
+                                    int n_rot_heads, int head_dim, void* stream) {
+    VGPT_REQUIRE(A && W && C && cos_t && sin_t, VGPT_ERR_INVALID, "vgpt_gemm_bf16_rope: null pointer");
+    VGPT_REQUIRE(M >= 0 && N > 0 && K > 0 && n_rot_heads > 0 && head_dim > 0, VGPT_ERR_INVALID,
+                 "vgpt_gemm_bf16_rope: bad shape");
+    VGPT_REQUIRE(head_dim % 16 == 0 && (int64_t)n_rot_heads * head_dim <= N, VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_rope: head_dim=%d must be a multiple of 16 and the rotated heads must fit in N", head_dim);
+    VGPT_REQUIRE(K % BK == 0, VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_rope: K=%ld not a multiple of 64", (long)K);
+    VGPT_REQUIRE(N % 16 == 0 && ldc % 4 == 0, VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_rope: N must be a multiple of 16, ldc of 4");
+    VGPT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && aligned16(A) && aligned16(W) && ((uintptr_t)C & 7) == 0 &&
+                     aligned16(cos_t) && aligned16(sin_t),
+                 VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_rope: operands must be 16-byte aligned rows");
+    VGPT_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_rope: dimension too large");
+    if (M == 0) return VGPT_OK;
+    GemmArgs g;
+    g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = (bf16*)C; g.extra = nullptr;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = 0;
+    g.epi = VGPT_EPI_NONE; g.act = VGPT_ACT_NONE; g.I = 0;
+    g.tiles_m = g.tiles_n = 0;
+    g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_cols = n_rot_heads * head_dim; g.head_dim = head_dim;
+    return launch<MODE_ROPE>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_rope");
 }

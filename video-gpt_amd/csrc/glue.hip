@@ -229,18 +229,22 @@ __global__ __launch_bounds__(256) void final_layer_kernel(
 }
 
 // ---- sampler -----------------------------------------------------------------------------------
-__global__ void set_timesteps_kernel(const float* sigma, const int32_t* step, float* ts, int n) {
+// `n_steps` = entries of the sigma table - 1: a replay past the end of the table (step >= n_steps) is a no-op instead of
+// an out-of-bounds read of sigma[step + 1]
+__global__ void set_timesteps_kernel(const float* sigma, const int32_t* step, float* ts, int n, int n_steps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ts[i] = sigma[*step];
+    const int st = *step;
+    if (i < n && st >= 0 && st <= n_steps) ts[i] = sigma[st];
 }
 
 __global__ __launch_bounds__(256) void euler_cfg_kernel(float* __restrict__ z, bf16* __restrict__ zm,
                                                         const bf16* __restrict__ pred,
                                                         const float* __restrict__ sigma,
-                                                        const int32_t* __restrict__ step, int n_frames,
+                                                        const int32_t* __restrict__ step, int n_steps, int n_frames,
                                                         int64_t elems, int pred_type, int use_cfg,
                                                         float cfg_scale) {
     const int st = *step;
+    if (st < 0 || st >= n_steps) return;   // past the sigma table: leave the state untouched
     const float sg = sigma[st], sg_next = sigma[st + 1];
     const float dt = sg_next - sg;
     const float inv = 1.0f / (1.0f - sg);
@@ -378,24 +382,24 @@ VGPT_EXPORT int vgpt_final_layer_fwd(const void* hidden, const int32_t* src_row,
     return VGPT_OK;
 }
 
-VGPT_EXPORT int vgpt_sampler_set_timesteps(const float* sigma, const int32_t* step, float* timesteps,
+VGPT_EXPORT int vgpt_sampler_set_timesteps(const float* sigma, const int32_t* step, int n_steps, float* timesteps,
                                            int n, void* stream) {
     VGPT_REQUIRE(sigma && step && timesteps, VGPT_ERR_INVALID,
                  "vgpt_sampler_set_timesteps: null pointer");
-    VGPT_REQUIRE(n >= 0, VGPT_ERR_INVALID, "vgpt_sampler_set_timesteps: bad shape");
+    VGPT_REQUIRE(n >= 0 && n_steps > 0, VGPT_ERR_INVALID, "vgpt_sampler_set_timesteps: bad shape");
     if (n == 0) return VGPT_OK;
     hipLaunchKernelGGL(set_timesteps_kernel, dim3((unsigned)cdiv(n, 64)), dim3(64), 0,
-                       (hipStream_t)stream, sigma, step, timesteps, n);
+                       (hipStream_t)stream, sigma, step, timesteps, n, n_steps);
     VGPT_CHECK_LAUNCH("vgpt_sampler_set_timesteps");
     return VGPT_OK;
 }
 
 VGPT_EXPORT int vgpt_euler_cfg_update(float* z, void* z_model, const void* pred, const float* sigma,
-                                      const int32_t* step, int n_frames, int64_t elems, int pred_type,
+                                      const int32_t* step, int n_steps, int n_frames, int64_t elems, int pred_type,
                                       int use_cfg, float cfg_scale, void* stream) {
     VGPT_REQUIRE(z && z_model && pred && sigma && step, VGPT_ERR_INVALID,
                  "vgpt_euler_cfg_update: null pointer");
-    VGPT_REQUIRE(n_frames >= 0 && elems >= 0, VGPT_ERR_INVALID, "vgpt_euler_cfg_update: bad shape");
+    VGPT_REQUIRE(n_frames >= 0 && elems >= 0 && n_steps > 0, VGPT_ERR_INVALID, "vgpt_euler_cfg_update: bad shape");
     VGPT_REQUIRE(pred_type == VGPT_PRED_V || pred_type == VGPT_PRED_X1, VGPT_ERR_INVALID,
                  "vgpt_euler_cfg_update: unknown prediction type %d", pred_type);
     VGPT_REQUIRE(!use_cfg || n_frames % 2 == 0, VGPT_ERR_INVALID,
@@ -404,7 +408,7 @@ VGPT_EXPORT int vgpt_euler_cfg_update(float* z, void* z_model, const void* pred,
     const int64_t total = (int64_t)(use_cfg ? n_frames / 2 : n_frames) * elems;
     int grid = (int)std::min<int64_t>(cdiv(total, 256), 2048);
     hipLaunchKernelGGL(euler_cfg_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z,
-                       (bf16*)z_model, (const bf16*)pred, sigma, step, n_frames, elems, pred_type,
+                       (bf16*)z_model, (const bf16*)pred, sigma, step, n_steps, n_frames, elems, pred_type,
                        use_cfg, cfg_scale);
     VGPT_CHECK_LAUNCH("vgpt_euler_cfg_update");
     return VGPT_OK;

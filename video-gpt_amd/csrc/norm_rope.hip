@@ -121,13 +121,13 @@ VGPT_EXPORT int vgpt_rmsnorm_fwd(const void* x, const void* w, void* y, int64_t 
 
 __global__ void rope_table_kernel(const int64_t* __restrict__ pos, const float* __restrict__ inv_freq,
                                   float* __restrict__ cos_o, float* __restrict__ sin_o,
-                                  int64_t tokens, int half, int round_bf16) {
+                                  int64_t tokens, int half, int round_bf16, float scale) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= tokens * half) return;
     const int64_t t = idx / half;
     const int i = (int)(idx % half);
     const float ang = (float)pos[t] * inv_freq[i];
-    float c = cosf(ang), s = sinf(ang);
+    float c = cosf(ang) * scale, s = sinf(ang) * scale;   // longrope attention factor (1 for plain RoPE)
     if (round_bf16) {
         c = bf2f(f2bf(c));
         s = bf2f(f2bf(s));
@@ -138,7 +138,7 @@ __global__ void rope_table_kernel(const int64_t* __restrict__ pos, const float* 
 
 VGPT_EXPORT int vgpt_rope_table(const int64_t* position_ids, const float* inv_freq, float* cos_out,
                                 float* sin_out, int64_t tokens, int half, int round_bf16,
-                                void* stream) {
+                                float scale, void* stream) {
     VGPT_REQUIRE(position_ids && inv_freq && cos_out && sin_out, VGPT_ERR_INVALID,
                  "vgpt_rope_table: null pointer");
     VGPT_REQUIRE(tokens >= 0 && half > 0, VGPT_ERR_INVALID, "vgpt_rope_table: bad shape");
@@ -146,7 +146,7 @@ VGPT_EXPORT int vgpt_rope_table(const int64_t* position_ids, const float* inv_fr
     const int64_t n = tokens * half;
     hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, position_ids, inv_freq, cos_out, sin_out, tokens, half,
-                       round_bf16);
+                       round_bf16, scale);
     VGPT_CHECK_LAUNCH("vgpt_rope_table");
     return VGPT_OK;
 }

@@ -235,6 +235,10 @@ class StaticDenoiser:
         self.mod = e(n_frames, 2 * H)
         self.graph = None
         self.time_qkv = None   # hoisting: (steps, layers, n_frames, 3H) q/k/v rows of the time tokens of every step
+        self.mod_all = None    # (steps, 1, n_frames, 2H) adaLN shift / scale of the final layer for every step (_mod_pass)
+        self.steps_taken = 0
+        if self.sigma is not None:
+            self._mod_pass()
         if S:
             self.prefill()
             if self.hoist and self.sigma is not None:
@@ -262,8 +266,7 @@ class StaticDenoiser:
             at, mlp = layer.self_attn, layer.mlp
             full = self.qkv_full[li]
             ops.rmsnorm(hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=nrm)
-            ops.linear(nrm, at.qkv_proj.weight, out=full[:S])
-            ops.rope_qk_inplace(full[:S], rope[0], rope[1], nq, nk, hd)
+            ops.linear_qkv_rope(nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=full[:S])
             ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, 0, ctx, segments=seg)
             ops.linear(ctx, at.o_proj.weight, residual=hid, out=hid)
             ops.rmsnorm(hid, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon, out=nrm)
@@ -271,11 +274,41 @@ class StaticDenoiser:
             ops.linear(act, mlp.down_proj.weight, residual=hid, out=hid)
         torch.cuda.current_stream().synchronize()
 
+    def per_clip_setup(self):
+        """Everything a clip computes once instead of once per step: condition-prefix prefill, the special rows of every
+        step, the final layer's adaLN modulation of every step."""
+        if self.S:
+            self.prefill()
+            if self.hoist:
+                self._time_pass()
+        self._mod_pass()
+
     def set_sigma(self, sigma: torch.Tensor):
         self.sigma = sigma.to(self.dev, torch.float32).contiguous()
         self.num_steps = self.sigma.numel() - 1
+        if getattr(self, "mod", None) is not None:
+            self._mod_pass()
         if getattr(self, "hoist", None) and getattr(self, "qkv_full", None) is not None:
             self._time_pass()
+
+    def _mod_pass(self):
+        """t_embedder MLP + adaLN modulation of the final layer for EVERY step in one pass per clip: they depend on
+        sigma_i alone (every frame of a step carries the same t, LVM/scheduler.py:169), while the reference recomputes
+        them inside every model call (LVM/model.py:480-486).  A step then copies its row (step index read on the device)."""
+        m, dev, H, T = self.model, self.dev, self.H, self.num_steps
+        e = lambda *s_: torch.empty(*s_, dtype=BF16, device=dev)
+        sin, te_h, temb, mod = e(T, 256), e(T, H), e(T, H), e(T, 2 * H)
+        ops.timestep_sinusoid(self.sigma[:T].contiguous(), m.t_embedder.freqs(dev), out=sin)
+        te, ada = m.t_embedder.mlp, m.final_layer.adaLN_modulation[1]
+        for c in range(0, T, 32):   # the small-M kernel takes at most 32 rows per call
+            ops.linear_small(sin[c:c + 32], te[0].weight, te[0].bias, post_act=ops.ACT_SILU, out=te_h[c:c + 32])
+            ops.linear_small(te_h[c:c + 32], te[2].weight, te[2].bias, out=temb[c:c + 32])
+            ops.linear_small(temb[c:c + 32], ada.weight, ada.bias, pre_act=ops.ACT_SILU, out=mod[c:c + 32])
+        shape = (T, 1, self.nf, 2 * H)
+        if self.mod_all is None or tuple(self.mod_all.shape) != shape:
+            self.mod_all = e(*shape)          # a captured graph reads this buffer: re-allocating invalidates it
+            self.graph = None
+        self.mod_all.copy_(mod.view(T, 1, 1, 2 * H).expand(*shape))
 
     # ---- special-row hoisting ------------------------------------------------------------------------------------
     @staticmethod
@@ -369,8 +402,7 @@ class StaticDenoiser:
             buf[:S0].copy_(full[:S0])
             buf[P0:P0 + T * nf].view(T, nf, W3).copy_(full[S0:S0 + nf].unsqueeze(0).expand(T, nf, W3))
             ops.rmsnorm(hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=nrm)
-            ops.linear(nrm, at.qkv_proj.weight, out=buf[P1:])
-            ops.rope_qk_inplace(buf[P1:], rope_s[0], rope_s[1], nq, nk, hd)
+            ops.linear_qkv_rope(nrm, at.qkv_proj.weight, rope_s[0], rope_s[1], nq, nk, hd, out=buf[P1:])
             ops.attention_qkv_range(buf.view(1, Lp, -1), pm, nq, nk, hd, P1, ctx, segments=seg)
             ops.linear(ctx, at.o_proj.weight, residual=hid, out=hid)
             ops.rmsnorm(hid, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon, out=nrm)
@@ -385,9 +417,12 @@ class StaticDenoiser:
         self.z.copy_(z.reshape(self.nf, -1).to(torch.float32))
         ops.cast_f32_to_bf16(self.z, self.z_model)
         self.step.zero_()
+        self.steps_taken = 0
 
     # ---- one denoise forward: z_model, ts -> pred ----
-    def forward_step(self):
+    def forward_step(self, from_tables: bool = False):
+        """from_tables: the step is sigma[*step] of the table (sampler_step), so everything that depends on the step
+        alone comes from the per-clip passes; otherwise `self.ts` may hold any timesteps."""
         m, cfg, H = self.model, self.cfg, self.H
         seq2d = self.hid.view(-1, H)
         pos = m.pos_embed[0]
@@ -398,7 +433,9 @@ class StaticDenoiser:
         if self.cond is not None and not S:
             ops.patch_embed(self.cond, m.input_x_embedder.proj.weight, m.input_x_embedder.proj.bias, pos,
                             self.cond_rows, seq2d, m.pos_embed_max_size)
-        ops.timestep_sinusoid(self.ts, m.time_token.freqs(self.dev), out=self.temb_sin)
+        from_tables = from_tables and self.mod_all is not None
+        if not (from_tables and self.hoist):
+            ops.timestep_sinusoid(self.ts, m.time_token.freqs(self.dev), out=self.temb_sin)
         if self.hoist:
             if self.time_qkv is None:
                 raise VgptError("StaticDenoiser: set_sigma() must run before the first step")
@@ -416,12 +453,10 @@ class StaticDenoiser:
             if S:
                 full = self.qkv_full[li_]
                 live = full[S:]                                  # this step's q/k/v rows, behind the cached prefix
-                ops.linear(self.nrm, at.qkv_proj.weight, out=live)
-                ops.rope_qk_inplace(live, rope[0], rope[1], nq, nk, hd)
+                ops.linear_qkv_rope(self.nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=live)
                 ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, S, self.ctx, segments=self.seg_live)
             else:
-                ops.linear(self.nrm, at.qkv_proj.weight, out=self.qkv)
-                ops.rope_qk_inplace(self.qkv, rope[0], rope[1], nq, nk, hd)
+                ops.linear_qkv_rope(self.nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=self.qkv)
                 if self.seg_all is not None:
                     ops.attention_qkv_range(self.qkv, self.pm, nq, nk, hd, 0, self.ctx, segments=self.seg_all)
                 else:
@@ -434,20 +469,23 @@ class StaticDenoiser:
         ops.rmsnorm(self.hid, m.llm.norm.weight, m.llm.norm.variance_epsilon, out=self.nrm)
         # t_embedder + adaLN modulation: every frame of a step carries the same t (LVM/scheduler.py:169), so one row is
         # computed and broadcast (the small-M kernel re-reads its input rows for every output column)
-        te = m.t_embedder.mlp
-        ops.linear_small(self.temb_sin[:1], te[0].weight, te[0].bias, post_act=ops.ACT_SILU, out=self.te_h[:1])
-        ops.linear_small(self.te_h[:1], te[2].weight, te[2].bias, out=self.temb[:1])
-        ada = m.final_layer.adaLN_modulation[1]
-        ops.linear_small(self.temb[:1], ada.weight, ada.bias, pre_act=ops.ACT_SILU, out=self.mod[:1])
-        if self.nf > 1:
-            self.mod[1:].copy_(self.mod[:1].expand(self.nf - 1, -1))
+        if from_tables:
+            ops.sampler_copy_step_rows(self.mod_all, self.mod.view(1, self.nf, 2 * H), self.step)
+        else:
+            te = m.t_embedder.mlp
+            ops.linear_small(self.temb_sin[:1], te[0].weight, te[0].bias, post_act=ops.ACT_SILU, out=self.te_h[:1])
+            ops.linear_small(self.te_h[:1], te[2].weight, te[2].bias, out=self.temb[:1])
+            ada = m.final_layer.adaLN_modulation[1]
+            ops.linear_small(self.temb[:1], ada.weight, ada.bias, pre_act=ops.ACT_SILU, out=self.mod[:1])
+            if self.nf > 1:
+                self.mod[1:].copy_(self.mod[:1].expand(self.nf - 1, -1))
         ops.final_layer(self.nrm.view(-1, H), x_rows, self.mod, m.final_layer.linear.weight,
                         m.final_layer.linear.bias, self.pred)
 
     def sampler_step(self):
         """LVM/scheduler.py:168-204 for one i: timesteps, model call, x1->v, CFG, Euler, i += 1."""
         ops.sampler_set_timesteps(self.sigma, self.step, self.ts)
-        self.forward_step()
+        self.forward_step(from_tables=True)
         ops.euler_cfg_update(self.z, self.z_model, self.pred, self.sigma, self.step, self.pred_type, self.use_cfg,
                              self.cfg_scale)
         ops.sampler_advance(self.step)
@@ -465,6 +503,10 @@ class StaticDenoiser:
 
     def run(self, num_steps: Optional[int] = None, use_graph: bool = True):
         n = self.num_steps if num_steps is None else num_steps
+        if self.steps_taken + n > self.num_steps:
+            raise VgptError(f"StaticDenoiser.run: {n} more steps after {self.steps_taken} exceed the {self.num_steps}-step "
+                            "sigma table")
+        self.steps_taken += n
         if use_graph and self.graph is None and n > 0:
             # the first step runs eagerly (kernels set their launch attributes on first use, which a capture cannot
             # record) and counts as a real step; the capture that follows records without executing

@@ -43,7 +43,9 @@ class Phi3Config:
 
     _DEFAULTS = dict(vocab_size=32064, hidden_size=3072, intermediate_size=8192, num_hidden_layers=32,
                      num_attention_heads=32, num_key_value_heads=None, hidden_act="silu", rms_norm_eps=1e-5,
-                     rope_theta=10000.0, pad_token_id=32000, use_cache=False, attention_dropout=0.0)
+                     rope_theta=10000.0, pad_token_id=32000, use_cache=False, attention_dropout=0.0,
+                     max_position_embeddings=4096, original_max_position_embeddings=None, rope_scaling=None,
+                     partial_rotary_factor=1.0)
 
     def __init__(self, **kw):
         for k, v in self._DEFAULTS.items():
@@ -52,22 +54,76 @@ class Phi3Config:
             self.num_key_value_heads = self.num_attention_heads
         for k, v in kw.items():
             setattr(self, k, v)
+        self._check_rope()
+
+    def _check_rope(self):
+        """Rotary variants of the checkpoint's config.json (the reference builds its rotary embedding from it,
+        LVM/model.py:202 -> HF Phi3Attention._init_rope): plain RoPE, or "su" / "longrope" (Phi-3-128k family: per-dim
+        short / long factors + an attention factor on cos / sin).  Anything else is refused instead of silently
+        rotating q / k differently from the reference."""
+        if float(self.partial_rotary_factor or 1.0) != 1.0:
+            raise VgptError(f"partial_rotary_factor={self.partial_rotary_factor} is not supported (the reference's "
+                            "transformers 4.47.1 Phi3 rotates the whole head)")
+        rs = self.rope_scaling
+        if rs is None:
+            return
+        if not isinstance(rs, dict):
+            raise VgptError(f"rope_scaling must be a dict, got {type(rs).__name__}")
+        kind = rs.get("rope_type", rs.get("type", "default"))
+        if kind in (None, "default"):
+            self.rope_scaling = None
+            return
+        if kind not in ("su", "longrope"):
+            raise VgptError(f"rope_scaling type {kind!r} is not supported (plain RoPE, 'su' and 'longrope' are)")
+        half = self.head_dim // 2
+        for key in ("short_factor", "long_factor"):
+            if not isinstance(rs.get(key), (list, tuple)) or len(rs[key]) != half:
+                raise VgptError(f"rope_scaling.{key} must list head_dim/2 = {half} numbers")
+        if self.original_max_position_embeddings is None:
+            self.original_max_position_embeddings = rs.get("original_max_position_embeddings", self.max_position_embeddings)
+
+    @classmethod
+    def _from_dict(cls, d):
+        d = dict(d)
+        rp = d.get("rope_parameters")
+        if isinstance(rp, dict):      # transformers 5.x spelling of rope_theta / rope_scaling / partial_rotary_factor
+            d.setdefault("rope_theta", rp.get("rope_theta", 10000.0))
+            if d.get("rope_scaling") is None and rp.get("rope_type", "default") != "default":
+                d["rope_scaling"] = rp
+            if "partial_rotary_factor" in rp:
+                d.setdefault("partial_rotary_factor", rp["partial_rotary_factor"])
+            if d.get("original_max_position_embeddings") is None and "original_max_position_embeddings" in rp:
+                d["original_max_position_embeddings"] = rp["original_max_position_embeddings"]
+        return cls(**{k: d[k] for k in cls._DEFAULTS if k in d and d[k] is not None})
 
     @classmethod
     def from_hf(cls, cfg):
         if isinstance(cfg, cls):
             return cfg
-        d = cfg.to_dict() if hasattr(cfg, "to_dict") else dict(vars(cfg))
-        if "rope_theta" not in d and isinstance(d.get("rope_parameters"), dict):
-            d["rope_theta"] = d["rope_parameters"].get("rope_theta", 10000.0)
-        return cls(**{k: d[k] for k in cls._DEFAULTS if k in d and d[k] is not None})
+        return cls._from_dict(cfg.to_dict() if hasattr(cfg, "to_dict") else dict(vars(cfg)))
 
     @classmethod
     def from_pretrained(cls, model_name):
         import json
         with open(os.path.join(model_name, "config.json")) as f:
-            d = json.load(f)
-        return cls(**{k: d[k] for k in cls._DEFAULTS if k in d and d[k] is not None})
+            return cls._from_dict(json.load(f))
+
+    def rope_spec(self, max_position: int):
+        """-> (ext_factors | None, cos/sin scale) for a sequence whose largest position id is `max_position`
+        (HF 4.47.1 Phi3LongRoPEScaledRotaryEmbedding.forward: seq_len = max(position_ids) + 1 picks the long factors
+        beyond original_max_position_embeddings; scale = sqrt(1 + ln(max/orig) / ln(orig)) when max > orig)."""
+        rs = self.rope_scaling
+        if rs is None:
+            return None, 1.0
+        orig = int(self.original_max_position_embeddings)
+        ext = rs["long_factor"] if max_position + 1 > orig else rs["short_factor"]
+        factor = rs.get("factor")
+        if factor is None or self.original_max_position_embeddings is not None:
+            factor = self.max_position_embeddings / orig
+        att = rs.get("attention_factor")
+        if att is None:
+            att = 1.0 if factor <= 1.0 else math.sqrt(1 + math.log(factor) / math.log(orig))
+        return ext, float(att)
 
     @property
     def head_dim(self):
@@ -149,6 +205,13 @@ class Phi3RMSNorm(nn.Module):
         return ops.rmsnorm(x, self.weight, self.variance_epsilon, out=out)
 
 
+def rope_tables_for(config, position_ids):
+    """cos / sin tables of the checkpoint's rotary variant (plain, or su / longrope: Phi3Config.rope_spec)."""
+    ext, scale = config.rope_spec(int(position_ids.max()) if config.rope_scaling is not None else 0)
+    inv = ops.rope_inv_freq(config.head_dim, config.rope_theta, position_ids.device, ext)
+    return ops.rope_table(position_ids.contiguous(), inv, scale=scale)
+
+
 class Phi3Attention(nn.Module):
     """Attention module with the reference's operator seam: `local_attn` / `dist_attn`
     (LVM/transform/sdpa_transform.py:162-169).  With the default `local_attn` the fused
@@ -177,10 +240,9 @@ class Phi3Attention(nn.Module):
         B, L, _ = hidden_states.shape
         pm = ops.as_packed_mask(attention_mask, hidden_states.device)
         if rope is None:
-            inv = ops.rope_inv_freq(self.head_dim, self.config.rope_theta, hidden_states.device)
-            rope = ops.rope_table(position_ids.contiguous(), inv)
-        qkv = ops.linear(hidden_states, self.qkv_proj.weight)
-        ops.rope_qk_inplace(qkv, rope[0], rope[1], self.num_heads, self.num_key_value_heads, self.head_dim)
+            rope = rope_tables_for(self.config, position_ids)
+        qkv = ops.linear_qkv_rope(hidden_states, self.qkv_proj.weight, rope[0], rope[1], self.num_heads,
+                                  self.num_key_value_heads, self.head_dim)
         if self.local_attn is ops.sdpa and self.dist_attn is None:
             ctx = ops.attention_qkv(qkv, pm, self.num_heads, self.num_key_value_heads, self.head_dim)
         else:
@@ -247,6 +309,8 @@ class Phi3Transformer(nn.Module):
         self._inv_freq = None
 
     def rope_tables(self, position_ids):
+        if self.config.rope_scaling is not None:
+            return rope_tables_for(self.config, position_ids)
         dev = position_ids.device
         if self._inv_freq is None or self._inv_freq.device != dev:
             self._inv_freq = ops.rope_inv_freq(self.config.head_dim, self.config.rope_theta, dev)

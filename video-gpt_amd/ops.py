@@ -63,19 +63,27 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[tor
     return out
 
 
-def rope_inv_freq(head_dim: int, theta: float, device) -> torch.Tensor:
-    """Phi3RotaryEmbedding.inv_freq, computed on the host exactly as transformers does."""
-    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+def rope_inv_freq(head_dim: int, theta: float, device, ext_factors=None) -> torch.Tensor:
+    """Phi3RotaryEmbedding.inv_freq, computed on the host exactly as transformers does; `ext_factors` (head_dim/2 values)
+    are the short / long factors of a "su" / "longrope" checkpoint: inv_freq = 1 / (ext_factors * theta^(2i/d))."""
+    shape = torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim
+    if ext_factors is None:
+        inv = 1.0 / (theta ** shape)
+    else:
+        ext = torch.tensor(list(ext_factors), dtype=torch.float32)
+        if ext.numel() != shape.numel():
+            raise VgptError(f"rope_scaling factors must have head_dim/2 = {shape.numel()} entries, got {ext.numel()}")
+        inv = 1.0 / (ext * theta ** shape)
     return inv.to(device)
 
 
-def rope_table(position_ids: torch.Tensor, inv_freq: torch.Tensor, round_bf16: bool = True):
+def rope_table(position_ids: torch.Tensor, inv_freq: torch.Tensor, round_bf16: bool = True, scale: float = 1.0):
     _chk(position_ids, torch.int64, "rope_table.position_ids"); _chk(inv_freq, torch.float32, "rope_table.inv_freq")
     tokens, half = position_ids.numel(), inv_freq.numel()
     cos = torch.empty(tokens, half, dtype=torch.float32, device=position_ids.device)
     sin = torch.empty_like(cos)
     call("vgpt_rope_table", position_ids.data_ptr(), inv_freq.data_ptr(), cos.data_ptr(), sin.data_ptr(),
-         tokens, half, int(round_bf16), _stream())
+         tokens, half, int(round_bf16), float(scale), _stream())
     return cos, sin
 
 
@@ -119,6 +127,30 @@ def linear(x: torch.Tensor, weight: torch.Tensor, residual: Optional[torch.Tenso
         epi, extra = EPI_BIAS, bias
     call("vgpt_gemm_bf16", x.data_ptr(), weight.data_ptr(), out.data_ptr(), _ptr(extra), M, N, K, K, K, N,
          ldr, epi, _stream())
+    return out
+
+
+def linear_qkv_rope(x: torch.Tensor, weight: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_q_heads: int,
+                    n_kv_heads: int, head_dim: int, out: Optional[torch.Tensor] = None):
+    """qkv_proj + apply_rotary_pos_emb as one kernel (LVM/transform/sdpa_transform.py:39,52-53): == linear() followed by
+    rope_qk_inplace(); cos / sin (tokens, head_dim/2) fp32 from rope_table, row t = token t of x."""
+    _chk(x, BF16, "linear_qkv_rope.x"); _chk(weight, BF16, "linear_qkv_rope.weight")
+    _chk(cos, torch.float32, "linear_qkv_rope.cos"); _chk(sin, torch.float32, "linear_qkv_rope.sin")
+    K = x.shape[-1]
+    N = weight.shape[0]
+    if weight.shape[1] != K or N != (n_q_heads + 2 * n_kv_heads) * head_dim:
+        raise VgptError("linear_qkv_rope: weight shape mismatch")
+    M = x.numel() // K
+    if cos.numel() != M * (head_dim // 2) or sin.numel() != cos.numel():
+        raise VgptError("linear_qkv_rope: cos/sin table size mismatch")
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=BF16, device=x.device)
+    else:
+        _chk(out, BF16, "linear_qkv_rope.out")
+        if out.numel() != M * N:
+            raise VgptError("linear_qkv_rope: out shape mismatch")
+    call("vgpt_gemm_bf16_rope", x.data_ptr(), weight.data_ptr(), out.data_ptr(), cos.data_ptr(), sin.data_ptr(), M, N, K,
+         K, K, N, n_q_heads + n_kv_heads, head_dim, _stream())
     return out
 
 
@@ -472,7 +504,7 @@ def final_layer(hidden: torch.Tensor, src_row: torch.Tensor, mod: torch.Tensor, 
 # ---- sampler ----------------------------------------------------------------------------------
 
 def sampler_set_timesteps(sigma: torch.Tensor, step: torch.Tensor, timesteps: torch.Tensor):
-    call("vgpt_sampler_set_timesteps", sigma.data_ptr(), step.data_ptr(), timesteps.data_ptr(),
+    call("vgpt_sampler_set_timesteps", sigma.data_ptr(), step.data_ptr(), sigma.numel() - 1, timesteps.data_ptr(),
          timesteps.numel(), _stream())
 
 
@@ -481,7 +513,7 @@ def euler_cfg_update(z: torch.Tensor, z_model: torch.Tensor, pred: torch.Tensor,
     _chk(z, torch.float32, "euler.z"); _chk(z_model, BF16, "euler.z_model"); _chk(pred, BF16, "euler.pred")
     nf = z.shape[0]
     call("vgpt_euler_cfg_update", z.data_ptr(), z_model.data_ptr(), pred.data_ptr(), sigma.data_ptr(),
-         step.data_ptr(), nf, z.numel() // nf, pred_type, int(use_cfg), float(cfg_scale), _stream())
+         step.data_ptr(), sigma.numel() - 1, nf, z.numel() // nf, pred_type, int(use_cfg), float(cfg_scale), _stream())
 
 
 def sampler_copy_step_rows(src: torch.Tensor, dst: torch.Tensor, step: torch.Tensor):

@@ -253,6 +253,88 @@ class LVMCollator:
                 "input_pixel_values": input_images, "input_image_sizes": inputs, "denoise_image_sizes": denoise,
                 "output_images": [], "time_emb_inx": time_inx, "frame_blocks": frame_blocks}
 
+    # -- single-target path (LVMPipeline.__call__ -> LVMProcessor.__call__ -> LVMCollator.__call__): the sequence is
+    #    [left pad | condition tokens | time token | target image tokens]  (LVM/processor.py:432-440, 536-573, 776-810, 841-866, 943-962)
+    def pad_input_ids(self, input_ids, image_sizes, num_tokens_for_output_images):
+        """LVM/processor.py:783-810: left-pad so that condition + 1 time token + image tokens end at a common length."""
+        n_out = num_tokens_for_output_images
+        max_l = max(len(r) + n_out[i] + 1 for i, r in enumerate(input_ids))
+        sp = self.sequence_parallel_size
+        if max_l % sp != 0:
+            max_l += sp - max_l % sp
+        rows_ids, rows_valid = [], []
+        for i, row in enumerate(input_ids):
+            pad = max_l - len(row) - n_out[i] - 1
+            rows_ids.append([self.pad_token_id] * pad + list(row))
+            rows_valid.append([0] * pad + [1] * len(row))
+            if i in image_sizes:
+                image_sizes[i] = [[s + pad, e + pad] for s, e in image_sizes[i]]
+        if len({len(r) for r in rows_ids}) != 1:   # the reference builds a ragged LongTensor here and fails the same way
+            raise ValueError("rows of one batch must have condition length + target tokens of one total")
+        return torch.LongTensor(rows_ids), torch.ByteTensor(rows_valid), image_sizes
+
+    def create_position(self, attention_mask, num_tokens_for_output_images):
+        """LVM/processor.py:432-440: 0 on the pad, then 0..valid+img_length (one extra for the time token)."""
+        text_l = attention_mask.size(-1)
+        img_l = max(num_tokens_for_output_images)
+        rows = np.zeros((attention_mask.size(0), text_l + img_l + 1), dtype=np.int64)
+        for i in range(attention_mask.size(0)):
+            valid = int(attention_mask[i].sum())
+            rows[i, text_l - valid:] = np.arange(valid + img_l + 1)
+        return torch.from_numpy(rows)
+
+    def create_mask(self, attention_mask, num_tokens_for_output_images):
+        """LVM/processor.py:536-573: condition + time rows causal, target rows see everything, pad columns hidden, pad
+        rows all ones, columns of a shorter target's padding hidden everywhere; uint8 like the reference."""
+        text_l = attention_mask.size(-1)
+        img_l = max(num_tokens_for_output_images)
+        L = text_l + img_l + 1
+        out = np.zeros((attention_mask.size(0), L, L), dtype=np.uint8)
+        padding_images = []
+        for i in range(attention_mask.size(0)):
+            valid = int(attention_mask[i].sum())
+            pad, T = text_l - valid, valid + 1
+            m = out[i]
+            m[pad:pad + T, pad:pad + T] = np.tril(np.ones((T, T), dtype=np.uint8))
+            m[pad + T:, pad:] = 1
+            m[:pad, :] = 1
+            short = img_l - num_tokens_for_output_images[i]
+            if short > 0:
+                m[:, L - short:] = 0
+                padding_images.append(torch.zeros(1, short, self.hidden_size))
+            else:
+                padding_images.append(None)
+        return torch.from_numpy(out), padding_images
+
+    def adjust_attention_for_input_images(self, attention_mask, image_sizes):
+        """LVM/processor.py:776-781: the tokens of one condition image see each other."""
+        for b in image_sizes.keys():
+            for s, e in image_sizes[b]:
+                attention_mask[b][s:e, s:e] = 1
+        return attention_mask
+
+    def process_mllm_input(self, mllm_inputs, target_img_size):
+        """LVM/processor.py:841-866."""
+        n_out = [sz[0] * sz[1] // 16 // 16 for sz in target_img_size]
+        pixel_values, image_sizes, _ = self._gather(mllm_inputs, False)
+        ids, valid, image_sizes = self.pad_input_ids([x["input_ids"] for x in mllm_inputs], image_sizes, n_out)
+        position_ids = self.create_position(valid, n_out)
+        mask, padding_images = self.create_mask(valid, n_out)
+        mask = self.adjust_attention_for_input_images(mask, image_sizes)
+        return ids, position_ids, mask, padding_images, pixel_values, image_sizes
+
+    def __call__(self, features):
+        """LVM/processor.py:943-962: features = [(mllm_input, img_cfg_mllm_input | None, [height, width]), ...]."""
+        mllm_inputs = [f[0] for f in features]
+        cfg_inputs = [f[1] for f in features]
+        target = [f[2] for f in features]
+        if cfg_inputs[0] is not None:
+            mllm_inputs = mllm_inputs + cfg_inputs
+            target = target + target
+        ids, position_ids, mask, padding_images, pixel_values, image_sizes = self.process_mllm_input(mllm_inputs, target)
+        return {"input_ids": ids, "attention_mask": mask, "position_ids": position_ids, "input_pixel_values": pixel_values,
+                "input_image_sizes": image_sizes, "padding_images": padding_images}
+
     def collate_stage1(self, mllm_inputs, frame_num: int):
         """TrainDataCollator.__call__ (LVM/train_helper/data.py:422-458) without the video I/O."""
         ids, position_ids, mask, pixel_values, sizes = self.process_mllm_input_training(mllm_inputs)
@@ -311,14 +393,12 @@ class LVMProcessor:
     @classmethod
     def from_pretrained(cls, model_name, sequence_parallel_size: int = 1):
         import os
-        tok = None
-        if os.path.isdir(model_name):
-            try:
-                from transformers import AutoTokenizer
-                tok = AutoTokenizer.from_pretrained(model_name)
-            except Exception:
-                tok = None
-        return cls(tok, sequence_parallel_size=sequence_parallel_size)
+        from transformers import AutoTokenizer
+        if not os.path.isdir(model_name):
+            raise FileNotFoundError(f"{model_name}: local checkpoint directories only (no hub access)")
+        # a missing / unreadable tokenizer is an error exactly as in the reference (LVM/processor.py:70-78): falling back
+        # to SpecialTokenizer's made-up ids would select the wrong embed_tokens rows without any failure
+        return cls(AutoTokenizer.from_pretrained(model_name), sequence_parallel_size=sequence_parallel_size)
 
     def crop_arr(self, pil_image):
         """LVM/processor.py:39-64: shrink to max_image_size, enlarge to >= 16, centre-crop to multiples of 16."""
@@ -431,6 +511,68 @@ class LVMProcessor:
                 for _ in range(fb):
                     emit(False)
         return {"input_ids": ids, "pixel_values": input_images, "image_sizes": sizes}
+
+    # -- single-target path (LVM/processor.py:90-126, 276-317, 319-364) --
+    def add_prefix_instruction(self, prompt):
+        return f"{prompt}<|diffusion|>"
+
+    def process_multi_modal_prompt(self, text, input_images):
+        """LVM/processor.py:90-126: `<|image_i|>` tags become N zero slots; the prompt ends with `<|diffusion|>`."""
+        text = self.add_prefix_instruction(text)
+        if input_images is None or len(input_images) == 0:
+            ids = list(self.text_tokenizer(text).input_ids)
+            if ids[0] == 1:
+                ids = ids[1:]
+            return {"input_ids": ids, "pixel_values": None, "image_sizes": None}
+        chunks, image_ids, uniq = self._chunks(text)
+        assert len(uniq) == len(input_images), (
+            f"total images must be the same as the number of image tags, got {len(uniq)} image tags and {len(input_images)} images")
+        input_images = [input_images[x - 1] for x in image_ids]
+        ids, sizes = [], []
+        for i, c in enumerate(chunks):
+            ids.extend(c)
+            if i != len(chunks) - 1:
+                n = self._ntok(input_images[i])
+                sizes.append([len(ids), len(ids) + n])
+                ids.extend([0] * n)
+        return {"input_ids": ids, "pixel_values": input_images, "image_sizes": sizes}
+
+    def _single_target_rows(self, instruction, images):
+        images = [self.process_image(x) for x in images] if images is not None and len(images) > 0 else None
+        if images is None:
+            assert "<img><|image_1|></img>" not in instruction
+        return self.process_multi_modal_prompt(instruction, images)
+
+    def __call__(self, instructions, input_images=None, height: int = 1024, width: int = 1024, use_img_cfg: bool = True,
+                 use_input_image_size_as_output: bool = False) -> Dict:
+        """LVM/processor.py:282-317: one row per instruction; the CFG row is the empty prompt (`<|diffusion|>` only)."""
+        if input_images is None:
+            use_img_cfg = False
+        if isinstance(instructions, str):
+            instructions, input_images = [instructions], [input_images]
+        data = []
+        for i, ins in enumerate(instructions):
+            row = self._single_target_rows(ins, None if input_images is None else input_images[i])
+            cfg_row = self.process_multi_modal_prompt("", None) if use_img_cfg else None
+            size = ([row["pixel_values"][0].size(-2), row["pixel_values"][0].size(-1)] if use_input_image_size_as_output
+                    else [height, width])
+            data.append((row, cfg_row, size))
+        return self.collator(data)
+
+    def prompt_condition_inference(self, instructions, input_images=None, height: int = 1024, width: int = 1024,
+                                   use_img_cfg: bool = True, use_input_image_size_as_output: bool = False) -> Dict:
+        """LVM/processor.py:319-364: instructions[0] is the conditional prompt, instructions[1] the CFG prompt."""
+        if input_images is None:
+            use_img_cfg = False
+        if isinstance(instructions, str):
+            instructions, input_images = [instructions], [input_images]
+        row = self._single_target_rows(instructions[0], None if input_images is None else input_images[0])
+        cfg_row = None
+        if use_img_cfg:
+            cfg_row = self._single_target_rows(instructions[1], None if input_images is None else input_images[1])
+        size = ([row["pixel_values"][0].size(-2), row["pixel_values"][0].size(-1)] if use_input_image_size_as_output
+                else [height, width])
+        return self.collator([(row, cfg_row, size)])
 
     def prompt_condition_frame_block_inference(self, instructions, input_images=None, height: int = 1024,
                                                width: int = 1024, use_img_cfg: bool = True,

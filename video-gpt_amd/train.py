@@ -177,8 +177,7 @@ class Stage1Trainer:
         for li, layer in enumerate(m.llm.layers):
             at, mlp = layer.self_attn, layer.mlp
             ops.rmsnorm(hbuf[li], layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=n1[li])
-            ops.linear(n1[li], at.qkv_proj.weight, out=qkv[li])
-            ops.rope_qk_inplace(qkv[li], prep["rope"][0], prep["rope"][1], nq, nk, hd)
+            ops.linear_qkv_rope(n1[li], at.qkv_proj.weight, prep["rope"][0], prep["rope"][1], nq, nk, hd, out=qkv[li])
             T.attention_qkv_train(qkv[li].view(B, L, -1), prep["pm"], nq, nk, hd, ctx[li].view(B, L, -1), lse[li])
             ops.linear(ctx[li], at.o_proj.weight, residual=hbuf[li], out=h2[li])
             ops.rmsnorm(h2[li], layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon,
