@@ -92,3 +92,45 @@ def test_layout_and_dense_masks_sample_the_same_clip(pipe_case):
         got[fmt] = torch.cat(pipe.last_samples[0]).clone()
     pipe.mask_format = "layout"
     assert torch.equal(got["layout"], got["bool"])
+
+
+@pytest.mark.parametrize("pt", ["x1", "v"])
+def test_single_target_call_matches_oracle(pipe_case, pt):
+    """LVMPipeline.__call__ (LVM/pipeline.py:138-343): [<img> image </img> x2, <|diffusion|> | time | target] through
+    LVM.forward_with_cfg + the Euler sampler, CFG row = the empty prompt; one round vs the oracle's LVM.forward."""
+    cfg, vcfg, p, vp, pipe, frames = pipe_case
+    steps, seed = 2, 5
+    vnoise = [torch.randn(1, 4, 8, 8, generator=torch.Generator("cpu").manual_seed(90 + i)) for i in range(2)]
+    out = pipe(input_images=frames, height=64, width=64, gen_num=1, num_inference_steps=steps, use_img_guidance=True,
+               img_guidance_scale=1.6, seed=seed, output_type="pt", prediction_type=pt, generator_device="cpu",
+               vae_noise=vnoise)
+    assert len(out) == 3 and out[-1].shape == (64, 64, 3) and out[-1].dtype == torch.uint8
+    cond = [VR.vae_encode(vp, vcfg, frames[i][None], vnoise[i]).to(BF).float() for i in range(2)]
+    P = importlib.import_module("video-gpt_amd.processor")
+    proc = P.LVMProcessor(P.SpecialTokenizer(10, 11, 12))
+    data = proc(["<img><|image_1|></img><img><|image_2|></img>"], [frames], height=64, width=64, use_img_cfg=True)
+    z0 = torch.randn(1, 4, 8, 8, generator=torch.Generator("cpu").manual_seed(seed)).to(BF).float()
+
+    def func(zl, t):
+        o = R.lvm_forward(p, cfg, torch.cat(zl), t, data["input_ids"], cond, data["input_image_sizes"],
+                          data["attention_mask"].bool(), data["position_ids"])
+        if pt == "v":   # LVM.forward_with_cfg applies CFG itself for 'v' (LVM/model.py:508-512)
+            c = o[1:2] + 1.6 * (o[0:1] - o[1:2])
+            o = torch.cat([c, c])
+        return [o[0:1], o[1:2]]
+    ref = R.scheduler_call(R.scheduler_sigma(steps, 1.0), [z0, z0.clone()], func, True, 1.6, pt)[0]
+    assert SC.rel_l2(pipe.last_samples[0], ref) < 3e-2
+    ref_img = VR.decode_to_uint8(vp, vcfg, ref)[0]
+    assert float((out[-1].cpu().int() - ref_img.int()).abs().float().mean()) <= 2.0
+
+
+def test_single_target_call_rounds_feed_back(pipe_case):
+    """gen_num rounds: every generated image becomes a (re-noised) condition image of the next round; no input images:
+    CFG is switched off for the first round (LVM/pipeline.py:210-218)."""
+    cfg, vcfg, p, vp, pipe, frames = pipe_case
+    out = pipe(input_images=None, height=64, width=64, gen_num=3, num_inference_steps=1, seed=3, output_type="pil",
+               prediction_type="x1", clean_image_noise_level=0.1)
+    assert len(out) == 3 and out[0].size == (64, 64)
+    out = pipe(input_images=frames[:1], height=64, width=64, gen_num=2, num_inference_steps=1, seed=3, output_type="pt",
+               prediction_type="v", clean_image_noise_level=0.1)
+    assert len(out) == 1 + 2

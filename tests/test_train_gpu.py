@@ -170,16 +170,87 @@ def test_adamw_and_clip(T):
 
 
 def _stage1_case(cfg):
-    p = {k: v.to(BF).float() for k, v in R.make_params(cfg, 3).items()}
-    batch = R.collate_stage1([3, 2], 16)
-    gen = torch.Generator("cpu").manual_seed(0)
-    nd = sum(len(v) for v in batch["denoise_image_sizes"].values())
-    nc = sum(len(v) for v in batch["input_image_sizes"].values())
-    mk = lambda n: torch.randn(n, 4, 8, 8, generator=gen)
-    x1, x0, clean, x0i = mk(nd), mk(nd), mk(nc), mk(nc)
-    t = torch.rand(nd, generator=gen)
-    ti = 0.9 + 0.1 * torch.rand(nc, generator=gen)
-    return p, batch, x1, x0, t, clean, x0i, ti
+    from tests import glue_cases as GC
+    return GC.stage1_case(cfg)
+
+
+def test_gradient_checkpointing_gives_bit_identical_gradients():
+    """OmniGen/transformer.py:182-192 / train_x1_stage1_noiseinput.py:170-171: with checkpointing only the layer inputs
+    are kept and every layer is recomputed inside its backward -- same kernels on the same inputs, so loss and EVERY
+    gradient are bit-identical to the run that saved all activations."""
+    cfg = R.TINY
+    p, batch, x1, x0, t, clean, x0i, ti = _stage1_case(cfg)
+    TR = importlib.import_module("video-gpt_amd.train")
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out = {}
+    for ck in (False, True):
+        model = SC.build_product_model(cfg, p, DEV, cls_name="LVMTraining")
+        if ck:
+            model.llm.gradient_checkpointing_enable()
+        tr = TR.Stage1Trainer(model, lr=1e-3, weight_decay=0.1)
+        assert tr.gradient_checkpointing == ck
+        loss = tr.step(dbatch, x1, x0, t, clean, x0i, ti, update=False)
+        torch.cuda.synchronize()
+        out[ck] = (loss.clone(), {k: v.clone() for k, v in tr.grads.items()}, tr._ws["qkv"].shape[0])
+    assert out[False][2] == cfg.num_hidden_layers and out[True][2] == 1      # one layer's activations instead of all
+    assert torch.equal(out[False][0], out[True][0])
+    big = {k for names in tr.layer_names for k in names}
+    for k, v in out[False][1].items():
+        if k in big:        # the decoder matrices (all but 2 % of the parameters): deterministic GEMMs
+            assert torch.equal(out[True][1][k], v), k
+        else:               # small fp32 gradients accumulate with atomics (order varies run to run): equal to rounding
+            assert rel_l2(out[True][1][k], v) < 1e-5, k
+
+
+def test_constant_with_warmup_schedule():
+    """diffusers get_scheduler("constant_with_warmup") (train_x1_stage1_noiseinput.py:279-283): optimizer step k runs at
+    lr * min(1, k / warmup) -- the very first step at lr 0, so it leaves the weights unchanged."""
+    cfg = R.TINY
+    p, batch, x1, x0, t, clean, x0i, ti = _stage1_case(cfg)
+    TR = importlib.import_module("video-gpt_amd.train")
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    tr = TR.Stage1Trainer(SC.build_product_model(cfg, p, DEV, cls_name="LVMTraining"), lr=1e-3, weight_decay=0.0,
+                          lr_scheduler="constant_with_warmup", lr_warmup_steps=4)
+    ref = torch.optim.lr_scheduler.LambdaLR(torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-3),
+                                            lambda s: s / 4.0 if s < 4 else 1.0)
+    w0 = tr.model.llm.layers[0].mlp.down_proj.weight.detach().clone()
+    lrs = []
+    for k in range(6):
+        assert abs(tr.current_lr() - ref.get_last_lr()[0]) < 1e-12
+        tr.step(dbatch, x1, x0, t, clean, x0i, ti)
+        lrs.append(tr.last_lr)
+        if k == 0:
+            assert torch.equal(tr.model.llm.layers[0].mlp.down_proj.weight.detach(), w0)      # lr 0
+        ref.optimizer.step(); ref.step()
+    assert lrs == [0.0, 0.00025, 0.0005, 0.00075, 0.001, 0.001]
+    assert not torch.equal(tr.model.llm.layers[0].mlp.down_proj.weight.detach(), w0)
+    with pytest.raises(Exception, match="lr_scheduler"):
+        TR.Stage1Trainer(tr.model, lr_scheduler="cosine")
+
+
+def test_loss_function_with_reference_signature():
+    """loss.training_losses_x1_noise_input(model | trainer, x1, model_kwargs, ...): the reference's call
+    (train_x1_stage1_noiseinput.py:362-377).  The noise is drawn from torch's global RNG in the reference's order, so
+    with the seed the reference-generated vector used (ref_loss_stage1_tiny.npz) the per-frame losses agree."""
+    from tests import glue_cases as GC
+    cfg = R.TINY
+    d = GC.load("ref_loss_stage1_tiny.npz")
+    p, batch, x1, _, _, clean, _, _ = _stage1_case(cfg)
+    LS = importlib.import_module("video-gpt_amd.loss")
+    TR = importlib.import_module("video-gpt_amd.train")
+    model = SC.build_product_model(cfg, p, DEV, cls_name="LVMTraining")
+    kw = {k: (batch[k].to(DEV) if torch.is_tensor(batch[k]) else batch[k]) for k in GC.BATCH_KEYS}
+    kw["input_img_latents"] = list(clean.split(1))
+    torch.manual_seed(123)                       # CPU latents -> CPU draws, the reference's stream
+    terms = LS.training_losses_x1_noise_input(model, list(x1.split(1)), dict(kw), device=DEV)
+    assert rel_l2(terms["loss"], torch.from_numpy(d["loss"])) < 2e-2
+    # through a trainer the same call also back-propagates and (update=True) steps the optimizer
+    tr = TR.Stage1Trainer(model, lr=1e-3)
+    torch.manual_seed(123)
+    t2 = LS.training_losses_x1_noise_input(tr, list(x1.split(1)), dict(kw), device=DEV, update=True)
+    assert torch.equal(t2["loss"], terms["loss"]) and tr.step_count == 1
+    key = "llm.layers.0.self_attn.o_proj.weight"
+    assert rel_l2(torch.from_numpy(GC.sampled_grad(tr.grads[key].float().cpu())), torch.from_numpy(d["grad." + key])) < 6e-2
 
 
 def test_stage1_loss_and_gradients_match_autograd():
@@ -285,6 +356,18 @@ def test_trainer_checkpoint_resume(tmp_path):
     b = TR.Stage1Trainer(SC.build_product_model(cfg, p, DEV, cls_name="LVMTraining"), lr=1e-3, weight_decay=0.1)
     assert b.auto_resume(str(tmp_path / "nothing-here")) is None
     assert b.auto_resume(str(tmp_path)) == 2 and b.step_count == 2
+    # a checkpoint that does not match is refused BEFORE anything is copied (no partially applied load)
+    import json, os, shutil
+    from safetensors.torch import load_file, save_file
+    bad = tmp_path / "bad" / "checkpoint-9"
+    shutil.copytree(path, bad)
+    sd = load_file(str(bad / "model.safetensors")); sd.pop("llm.norm.weight"); save_file(sd, str(bad / "model.safetensors"))
+    c = TR.Stage1Trainer(SC.build_product_model(cfg, p, DEV, cls_name="LVMTraining"), lr=5e-4, weight_decay=0.3)
+    before = {k: v.clone() for k, v in c.model.state_dict().items()}
+    with pytest.raises(Exception, match="llm.norm.weight missing"):
+        c.load_checkpoint(str(bad))
+    assert all(torch.equal(v, before[k]) for k, v in c.model.state_dict().items()) and c.step_count == 0
+    assert c.load_checkpoint(path) == 2 and c.lr == 1e-3 and c.wd == 0.1        # hyper-parameters come back too
     # restored state == the saved trainer's state, bit for bit
     for (ka, va), (kb, vb) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
         assert ka == kb and torch.equal(va, vb), ka
@@ -320,12 +403,26 @@ def _dp_worker(rank, world, port, q):
     TR = importlib.import_module("video-gpt_amd.train")
     tr = TR.Stage1Trainer(model, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
     dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    # the all-reduced gradient (sum over ranks; 1/world is folded into the optimizer's scale) == world x the MEAN of the
+    # ranks' oracle gradients (what DeepSpeed's averaged reduce-scatter hands the reference's optimizer)
+    tr.step(dbatch, x1, x0, t, clean, x0i, ti, update=False)
+    torch.cuda.synchronize()
+    mean_ref = {}
+    for r_ in range(world):
+        xr = torch.randn(x1.shape, generator=torch.Generator("cpu").manual_seed(500 + r_))
+        pr = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in p.items()}
+        lr_, _ = R.stage1_loss(pr, cfg, list(xr.split(1)), list(x0.split(1)), t, list(clean.split(1)), list(x0i.split(1)), ti, batch)
+        lr_.mean().backward()
+        for k in ("llm.layers.1.mlp.down_proj.weight", "llm.layers.0.self_attn.qkv_proj.weight", "llm.norm.weight",
+                  "final_layer.linear.weight"):
+            mean_ref[k] = mean_ref.get(k, 0) + pr[k].grad / world
+    errs = {k: SC.rel_l2(tr.grads[k].float() / world, v) for k, v in mean_ref.items()}
     for _ in range(2):
         tr.step(dbatch, x1, x0, t, clean, x0i, ti)
     torch.cuda.synchronize()
     w = model.llm.layers[1].mlp.down_proj.weight.detach().float().cpu().numpy()   # numpy: pickled by value
     e = model.llm.embed_tokens.weight.detach().float().cpu().numpy()
-    q.put((rank, w, e, float(tr.grad_norm)))
+    q.put((rank, w, e, float(tr.grad_norm), errs))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -343,7 +440,8 @@ def test_data_parallel_two_ranks_stay_in_sync():
     for p_ in procs:
         p_.join(timeout=120)
         assert p_.exitcode == 0
-    (_, w0, e0, n0), (_, w1, e1, n1) = res
+    (_, w0, e0, n0, g0), (_, w1, e1, n1, g1) = res
+    assert g0 == g1 and all(v < 6e-2 for v in g0.values()), g0   # reduced gradient == mean of the per-rank oracle gradients
     assert n0 == n1 and n0 > 0, (n0, n1)                          # same all-reduced gradient norm on both ranks
     assert np.array_equal(w0, w1), float(np.abs(w0 - w1).max())   # replicas identical after all-reduced updates
     assert np.array_equal(e0, e1), float(np.abs(e0 - e1).max())

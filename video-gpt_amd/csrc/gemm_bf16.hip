@@ -688,9 +688,9 @@ VGPT_EXPORT int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, voi
 VGPT_EXPORT int vgpt_gemm_bf16_rope(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t,
                                     int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
                                     int n_rot_heads, int head_dim, void* stream) {
-    VGPT_REQUIRE(A && W && C && cos_t && sin_t, VGPT_ERR_INVALID, "vgpt_gemm_bf16_rope: null pointer");
     VGPT_REQUIRE(M >= 0 && N > 0 && K > 0 && n_rot_heads > 0 && head_dim > 0, VGPT_ERR_INVALID,
                  "vgpt_gemm_bf16_rope: bad shape");
+    VGPT_REQUIRE(M == 0 || (A && W && C && cos_t && sin_t), VGPT_ERR_INVALID, "vgpt_gemm_bf16_rope: null pointer");
     VGPT_REQUIRE(head_dim % 16 == 0 && (int64_t)n_rot_heads * head_dim <= N, VGPT_ERR_UNSUPPORTED,
                  "vgpt_gemm_bf16_rope: head_dim=%d must be a multiple of 16 and the rotated heads must fit in N", head_dim);
     VGPT_REQUIRE(K % BK == 0, VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_rope: K=%ld not a multiple of 64", (long)K);

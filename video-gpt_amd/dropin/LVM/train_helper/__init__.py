@@ -1,0 +1,1 @@
+from .loss import training_losses_x1_noise_input  # noqa: F401

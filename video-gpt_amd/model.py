@@ -308,6 +308,14 @@ class Phi3Transformer(nn.Module):
                 nn.init.normal_(m.weight, mean=0.0, std=std)
         self._inv_freq = None
 
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        """HF PreTrainedModel API the training script calls (train_x1_stage1_noiseinput.py:170-171); read by
+        train.Stage1Trainer, which then keeps only layer inputs and recomputes each layer inside its backward."""
+        self.gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self):
+        self.gradient_checkpointing = False
+
     def rope_tables(self, position_ids):
         if self.config.rope_scaling is not None:
             return rope_tables_for(self.config, position_ids)

@@ -99,6 +99,83 @@ class LVMPipeline:
         return [Image.fromarray(arr[i]) for i in range(arr.shape[0])]
 
     @torch.no_grad()
+    def __call__(self, input_images=None, height: int = 1024, width: int = 1024, gen_num: int = 1,
+                 num_inference_steps: int = 50, use_img_guidance: bool = True, img_guidance_scale: float = 1.6,
+                 max_input_image_size: int = 1024, offload_model: bool = False, use_kv_cache: bool = True,
+                 offload_kv_cache: bool = True, use_input_image_size_as_output: bool = False,
+                 dtype: torch.dtype = torch.bfloat16, seed: int = None, output_type: str = "pil",
+                 time_shifting_factor: float = 1.0, prediction_type: str = "v", clean_image_noise_level: float = None,
+                 generator_device: str = "cuda", vae_noise: Optional[List[torch.Tensor]] = None):
+        """Single-target generation, one image per round, every generated image joining the condition images of the next
+        round (LVM/pipeline.py:138-343): sequence [<img> image </img> ... <|diffusion|> | time token | target tokens]
+        through `LVM.forward_with_cfg`; CFG row = the empty prompt.  Returns the decoded condition images of the first
+        round followed by the generated images."""
+        prompt_img_len = len(input_images) if input_images is not None else 0
+        if not use_input_image_size_as_output:
+            assert height % 16 == 0 and width % 16 == 0, "The height and width must be a multiple of 16."
+        if dtype != torch.bfloat16:
+            raise ops.VgptError("the HIP denoiser computes in bf16")
+        ori_input_images = list(input_images) if input_images is not None else None
+        output_images, output_image = [], None
+        if img_guidance_scale == 1:
+            use_img_guidance = False
+        ori_use_img_guidance = use_img_guidance
+        self.last_latents, self.last_samples = [], []
+        for gen_idx in range(gen_num):
+            if len(output_images) != 0:
+                ori_input_images = [output_image] if ori_input_images is None else ori_input_images + [output_image]
+            use_img_guidance = False if ori_input_images is None else ori_use_img_guidance
+            prompt = "".join(f"<img><|image_{i + 1}|></img>" for i in range(len(ori_input_images or [])))
+            if max_input_image_size != self.processor.max_image_size:
+                self.processor = LVMProcessor(self.processor.text_tokenizer, max_image_size=max_input_image_size)
+            self.processor.collator.hidden_size = self.model.hidden_size
+            self.model.to(self.device, dtype)
+            input_data = self.processor([prompt], [list(ori_input_images)] if ori_input_images is not None else None,
+                                        height=height, width=width, use_img_cfg=use_img_guidance,
+                                        use_input_image_size_as_output=use_input_image_size_as_output)
+            num_cfg = 1 if use_img_guidance else 0
+            if use_input_image_size_as_output:
+                height, width = input_data["input_pixel_values"][0].shape[-2:]
+            lh, lw = height // 8, width // 8
+            gdev = self.device if generator_device == "cuda" else torch.device("cpu")
+            generator = torch.Generator(device=gdev).manual_seed(seed) if seed is not None else None
+            latents = torch.randn(1, 4, lh, lw, device=gdev, generator=generator).to(self.device)
+            latents = torch.cat([latents] * (1 + num_cfg), 0).to(dtype)
+
+            input_img_latents = []
+            dists = self.vae_posteriors([img.to(self.device) for img in input_data["input_pixel_values"]])
+            for idx, d in enumerate(dists):
+                vn = vae_noise[len(self.last_latents)] if vae_noise is not None else None
+                lat = self.vae_encode(None, dtype, None if vn is None else vn.to(self.device), dist=d)
+                self.last_latents.append(lat)
+                if idx >= prompt_img_len:   # a generated image fed back as a condition is re-noised (pipeline.py:256-257)
+                    c = clean_image_noise_level
+                    noise = torch.randn(lat.shape, device=lat.device, dtype=torch.float32)
+                    cvec = torch.full((lat.shape[0],), float(c), device=lat.device, dtype=torch.float32)
+                    lat = ops_train.lerp_frames(noise, lat.float().contiguous(), cvec,
+                                                 torch.empty(lat.shape, device=lat.device, dtype=torch.bfloat16)).to(dtype)
+                input_img_latents.append(lat)
+
+            model_kwargs = dict(input_ids=self.move_to_device(input_data["input_ids"]), input_img_latents=input_img_latents,
+                                input_image_sizes=input_data["input_image_sizes"],
+                                attention_mask=self.move_to_device(input_data["attention_mask"]),
+                                position_ids=self.move_to_device(input_data["position_ids"]),
+                                img_cfg_scale=img_guidance_scale, use_img_cfg=use_img_guidance, use_kv_cache=use_kv_cache,
+                                offload_model=False)
+            scheduler = LVMScheduler(num_steps=num_inference_steps, time_shifting_factor=time_shifting_factor)
+            samples = scheduler(latents, self.model.forward_with_cfg, model_kwargs, use_kv_cache=use_kv_cache,
+                                offload_kv_cache=offload_kv_cache, prediction_type=prediction_type, vae=self.vae)
+            samples = samples.chunk(1 + num_cfg, dim=0)[0]
+            self.last_samples.append(samples)
+            if gen_idx == 0 and input_img_latents:
+                u8 = self.vae.decode_to_uint8(torch.cat(input_img_latents, dim=0))
+                output_images.extend(self._to_images(u8, output_type))
+            u8 = self.vae.decode_to_uint8(samples)
+            output_image = self._to_images(u8[:1], output_type)[0]
+            output_images.append(output_image)
+        return output_images
+
+    @torch.no_grad()
     def prompt_condition_frame_block_autoregressive_inference(
             self, input_images=None, height: int = 1024, width: int = 1024, gen_nums: list = [1],
             num_inference_steps: int = 50, use_img_guidance: bool = True, img_guidance_scale: float = 1.6,

@@ -94,39 +94,44 @@ class LVMScheduler:
             return [zf[i:i + 1] for i in range(len(frames))]
 
         # ---- generic path ----
+        # the state is a (rows, elems) fp32 matrix: one row per list entry, or per batch item of a tensor z
+        # (LVM/scheduler.py:183-204 treats both the same way: x1 -> v, CFG on the two halves, Euler update)
         dev = frames[0].device
-        shapes = [tuple(f.shape) for f in frames]
-        sizes = [f.numel() for f in frames]
-        uniform = len(set(sizes)) == 1
-        if not uniform:
-            raise VgptError("generic sampler path needs latents of one size (mixed resolutions: call per size)")
-        n, elems = len(frames), sizes[0]
-        zf = torch.cat([f.reshape(1, -1) for f in frames], dim=0).to(torch.float32).contiguous()
+        if is_list:
+            shapes = [tuple(f.shape) for f in frames]
+            if len({f.numel() for f in frames}) != 1:
+                raise VgptError("generic sampler path needs latents of one size (mixed resolutions: call per size)")
+            n, elems = len(frames), frames[0].numel()
+            zf = torch.cat([f.reshape(1, -1) for f in frames], dim=0).to(torch.float32).contiguous()
+        else:
+            zt = frames[0]
+            n, elems = zt.shape[0], zt.numel() // max(zt.shape[0], 1)
+            zf = zt.reshape(n, elems).to(torch.float32).contiguous()
         zm = torch.empty(n, elems, dtype=BF16, device=dev)
         ops.cast_f32_to_bf16(zf, zm)
         sigma = self.sigma.to(dev, torch.float32).contiguous()
         step = torch.zeros(1, dtype=torch.int32, device=dev)
-        ts = torch.empty(n if is_list else frames[0].shape[0], dtype=torch.float32, device=dev)
+        ts = torch.empty(n, dtype=torch.float32, device=dev)
         use_cfg = bool(model_kwargs.get("use_img_cfg", False))
         scale = float(model_kwargs.get("img_cfg_scale", 1.0))
-        # for 'v' predictions the CFG combination already happened inside func (LVM/model.py:555-562)
+        # for 'v' predictions the CFG combination already happened inside func (LVM/model.py:508-512, 555-562)
         kernel_cfg = use_cfg and prediction_type == "x1"
+        if kernel_cfg and n % 2:
+            raise VgptError("image CFG needs the conditional and unconditional halves (an even number of latents)")
         for _ in range(self.num_steps):
             ops.sampler_set_timesteps(sigma, step, ts)
-            z_in = [zm[i].view(shapes[i]) for i in range(n)] if is_list else zm.view(shapes[0])
+            z_in = [zm[i].view(shapes[i]) for i in range(n)] if is_list else zm.view(frames[0].shape)
             pred, _cache = func(z_in, ts, past_key_values=None, prediction_type=prediction_type, **model_kwargs)
             if is_list:
                 pred = torch.cat([p.reshape(1, -1) for p in pred], dim=0)
             pred = pred.reshape(n, elems).to(BF16).contiguous()
-            if kernel_cfg and not is_list:
-                raise VgptError("x1 + CFG on a batched tensor is not supported; pass a list of frames")
             ops.euler_cfg_update(zf, zm, pred, sigma, step, ops.PRED_X1 if prediction_type == "x1" else ops.PRED_V,
                                  kernel_cfg, scale)
             ops.sampler_advance(step)
         out = zf.to(out_dtype)
         if is_list:
             return [out[i].view(shapes[i]) for i in range(n)]
-        return out.view(shapes[0])
+        return out.view(frames[0].shape)
 
 
 class _null:

@@ -33,11 +33,25 @@ F32 = torch.float32
 
 class Stage1Trainer:
     def __init__(self, model, lr: float = 1e-4, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 max_grad_norm: Optional[float] = 1.0, input_noise: float = 0.9, pack_padding: bool = True):
+                 max_grad_norm: Optional[float] = 1.0, input_noise: float = 0.9, pack_padding: bool = True,
+                 lr_scheduler: str = "constant", lr_warmup_steps: int = 0, gradient_checkpointing: Optional[bool] = None,
+                 forward_only: bool = False):
+        """lr_scheduler / lr_warmup_steps: diffusers' get_scheduler("constant" | "constant_with_warmup")
+        (train_x1_stage1_noiseinput.py:279-283; the scripts use constant_with_warmup): the k-th optimizer step (k = 0, 1,
+        ...) runs at lr * min(1, k / warmup).  gradient_checkpointing (default: model.llm.gradient_checkpointing, set by
+        `model.llm.gradient_checkpointing_enable()`, train...py:170-171): keep only each decoder layer's input and
+        recompute the layer inside the backward (OmniGen/transformer.py:182-192).  forward_only: no gradient / optimizer
+        state (loss evaluation through `loss.training_losses_x1_noise_input`)."""
         model._check_ready()
         self.model = model
         self.cfg = model.llm.config
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        if lr_scheduler not in ("constant", "constant_with_warmup"):
+            raise VgptError(f"lr_scheduler {lr_scheduler!r}: only 'constant' and 'constant_with_warmup' are built")
+        self.lr_scheduler, self.lr_warmup_steps = lr_scheduler, int(lr_warmup_steps)
+        self.gradient_checkpointing = (bool(getattr(model.llm, "gradient_checkpointing", False))
+                                       if gradient_checkpointing is None else bool(gradient_checkpointing))
+        self.forward_only = forward_only
         self.max_grad_norm = max_grad_norm
         self.input_noise = input_noise
         self.pack_padding = pack_padding
@@ -45,12 +59,16 @@ class Stage1Trainer:
         self.step_count = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.params = {n: p for n, p in model.named_parameters()}
+        self._ws = {}
+        self.last = {}
+        self.grads: Dict[str, torch.Tensor] = {}
+        if forward_only:
+            return
         L = self.cfg.num_hidden_layers
         # ---- gradient storage: one flat bf16 bucket per decoder layer + one fp32 bucket for the rest ----
         self.layer_names = [[f"llm.layers.{i}.self_attn.qkv_proj.weight", f"llm.layers.{i}.self_attn.o_proj.weight",
                              f"llm.layers.{i}.mlp.gate_up_proj.weight", f"llm.layers.{i}.mlp.down_proj.weight"]
                             for i in range(L)]
-        self.grads: Dict[str, torch.Tensor] = {}
         self.layer_buckets = []
         for names in self.layer_names:
             n = sum(self.params[k].numel() for k in names)
@@ -100,8 +118,22 @@ class Stage1Trainer:
         self.sumsq = torch.zeros(1, dtype=F32, device=self.dev)
         self.coef = torch.ones(1, dtype=F32, device=self.dev)
         self.grad_norm = torch.zeros(1, dtype=F32, device=self.dev)
-        self._ws = {}
-        self.last = {}
+
+    @classmethod
+    def for_evaluation(cls, model):
+        """A forward-only trainer cached on the model (no gradient buckets, no optimizer state)."""
+        tr = getattr(model, "_vgpt_eval_trainer", None)
+        if tr is None:
+            tr = cls(model, forward_only=True)
+            object.__setattr__(model, "_vgpt_eval_trainer", tr)
+        return tr
+
+    def current_lr(self) -> float:
+        """Learning rate of the NEXT optimizer step (diffusers get_constant_schedule_with_warmup's lambda at
+        current_step = optimizer steps taken so far)."""
+        if self.lr_scheduler == "constant_with_warmup" and self.step_count < self.lr_warmup_steps:
+            return self.lr * self.step_count / max(1.0, float(self.lr_warmup_steps))
+        return self.lr
 
     # ------------------------------------------------------------------------------------------------
     def _buf(self, name, shape, dtype=BF16):
@@ -137,7 +169,7 @@ class Stage1Trainer:
 
     # ------------------------------------------------------------------------------------------------
     def step(self, batch, x1: torch.Tensor, x0: torch.Tensor, t: torch.Tensor, clean: Optional[torch.Tensor],
-             x0_in: Optional[torch.Tensor], t_in: Optional[torch.Tensor], update: bool = True):
+             x0_in: Optional[torch.Tensor], t_in: Optional[torch.Tensor], update: bool = True, backward: bool = True):
         """One optimisation step.  x1/x0: (F, C, h, w) fp32 target latents / noise, t: (F,) fp32;
         clean/x0_in/t_in: the clean-frame latents and their noise (loss.py:166-192).  Returns the per-frame losses."""
         m, cfg = self.model, self.cfg
@@ -170,21 +202,31 @@ class Stage1Trainer:
         ops.linear_small(tt_act, tt[2].weight, tt[2].bias, out=seq, out_row=prep["t_rows"], ldo=H)
         ops.patch_embed(xt, m.x_embedder.proj.weight, m.x_embedder.proj.bias, pos, prep["x_rows"], seq,
                         m.pos_embed_max_size)
-        n1 = self._buf("n1", (nl, M, H)); qkv = self._buf("qkv", (nl, M, (nq + 2 * nk) * hd))
-        ctx = self._buf("ctx", (nl, M, nq * hd)); h2 = self._buf("h2", (nl, M, H)); n2 = self._buf("n2", (nl, M, H))
-        gu = self._buf("gu", (nl, M, 2 * I)); act = self._buf("act", (nl, M, I))
-        lse = self._buf("lse", (nl, B, nq, L), F32)
-        for li, layer in enumerate(m.llm.layers):
-            at, mlp = layer.self_attn, layer.mlp
-            ops.rmsnorm(hbuf[li], layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=n1[li])
-            ops.linear_qkv_rope(n1[li], at.qkv_proj.weight, prep["rope"][0], prep["rope"][1], nq, nk, hd, out=qkv[li])
-            T.attention_qkv_train(qkv[li].view(B, L, -1), prep["pm"], nq, nk, hd, ctx[li].view(B, L, -1), lse[li])
-            ops.linear(ctx[li], at.o_proj.weight, residual=hbuf[li], out=h2[li])
-            ops.rmsnorm(h2[li], layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon,
-                        out=n2[li])
-            ops.linear(n2[li], mlp.gate_up_proj.weight, out=gu[li])
-            T.silu_mul_fwd(gu[li], act[li], mlp.act)
-            ops.linear(act[li], mlp.down_proj.weight, residual=h2[li], out=hbuf[li + 1])
+        # saved activations: every layer's (normal) or ONE layer's worth, recomputed per layer in the backward (checkpointing)
+        ck = self.gradient_checkpointing
+        ns = 1 if ck else nl
+        n1 = self._buf("n1", (ns, M, H)); qkv = self._buf("qkv", (ns, M, (nq + 2 * nk) * hd))
+        ctx = self._buf("ctx", (ns, M, nq * hd)); h2 = self._buf("h2", (ns, M, H)); n2 = self._buf("n2", (ns, M, H))
+        gu = self._buf("gu", (ns, M, 2 * I)); act = self._buf("act", (ns, M, I))
+        lse = self._buf("lse", (ns, B, nq, L), F32)
+        sv = lambda li: 0 if ck else li
+
+        def layer_forward(li, with_output=True):
+            layer = m.llm.layers[li]
+            at, mlp, k = layer.self_attn, layer.mlp, sv(li)
+            ops.rmsnorm(hbuf[li], layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=n1[k])
+            ops.linear_qkv_rope(n1[k], at.qkv_proj.weight, prep["rope"][0], prep["rope"][1], nq, nk, hd, out=qkv[k])
+            T.attention_qkv_train(qkv[k].view(B, L, -1), prep["pm"], nq, nk, hd, ctx[k].view(B, L, -1), lse[k])
+            ops.linear(ctx[k], at.o_proj.weight, residual=hbuf[li], out=h2[k])
+            ops.rmsnorm(h2[k], layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon,
+                        out=n2[k])
+            ops.linear(n2[k], mlp.gate_up_proj.weight, out=gu[k])
+            T.silu_mul_fwd(gu[k], act[k], mlp.act)
+            if with_output:
+                ops.linear(act[k], mlp.down_proj.weight, residual=h2[k], out=hbuf[li + 1])
+
+        for li in range(nl):
+            layer_forward(li)
         nrm = ops.rmsnorm(hbuf[nl], m.llm.norm.weight, m.llm.norm.variance_epsilon, out=self._buf("nrm", (M, H)))
         te_pre = ops.linear_small(sin, te[0].weight, te[0].bias)
         te_act = T.act_fwd(te_pre, ops.ACT_SILU)
@@ -201,7 +243,9 @@ class Stage1Trainer:
         dpred = self._buf("dpred", (nf, C, h, w))
         T.mse_frames(pred, x1, loss, dpred)
         self.last = dict(pred=pred, loss=loss, xt=xt)
-        if not update and not self._want_grads:
+        if self.forward_only or not backward:
+            if update:
+                raise VgptError("Stage1Trainer.step: an optimizer step needs the backward pass")
             return loss
         # ---------------- backward ----------------
         g = self.grads
@@ -231,20 +275,23 @@ class Stage1Trainer:
             layer = m.llm.layers[li]
             at, mlp = layer.self_attn, layer.mlp
             names = self.layer_names[li]
-            T.linear_dw(dh, act[li], sa, sb, g[names[3]])                               # dW_down
+            if ck:      # same kernels on the same inputs as the forward pass: the recomputed activations are bit-identical
+                layer_forward(li, with_output=False)
+            k = sv(li)
+            T.linear_dw(dh, act[k], sa, sb, g[names[3]])                               # dW_down
             T.linear_dx(dh, mlp.down_proj.weight, sw, out=dact)
-            T.silu_mul_bwd(gu[li], dact, dgu, mlp.act)
-            T.linear_dw(dgu, n2[li], sa, sb, g[names[2]])                               # dW_gate_up
+            T.silu_mul_bwd(gu[k], dact, dgu, mlp.act)
+            T.linear_dw(dgu, n2[k], sa, sb, g[names[2]])                               # dW_gate_up
             T.linear_dx(dgu, mlp.gate_up_proj.weight, sw, out=dn)
-            T.rmsnorm_bwd(h2[li], layer.post_attention_layernorm.weight, dn, dh_b,
+            T.rmsnorm_bwd(h2[k], layer.post_attention_layernorm.weight, dn, dh_b,
                           g[f"llm.layers.{li}.post_attention_layernorm.weight"],
                           layer.post_attention_layernorm.variance_epsilon, dres=dh)       # dh2
-            T.linear_dw(dh_b, ctx[li], sa, sb, g[names[1]])                             # dW_o
+            T.linear_dw(dh_b, ctx[k], sa, sb, g[names[1]])                             # dW_o
             T.linear_dx(dh_b, at.o_proj.weight, sw, out=dctx)
-            T.attention_qkv_bwd(qkv[li].view(B, L, -1), ctx[li].view(B, L, -1), dctx.view(B, L, -1), lse[li], delta,
+            T.attention_qkv_bwd(qkv[k].view(B, L, -1), ctx[k].view(B, L, -1), dctx.view(B, L, -1), lse[k], delta,
                                 dqkv.view(B, L, -1), prep["pm"], nq, nk, hd)
             ops.rope_qk_inplace(dqkv, prep["rope"][0], nsin, nq, nk, hd)                 # inverse rotation
-            T.linear_dw(dqkv, n1[li], sa, sb, g[names[0]])                              # dW_qkv
+            T.linear_dw(dqkv, n1[k], sa, sb, g[names[0]])                              # dW_qkv
             T.linear_dx(dqkv, at.qkv_proj.weight, sw, out=dn)
             T.rmsnorm_bwd(hbuf[li], layer.input_layernorm.weight, dn, dh,
                           g[f"llm.layers.{li}.input_layernorm.weight"], layer.input_layernorm.variance_epsilon,
@@ -266,8 +313,6 @@ class Stage1Trainer:
         if update:
             self.optimizer_step()
         return loss
-
-    _want_grads = True
 
     def _neg_sin(self, prep):
         key = ("nsin", prep["rope"][1].data_ptr())
@@ -293,6 +338,8 @@ class Stage1Trainer:
 
     # ------------------------------------------------------------------------------------------------
     def optimizer_step(self):
+        lr = self.current_lr()
+        self.last_lr = lr
         self.step_count += 1
         self.sumsq.zero_()
         for b in self.layer_buckets:
@@ -304,8 +351,8 @@ class Stage1Trainer:
         b1, b2 = self.betas
         for i in range(len(self.layer_buckets)):
             T.adamw_step(self.master_layers[i], self.param_layers[i], self.layer_buckets[i], self.m_layers[i],
-                         self.v_layers[i], self.lr, b1, b2, self.eps, self.wd, self.step_count, self.coef)
-        T.adamw_step(self.master_small, self.param_small, self.small_bucket, self.m_small, self.v_small, self.lr, b1, b2,
+                         self.v_layers[i], lr, b1, b2, self.eps, self.wd, self.step_count, self.coef)
+        T.adamw_step(self.master_small, self.param_small, self.small_bucket, self.m_small, self.v_small, lr, b1, b2,
                      self.eps, self.wd, self.step_count, self.coef)
 
 
@@ -314,25 +361,35 @@ class Stage1Trainer:
     #      load: model.safetensors holds the bf16 state_dict under the reference's keys (loadable by
     #      LVM.from_pretrained), optimizer.safetensors the fp32 master weights and Adam moments per bucket. ----
     def save_checkpoint(self, results_dir: str, global_step: Optional[int] = None) -> str:
+        """Rank 0 writes (replicas are identical under data parallelism); every rank returns after the files exist."""
         import json
         import os
         from safetensors.torch import save_file
         step = self.step_count if global_step is None else int(global_step)
         path = os.path.join(results_dir, f"checkpoint-{step}")
-        os.makedirs(path, exist_ok=True)
-        save_file({k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()},
-                  os.path.join(path, "model.safetensors"))
-        opt = {"master_small": self.master_small, "m_small": self.m_small, "v_small": self.v_small}
-        for i in range(len(self.master_layers)):
-            opt[f"master.{i}"], opt[f"m.{i}"], opt[f"v.{i}"] = self.master_layers[i], self.m_layers[i], self.v_layers[i]
-        save_file({k: v.detach().cpu().contiguous() for k, v in opt.items()}, os.path.join(path, "optimizer.safetensors"))
-        with open(os.path.join(path, "trainer_state.json"), "w") as f:
-            json.dump({"step_count": self.step_count, "global_step": step, "lr": self.lr, "weight_decay": self.wd,
-                       "betas": list(self.betas), "eps": self.eps, "small_names": self.small_names}, f)
+        distributed = dist.is_available() and dist.is_initialized()
+        if not distributed or dist.get_rank() == 0:
+            os.makedirs(path, exist_ok=True)
+            save_file({k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()},
+                      os.path.join(path, "model.safetensors"))
+            opt = {"master_small": self.master_small, "m_small": self.m_small, "v_small": self.v_small}
+            for i in range(len(self.master_layers)):
+                opt[f"master.{i}"], opt[f"m.{i}"], opt[f"v.{i}"] = self.master_layers[i], self.m_layers[i], self.v_layers[i]
+            save_file({k: v.detach().cpu().contiguous() for k, v in opt.items()}, os.path.join(path, "optimizer.safetensors"))
+            with open(os.path.join(path, "trainer_state.json"), "w") as f:
+                json.dump({"step_count": self.step_count, "global_step": step, "lr": self.lr, "weight_decay": self.wd,
+                           "betas": list(self.betas), "eps": self.eps, "lr_scheduler": self.lr_scheduler,
+                           "lr_warmup_steps": self.lr_warmup_steps, "small_names": self.small_names}, f)
+        if distributed:
+            dist.barrier()
         return path
 
-    def load_checkpoint(self, path: str) -> int:
-        """Restores parameters, fp32 master weights, Adam moments and the step counter; returns the global step."""
+    def load_checkpoint(self, path: str, restore_hyperparameters: bool = True) -> int:
+        """Restores parameters, fp32 master weights, Adam moments, the step counter and (by default) the optimizer
+        hyper-parameters and LR schedule; returns the global step.  Everything is validated before anything is copied.
+        Only checkpoints written by this trainer resume (the reference's are accelerate / DeepSpeed `save_state`
+        directories, whose optimizer shards are pickles: warm-start from those through LVM.from_pretrained's weight
+        loaders instead)."""
         import json
         import os
         from safetensors.torch import load_file
@@ -344,15 +401,27 @@ class Stage1Trainer:
         pairs = [(self.master_small, "master_small"), (self.m_small, "m_small"), (self.v_small, "v_small")]
         for i in range(len(self.master_layers)):
             pairs += [(self.master_layers[i], f"master.{i}"), (self.m_layers[i], f"m.{i}"), (self.v_layers[i], f"v.{i}")]
-        for dst, key in pairs:
-            if opt[key].shape != dst.shape:
-                raise VgptError(f"checkpoint tensor {key} has shape {tuple(opt[key].shape)}, expected {tuple(dst.shape)}")
-            dst.copy_(opt[key])
         model_sd = load_file(os.path.join(path, "model.safetensors"))
+        own = self.model.state_dict()
+        problems = [f"optimizer tensor {k} missing" for _, k in pairs if k not in opt]
+        problems += [f"optimizer tensor {k}: shape {tuple(opt[k].shape)} != {tuple(d.shape)}" for d, k in pairs
+                     if k in opt and opt[k].shape != d.shape]
+        problems += [f"model tensor {k} missing" for k in own if k not in model_sd]
+        problems += [f"model tensor {k}: shape {tuple(model_sd[k].shape)} != {tuple(v.shape)}" for k, v in own.items()
+                     if k in model_sd and model_sd[k].shape != v.shape]
+        if problems:
+            raise VgptError(f"{path}: checkpoint does not match this trainer: " + "; ".join(problems[:8]))
+        for dst, key in pairs:
+            dst.copy_(opt[key])
         with torch.no_grad():     # parameters are views of the flat bf16 buffers: copy in place, keep the views
-            for k, p_ in self.model.state_dict().items():
+            for k, p_ in own.items():
                 p_.copy_(model_sd[k])
         self.step_count = int(st["step_count"])
+        if restore_hyperparameters:
+            self.lr, self.wd, self.eps = float(st["lr"]), float(st["weight_decay"]), float(st["eps"])
+            self.betas = tuple(st["betas"])
+            self.lr_scheduler = st.get("lr_scheduler", self.lr_scheduler)
+            self.lr_warmup_steps = int(st.get("lr_warmup_steps", self.lr_warmup_steps))
         return int(st["global_step"])
 
     def auto_resume(self, results_dir: str) -> Optional[int]:
