@@ -250,3 +250,34 @@ class AutoencoderKL(nn.Module):
         shift = self.config.shift_factor or 0.0
         z = ops.affine_to_f32(latents, 1.0 / self.config.scaling_factor, shift)
         return ops.vae_postprocess_u8(self.decode(z).sample)
+
+
+# ---- LVM/utils.py:99-145: the VAE seam of the training loops -------------------------------------------------------
+def vae_encode(vae, x, weight_dtype, seed=None, batch_encode=False):
+    """list of images (1, 3, H, W) in [-1, 1] -> list of latents (1, 4, H/8, W/8): posterior sample, (z - shift) *
+    scaling, cast (LVM/utils.py:99-137; call sites train_x1_stage1_noiseinput.py:354-358).  `batch_encode` runs the
+    encoder once over the concatenated images; `seed` draws the posterior noise from a generator seeded with it (the
+    reference reseeds and restores the global RNGs around every image, :113-135)."""
+    shift, scaling = vae.config.shift_factor or 0.0, vae.config.scaling_factor
+    if len(x) == 0:
+        return []
+    same = all(t.shape == x[0].shape for t in x)
+    if batch_encode or (same and seed is None):
+        if not same:
+            raise VgptError("vae_encode(batch_encode=True): images must share one resolution")
+        mom = vae.encode(torch.cat(list(x), dim=0)).latent_dist.parameters
+        dists = [DiagonalGaussianDistribution(mom[i:i + 1]) for i in range(len(x))]
+    else:
+        dists = [vae.encode(img).latent_dist for img in x]
+    out = []
+    for d in dists:
+        p = d.parameters
+        gen = torch.Generator(device=p.device).manual_seed(seed) if seed is not None else None
+        noise = torch.randn(p.shape[0], p.shape[1] // 2, *p.shape[2:], device=p.device, dtype=F32, generator=gen)
+        out.append(d.sample_scaled(noise, shift, scaling).to(weight_dtype))
+    return out
+
+
+def vae_encode_list(vae, x, weight_dtype):
+    """LVM/utils.py:140-145."""
+    return [vae_encode(vae, img, weight_dtype) for img in x]
