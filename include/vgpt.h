@@ -162,27 +162,21 @@ int vgpt_attn_blockmask_fwd_qrange(const void* q, const void* k, const void* v, 
                                    int64_t o_sh, int64_t o_ss, float scale, void* stream);
 
 /* ---- planned forward.  A PLAN describes the query side of one mask:
- *   items         (n_items, 4) int32: {batch, row0, nrows (1..item_rows), 0}; disjoint row ranges, cut wherever the
+ *   items         (n_items, 4) int32: {batch, row0, nrows (1..128), 0}; disjoint row ranges, cut wherever the
  *                 caller likes -- at the boundaries of packed sequences, so that no item mixes rows with different key
  *                 sets (an aligned block straddling two sequences would walk the key tiles of both);
  *   item_summary  (n_items, ceil(L/64)) uint16: 2 bits per 32-row slab of the item (0 none / 1 all / 2 mixed);
  *   order         (n_items) int32: items sorted longest first.
- * item_rows selects the kernel: 128 = the 4-wave kernel of vgpt_attn_blockmask_fwd (two workgroups per CU; the default
- * of the Python host), 256 = an 8-wave kernel (head_dim 96 only) whose two wave groups alternate matrix and vector
- * phases under workgroup barriers -- measured slower on MI355X at the cfg-2 shapes and kept selectable.
- * Key-split items (item_rows 128): a row range whose key set is much longer than the others' may appear as `nparts`
- * work items with items[.][3] = part | nparts << 8 | pbase << 16 (pbase = number of key slices of all earlier split
- * items); each walks its slice of the visible key tiles and leaves (unnormalised O, m, l) in split_ws, a merge kernel
- * launched behind the main one writes the rows.  split_items (n_split, 4) = {batch, row0, nrows, nparts | pbase << 8};
- * split_ws holds (total key slices) * n_heads * 128 * (head_dim + 4) floats.  n_split = 0: no splitting.
- * vgpt_attn_plan_build fills item_summary and order from bits and items.  vgpt_attn_fwd_plan computes exactly the rows
- * the items cover (same math as vgpt_attn_blockmask_fwd); lse may be NULL. */
-int vgpt_attn_plan_build(const uint32_t* bits, int64_t B, int64_t L, const int32_t* items, int64_t n_items, int item_rows,
+ * vgpt_attn_plan_build fills item_summary and order from bits and items; both live in ONE caller-allocated workspace of
+ * vgpt_attn_plan_workspace_bytes(L, n_items) bytes: item_summary at its start, order at the next multiple of 256 bytes
+ * behind n_items * ceil(L/64) * 2.  vgpt_attn_fwd_plan computes exactly the rows the items cover (same result as
+ * vgpt_attn_blockmask_fwd up to the rounding of the online softmax); lse may be NULL. */
+int64_t vgpt_attn_plan_workspace_bytes(int64_t L, int64_t n_items);
+int vgpt_attn_plan_build(const uint32_t* bits, int64_t B, int64_t L, const int32_t* items, int64_t n_items,
                          uint16_t* item_summary, int32_t* order, void* stream);
 int vgpt_attn_fwd_plan(const void* q, const void* k, const void* v, void* o, float* lse, const uint32_t* bits,
                        const int32_t* items, const uint16_t* item_summary, const int32_t* order, int64_t n_items,
-                       int item_rows, const int32_t* split_items, int64_t n_split, float* split_ws, int64_t B, int64_t L,
-                       int n_heads, int n_kv_heads, int head_dim, int64_t q_sb,
+                       int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim, int64_t q_sb,
                        int64_t q_sh, int64_t q_ss, int64_t k_sb, int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
                        int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss, float scale, void* stream);
 

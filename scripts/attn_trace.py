@@ -29,12 +29,12 @@ eng.set_latents(torch.cat(z, 0)); eng.sampler_step(); torch.cuda.synchronize()
 nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
 if "--solo" in sys.argv:   # only group A has rows: intrinsic phase lengths without a partner wave
     eng.seg_live = ((0, eng.S, eng.S + 128),)
-IR = 256 if "--pp" in sys.argv else 128
+IR = 128
 def run():
     if eng.S:
-        ops.attention_qkv_range(eng.qkv_full[0].view(1, eng.L, -1), eng.pm, nq, nk, hd, eng.S, eng.ctx, segments=eng.seg_live, item_rows=IR)
+        ops.attention_qkv_range(eng.qkv_full[0].view(1, eng.L, -1), eng.pm, nq, nk, hd, eng.S, eng.ctx, segments=eng.seg_live)
     else:
-        ops.attention_qkv_range(eng.qkv, eng.pm, nq, nk, hd, 0, eng.ctx, segments=eng.seg_all, item_rows=IR)
+        ops.attention_qkv_range(eng.qkv, eng.pm, nq, nk, hd, 0, eng.ctx, segments=eng.seg_all)
 for _ in range(5): run()
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,10 +42,10 @@ s.record()
 for _ in range(20): run()
 e.record(); torch.cuda.synchronize()
 print("avg attention launch us:", s.elapsed_time(e) / 20 * 1e3, "S", eng.S, "L", eng.L, "Ma", eng.Ma)
-plan = eng.pm.plan(eng.seg_live if eng.S else eng.seg_all, IR)
+plan = eng.pm.plan(eng.seg_live if eng.S else eng.seg_all)
 print("items", plan.items.cpu().tolist(), "order", plan.order.cpu().tolist())
 nblk = plan.n_items * nq
-NSLOT = 256 if IR == 256 else 512
+NSLOT = 512
 tr = torch.zeros(nblk + 8 * 32, 4, dtype=torch.int64, device=dev)
 L_.call("vgpt_attn_trace", tr.data_ptr(), nblk)
 run(); torch.cuda.synchronize()

@@ -47,9 +47,10 @@ SIGNATURES = {
         c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
     "vgpt_attn_qblock_order": (c_int, [_P, _I64, _I64, _I64, _P, _P]),
     "vgpt_attn_trace": (c_int, [_P, _I64]),
-    "vgpt_attn_plan_build": (c_int, [_P, _I64, _I64, _P, _I64, c_int, _P, _P, _P]),
+    "vgpt_attn_plan_build": (c_int, [_P, _I64, _I64, _P, _I64, _P, _P, _P]),
+    "vgpt_attn_plan_workspace_bytes": (_I64, [_I64, _I64]),
     "vgpt_attn_fwd_plan": (
-        c_int, [_P] * 9 + [_I64, c_int, _P, _I64, _P, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
+        c_int, [_P] * 9 + [_I64, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
     "vgpt_embed_gather": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "vgpt_patch_embed_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64, c_int, _P]),
     "vgpt_timestep_sinusoid": (c_int, [_P, _P, _P, c_int, c_int, _P]),

@@ -38,9 +38,6 @@ struct AttnArgs {
     const uint16_t* isum;      // n_items x nkt, 2 bits per 32-row slab
     const int32_t* iorder;     // n_items
     int n_items;
-    // items[4i+3] = part | nparts << 8 | pbase << 16: an item may be cut into `nparts` work items that each walk a slice
-    // of its visible key tiles and leave (unnormalised O, m, l) in split_ws (slice index pbase + part) for the merge kernel
-    float* split_ws;
     float* lse;  // optional (B, n_heads, L): base-2 log-sum-exp of the scaled scores, for the backward
     int B, L, n_heads, kv_group;  // kv_group = n_heads / n_kv_heads
     int W;                        // mask words per row
@@ -110,7 +107,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     int n_tiles_done = 0;
 
     // ---- work item ----
-    int wid = blockIdx.x, head, b, row0, row_last, part = 0, nparts = 1, slot = 0;
+    int wid = blockIdx.x, head, b, row0, row_last;
     const uint8_t* sum8 = nullptr;
     const uint16_t* sum16 = nullptr;
     if (a.items) {
@@ -129,10 +126,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         b = a.items[4 * item];
         row0 = a.items[4 * item + 1];
         row_last = row0 + a.items[4 * item + 2] - 1;
-        const int meta = a.items[4 * item + 3];
-        part = meta & 255;
-        nparts = max((meta >> 8) & 255, 1);
-        slot = meta >> 16;
         sum16 = a.isum + (int64_t)item * a.nkt;
         wid = item;
     } else {
@@ -274,23 +267,16 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     if (wave == 0) {
         const int lim = min(chunk0 + ACT_MAX, a.nkt);
         auto code_of_tile = [&](int t) { return t < lim ? (sum16 ? (uint32_t)sum16[t] & 0xffu : (uint32_t)sum8[t]) : 0u; };
-        int lo = 0, hi = 0x7fffffff;
-        if (nparts > 1) {   // this work item takes slice `part` of the visible tiles (counted first)
-            int n_all = 0;
-            for (int base = chunk0; base < lim; base += 64) n_all += __popcll(__ballot(code_of_tile(base + lane) != 0));
-            lo = n_all * part / nparts;
-            hi = n_all * (part + 1) / nparts;
-        }
         int n = 0;
         for (int base = chunk0; base < lim; base += 64) {
             const int t = base + lane;
             const uint32_t c = code_of_tile(t);
             const uint64_t bal = __ballot(c != 0);
             const int idx = n + __popcll(bal & ((1ull << lane) - 1));
-            if (c && idx >= lo && idx < hi) alist[1 + idx - lo] = ((uint32_t)t << 8) | c;
+            if (c) alist[1 + idx] = ((uint32_t)t << 8) | c;
             n += __popcll(bal);
         }
-        if (lane == 0) alist[0] = (uint32_t)(min(n, hi) - min(n, lo));
+        if (lane == 0) alist[0] = (uint32_t)n;
     }
     __syncthreads();
     const int n_act = __builtin_amdgcn_readfirstlane((int)alist[0]);
@@ -449,20 +435,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         t[3] = ((unsigned long long)(unsigned)wid << 32) | (unsigned)n_tiles_done;
     }
     // ---- epilogue: lane holds O^T[d = 32dt + (i&3) + 8(i>>2) + 4h][q = r] ----
-    if (nparts > 1) {   // partial result of a key slice: rows of (D + 4) floats = O (unnormalised), m, l, -, -
-        float* wsr = a.split_ws + ((((int64_t)slot + part) * a.n_heads + head) * 128 + wave * 32 + r) * (D + 4);  // slot = pbase
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                *reinterpret_cast<f32x4*>(wsr + dt * 32 + 8 * g4 + 4 * h) =
-                    f32x4{O[dt][4 * g4], O[dt][4 * g4 + 1], O[dt][4 * g4 + 2], O[dt][4 * g4 + 3]};
-        if (h == 0) {
-            wsr[D] = m_i;
-            wsr[D + 1] = l_i;
-        }
-        return;
-    }
     if (a.lse && q_valid && h == 0)
         a.lse[((int64_t)b * a.n_heads + head) * a.L + q_row] = l_i > 0.f ? m_i + __builtin_amdgcn_logf(l_i) : INFINITY;
     if (q_valid) {
@@ -478,49 +450,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
                 *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g4 + 4 * h) = o;
             }
     }
-}
-
-// merge of the key-slice partials of split items: one workgroup per (split item, head), thread = (row, half of d)
-template <int D>
-__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ ws, const int32_t* __restrict__ split_items,
-                                                         bf16* __restrict__ o, float* __restrict__ lse, int n_heads, int L,
-                                                         int64_t o_sb, int64_t o_sh, int64_t o_ss) {
-    const int slot = blockIdx.x / n_heads, head = blockIdx.x % n_heads;
-    const int b = split_items[4 * slot], row0 = split_items[4 * slot + 1], nrows = split_items[4 * slot + 2];
-    const int nparts = split_items[4 * slot + 3] & 255, pbase = split_items[4 * slot + 3] >> 8;
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
-    if (row >= nrows) return;
-    const int64_t pstride = (int64_t)n_heads * 128 * (D + 4);   // between consecutive key slices of one (item, head)
-    const float* base = ws + (((int64_t)pbase * n_heads + head) * 128 + row) * (D + 4);
-    float m_all = -INFINITY;
-    for (int p = 0; p < nparts; ++p) m_all = fmaxf(m_all, base[p * pstride + D]);
-    float l_all = 0.f;
-    float acc[D / 2];
-#pragma unroll
-    for (int d = 0; d < D / 2; ++d) acc[d] = 0.f;
-    for (int p = 0; p < nparts; ++p) {
-        const float* pr = base + p * pstride;
-        const float mp = pr[D];
-        const float f = mp == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mp - m_all);
-        l_all += pr[D + 1] * f;
-#pragma unroll
-        for (int d4 = 0; d4 < D / 8; ++d4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(pr + half * (D / 2) + 4 * d4);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[4 * d4 + t] += v[t] * f;
-        }
-    }
-    const float inv = l_all > 0.f ? 1.0f / l_all : 0.f;
-    bf16* op = o + b * o_sb + head * o_sh + (int64_t)(row0 + row) * o_ss + half * (D / 2);
-#pragma unroll
-    for (int d4 = 0; d4 < D / 8; ++d4) {
-        bf16x4 v;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = f2bf(acc[4 * d4 + t] * inv);
-        *reinterpret_cast<bf16x4*>(op + 4 * d4) = v;
-    }
-    if (lse && half == 0)
-        lse[((int64_t)b * n_heads + head) * L + row0 + row] = l_all > 0.f ? m_all + __builtin_amdgcn_logf(l_all) : INFINITY;
 }
 
 template <int D, bool TR>
@@ -547,10 +476,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
 static unsigned long long* g_trace = nullptr;
 static int64_t g_trace_cap = 0;
 
-void vgpt_attn_pp_set_trace(void* buf, int64_t cap);  // attn_fwd_pp.hip
-
 VGPT_EXPORT int vgpt_attn_trace(void* buf, int64_t capacity_workgroups) {
-    vgpt_attn_pp_set_trace(buf, capacity_workgroups);
     g_trace = (unsigned long long*)buf;
     g_trace_cap = buf ? capacity_workgroups : 0;
     return VGPT_OK;
@@ -565,9 +491,6 @@ struct ItemPlan {
     const uint16_t* isum;
     const int32_t* order;
     int64_t n_items;
-    const int32_t* split_items;   // n_split x 4: batch, row0, nrows, nparts | pbase << 8 (items cut into key slices), or null
-    int64_t n_split;
-    float* split_ws;              // n_split * n_heads * sum(nparts) * 128 * (head_dim + 4) floats
 };
 
 static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, int64_t q_start,
@@ -617,9 +540,6 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
     a.isum = plan ? plan->isum : nullptr;
     a.iorder = plan ? plan->order : nullptr;
     a.n_items = plan ? (int)plan->n_items : 0;
-    a.split_ws = plan ? plan->split_ws : nullptr;
-    VGPT_REQUIRE(!plan || plan->n_split == 0 || (plan->split_items && plan->split_ws && variant == 0), VGPT_ERR_INVALID,
-                 "vgpt_attn_fwd_plan: split items need their table and workspace");
     const int64_t n_wg = plan ? plan->n_items * n_heads : (int64_t)(a.nqb - a.qb0) * n_heads * B;
     a.trace = n_wg <= g_trace_cap ? g_trace : nullptr;
     hipStream_t s = (hipStream_t)stream;
@@ -627,11 +547,6 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
 #define ATTN_CASE(DD)                                                                     \
     case DD:                                                                              \
         rc = variant == 0 ? launch<DD, true>(a, s) : launch<DD, false>(a, s);             \
-        if (rc == VGPT_OK && plan && plan->n_split > 0) {                                 \
-            hipLaunchKernelGGL(attn_merge_kernel<DD>, dim3((unsigned)(plan->n_split * n_heads)), dim3(256), 0, s, \
-                               plan->split_ws, plan->split_items, a.o, a.lse, n_heads, a.L, a.o_sb, a.o_sh, a.o_ss); \
-            VGPT_CHECK_LAUNCH("vgpt_attn_fwd_plan (merge)");                                \
-        }                                                                                 \
         break;
     switch (head_dim) {
         ATTN_CASE(64) ATTN_CASE(96) ATTN_CASE(128)
@@ -678,12 +593,95 @@ VGPT_EXPORT int vgpt_attn_blockmask_fwd_qrange(const void* q, const void* k, con
                          q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, scale, 0, stream);
 }
 
-// 128-row items of a plan on the 4-wave kernel (called by vgpt_attn_fwd_plan, attn_fwd_pp.hip)
-int vgpt_attn_fwd_items128(const void* q, const void* k, const void* v, void* o, float* lse, const uint32_t* bits,
-                           const int32_t* items, const uint16_t* item_summary, const int32_t* order, int64_t n_items,
-                           const int32_t* split_items, int64_t n_split, float* split_ws, int64_t B, int64_t L, int n_heads,
-                           int n_kv_heads, int head_dim, const int64_t* st, float scale, void* stream) {
-    const ItemPlan plan = {items, item_summary, order, n_items, split_items, n_split, split_ws};
-    return attn_fwd_impl(q, k, v, o, lse, 0, bits, nullptr, nullptr, &plan, B, L, n_heads, n_kv_heads, head_dim, st[0], st[1],
-                         st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], scale, 0, stream);
+namespace {
+// ---- plan: per (item, key tile) summary and the longest-first order ----
+// block = 256 threads, one per row of an item (items hold at most 128 rows here); 2 bits per 32-row slab
+__global__ __launch_bounds__(256) void item_summary_kernel(const uint32_t* __restrict__ bits,
+                                                           const int32_t* __restrict__ items,
+                                                           uint16_t* __restrict__ isum, int L, int W, int nkt) {
+    __shared__ int codes[8];
+    const int kt = blockIdx.x, item = blockIdx.y;
+    const int b = items[4 * item], row0 = items[4 * item + 1], nrows = items[4 * item + 2];
+    const int i = threadIdx.x, lane = i & 63;
+    bool none = true, all = true;
+    if (i < nrows) {
+        const uint32_t* rowp = bits + ((int64_t)b * L + row0 + i) * W;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int w = 2 * kt + half, k0 = w * 32;
+            const uint32_t full = k0 + 32 <= L ? 0xffffffffu : 0u;  // a tile reaching past L is never "all visible"
+            const uint32_t word = w < W ? rowp[w] : 0u;
+            none = none && word == 0u;
+            all = all && word == 0xffffffffu && full == 0xffffffffu;
+        }
+    }
+    const uint64_t bn = __ballot(none), ba = __ballot(all);
+    if ((lane & 31) == 0) {
+        const uint32_t n32 = (uint32_t)(bn >> (lane & 32)), a32 = (uint32_t)(ba >> (lane & 32));
+        codes[i >> 5] = n32 == 0xffffffffu ? 0 : (a32 == 0xffffffffu ? 1 : 2);
+    }
+    __syncthreads();
+    if (i == 0) {
+        int c = 0;
+        for (int s = 0; s < 8; ++s) c |= codes[s] << (2 * s);
+        isum[(int64_t)item * nkt + kt] = (uint16_t)c;
+    }
+}
+
+constexpr int PLAN_SORT_MAX = 2048;
+__global__ void item_order_kernel(const int32_t* __restrict__ items, const uint16_t* __restrict__ isum, int n, int nkt,
+                                  int32_t* __restrict__ order) {
+    __shared__ int cnt[PLAN_SORT_MAX];
+    if (n > PLAN_SORT_MAX) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) order[i] = i;
+        return;
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint16_t* row = isum + (int64_t)i * nkt;
+        int c = 0;
+        for (int t = 0; t < nkt; ++t) c += row[t] != 0;
+        cnt[i] = c;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int ci = cnt[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (cnt[j] > ci) || (cnt[j] == ci && j < i);
+        order[rank] = i;
+    }
+}
+
+}  // namespace
+
+VGPT_EXPORT int64_t vgpt_attn_plan_workspace_bytes(int64_t L, int64_t n_items) {
+    if (L <= 0 || n_items < 0) return -1;
+    // item_summary (n_items x ceil(L/64) uint16), then the order (n_items int32), each rounded up to 256 bytes
+    const int64_t s = (n_items * cdiv(L, 64) * 2 + 255) / 256 * 256, o = (n_items * 4 + 255) / 256 * 256;
+    return s + o;
+}
+
+VGPT_EXPORT int vgpt_attn_plan_build(const uint32_t* bits, int64_t B, int64_t L, const int32_t* items, int64_t n_items,
+                                     uint16_t* item_summary, int32_t* order, void* stream) {
+    VGPT_REQUIRE(bits && items && item_summary && order, VGPT_ERR_INVALID, "vgpt_attn_plan_build: null pointer");
+    VGPT_REQUIRE(B > 0 && L > 0 && L <= (1 << 22) && n_items > 0 && n_items < 65536, VGPT_ERR_INVALID,
+                 "vgpt_attn_plan_build: bad shape");
+    const int nkt = (int)cdiv(L, 64);
+    hipLaunchKernelGGL(item_summary_kernel, dim3(nkt, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, bits, items,
+                       item_summary, (int)L, (int)cdiv(L, 32), nkt);
+    hipLaunchKernelGGL(item_order_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, items, item_summary, (int)n_items,
+                       nkt, order);
+    VGPT_CHECK_LAUNCH("vgpt_attn_plan_build");
+    return VGPT_OK;
+}
+
+VGPT_EXPORT int vgpt_attn_fwd_plan(const void* q, const void* k, const void* v, void* o, float* lse, const uint32_t* bits,
+                                   const int32_t* items, const uint16_t* item_summary, const int32_t* order,
+                                   int64_t n_items, int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim,
+                                   int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                                   int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
+                                   float scale, void* stream) {
+    VGPT_REQUIRE(items && item_summary && order, VGPT_ERR_INVALID, "vgpt_attn_fwd_plan: null pointer");
+    const ItemPlan plan = {items, item_summary, order, n_items};
+    return attn_fwd_impl(q, k, v, o, lse, 0, bits, nullptr, nullptr, &plan, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
+                         k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, scale, 0, stream);
 }

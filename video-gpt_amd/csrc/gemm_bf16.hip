@@ -413,11 +413,32 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         // Linear output rounded to bf16 (what the reference's qkv_proj returns), then q*cos + rotate_half(q)*sin in
         // fp32 and one more rounding -- the arithmetic of vgpt_rope_qk_inplace on the stored tensor, without the store
         // and reload.  N % 16 == 0 (checked on the host), so lane and lane ^ 32 are in range together.
+        // The cos / sin rows of this tile's BM tokens are first copied into the (now free) staging buffers with one
+        // coalesced LDS-DMA burst: read per lane from global memory they were 2 x MI x NI latency-bound 16-byte loads
+        // touching 16 cache lines each.
         const int half = g.head_dim >> 1;
+        const int tab_bytes = (BM * half * 4 + 1023) & ~1023;          // one table's rows of this tile, whole 1-KiB pieces
+        const bool staged = 2 * tab_bytes <= C::LDS_BYTES;
+        if (staged) {
+            __syncthreads();                                           // every wave has read its last fragments
+            const int64_t row0_bytes = (int64_t)m0 * half * 4;
+            // last readable 16 bytes of the table, relative to this tile's first row (rows past M are never used)
+            const uint32_t last = (uint32_t)min((int64_t)g.M * half * 4 - row0_bytes - 16, (int64_t)tab_bytes);
+            const char* cbase = reinterpret_cast<const char*>(g.rope_cos) + row0_bytes;
+            const char* sbase = reinterpret_cast<const char*>(g.rope_sin) + row0_bytes;
+            for (int pc = wave; pc * 1024 < tab_bytes; pc += C::NWAVES) {
+                const uint32_t off = min((uint32_t)(pc * 1024 + lane * 16), last);
+                glds16_asm(cbase, off, lds_base + (uint32_t)(pc * 1024));
+                glds16_asm(sbase, off, lds_base + (uint32_t)(tab_bytes + pc * 1024));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         const bool upper = (lane & 32) != 0;
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
-            const int m = m0 + wm * (MI * 16) + j * 16 + em;
+            const int ml = wm * (MI * 16) + j * 16 + em;
+            const int m = m0 + ml;
             if (m >= g.M) continue;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -428,8 +449,14 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                 bf16x4 o;
                 if (gs < g.rope_cols) {
                     const int d = (n % g.head_dim) - (upper ? half : 0);
-                    const f32x4 cs = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)m * half + d);
-                    const f32x4 sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)m * half + d);
+                    f32x4 cs, sn;
+                    if (staged) {
+                        cs = *reinterpret_cast<const f32x4*>(smem + (ml * half + d) * 4);
+                        sn = *reinterpret_cast<const f32x4*>(smem + tab_bytes + (ml * half + d) * 4);
+                    } else {
+                        cs = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)m * half + d);
+                        sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)m * half + d);
+                    }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const float own = bf2f(f2bf(v[t]));
@@ -523,26 +550,29 @@ int forced_tile() {
 // Launch plan of a big-tile GEMM: the big-tile kernel (one block per CU, so T tiles take ceil(T/256) rounds) gets either
 // everything or — when the last round would be badly filled — only the m-tile rows that make full rounds, and the
 // 128x128 kernel (2 blocks/CU, 4x smaller tiles) runs the remaining rows behind it.
+// Costs are in units of one 256-row big-tile ROUND.  A round takes the same time whatever the tile's width (1.57 us per
+// k-tile with 256 x 192 tiles against 1.62 with 256 x 256: the loop waits on its operand stream, not on the MFMAs), so a
+// narrower tile only pays where it removes a badly filled round; a round of the 128-tile kernel (512 tiles) measured at
+// 0.62 of a big round (46 us against 75-78 at K = 3072).
 struct BigPlan {
     int64_t rows_big;  // rows given to the big-tile kernel (M: no split)
-    double cost;       // estimated time in units of "one column of a 256-row tile round"
+    double cost;
 };
 BigPlan plan_big(int64_t M, int64_t n_out, int bn_out) {
     constexpr int CUS = 256;
+    const double round_cost = bn_out == 192 ? 0.97 : 1.0;
     const int64_t tiles_n = cdiv(n_out, bn_out), tiles_m = cdiv(M, 256), T = tiles_m * tiles_n;
     const int64_t full = T / CUS, rem = T % CUS;
-    // a round of the 128-tile kernel (512 tiles) measured at ~1.15x the time of half a 256x256 round
-    auto small = [&](int64_t rows) { return (double)cdiv(cdiv(rows, 128) * cdiv(n_out, 128), 2 * CUS) * 128.0 * 1.15; };
+    auto small = [&](int64_t rows) { return (double)cdiv(cdiv(rows, 128) * cdiv(n_out, 128), 2 * CUS) * 0.62; };
+    const double whole = (double)cdiv(T, CUS) * round_cost;
     if (full >= 1 && rem > 0 && rem < (CUS * 85) / 100) {
         const int64_t rows_big = (full * CUS) / tiles_n;
         if (rows_big >= 1 && rows_big < tiles_m) {
-            const double split = (double)cdiv(rows_big * tiles_n, CUS) * bn_out + small(M - rows_big * 256);
-            // whole rounds only when clearly cheaper: at 2 % (7740 x 16384: 8 rounds against 7 + remainder) the split
-            // measured 7 % faster, at 7 % (dW of qkv_proj: 2 rounds against 1 + remainder) the whole launch 3 % faster
-            if (split < 1.05 * (double)cdiv(T, CUS) * bn_out) return {rows_big * 256, split};
+            const double split = (double)cdiv(rows_big * tiles_n, CUS) * round_cost + small(M - rows_big * 256);
+            if (split < 0.97 * whole) return {rows_big * 256, split};
         }
     }
-    return {M, (double)cdiv(T, CUS) * bn_out};
+    return {M, whole};
 }
 
 template <int MODE, bool ATR = false, bool WTR = false>
@@ -564,7 +594,7 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
         // FLOP, so a small estimated gain is not taken)
         BigPlan p192 = plan_big(g.M, n_out, 192);
         if (f == 192) p192.rows_big = g.M;
-        use192 = f == 192 || (f == 0 && p192.cost < 0.93 * p256.cost);
+        use192 = f == 192 || (f == 0 && p192.cost < 0.985 * p256.cost);
         if (use192) p = p192;
     }
     auto big = [&](const GemmArgs& ga) {

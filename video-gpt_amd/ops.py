@@ -175,19 +175,14 @@ def gated_mlp_act(x: torch.Tensor, w_gate_up: torch.Tensor, act: int = ACT_SILU,
 # ---- attention --------------------------------------------------------------------------------
 
 class AttnPlan:
-    def __init__(self, items, summary, order, n_items, item_rows, split_items=None, split_rows=0):
-        self.items, self.summary, self.order, self.n_items, self.item_rows = items, summary, order, n_items, item_rows
-        self.split_items, self.split_rows = split_items, split_rows    # key-split slots; total (parts x 128) rows
-        self._ws = {}
+    """Work items of a planned attention launch: items (n,4) int32, and one workspace sized by
+    vgpt_attn_plan_workspace_bytes holding the per-(item, key tile) summary and the longest-first order."""
 
-    def workspace(self, n_heads: int, head_dim: int):
-        """fp32 scratch of the key-slice partials (include/vgpt.h): allocated once per (heads, head_dim)."""
-        if self.split_items is None:
-            return None
-        k = (n_heads, head_dim)
-        if k not in self._ws:
-            self._ws[k] = torch.empty(self.split_rows * n_heads * (head_dim + 4), dtype=F32, device=self.items.device)
-        return self._ws[k]
+    def __init__(self, items, summary, order, n_items):
+        self.items, self.summary, self.order, self.n_items = items, summary, order, n_items
+
+
+ITEM_ROWS = 128   # rows per work item of the planned forward kernel (four waves x 32 rows)
 
 
 class PackedMask:
@@ -198,16 +193,13 @@ class PackedMask:
         self._order = {}
         self._plans = {}
 
-    def plan(self, segments=None, item_rows: int = 128, split_keys: bool = False) -> "AttnPlan":
+    def plan(self, segments=None) -> "AttnPlan":
         """Work plan of the planned forward kernel (include/vgpt.h, vgpt_attn_plan_build) for the query rows of
         `segments` = ((batch, row_begin, row_end), ...); default: every row, one segment per batch item.  Each
-        segment is cut into items of item_rows (128: 4-wave kernel, 256: 8-wave head_dim-96 kernel) rows; cut
-        segments where packed sequences meet.  split_keys (128-row items, off by default): items whose visible key
-        tiles exceed 1.4x the shortest full item's are cut into key slices of about that length, merged by a second
-        kernel.  Measured on the cfg-2 layout it does not pay (the per-work-item overhead and the merge cost more than
-        the better balance returns: 230 vs 200 us per layer); it is there for masks with far more skewed key sets."""
+        segment is cut into items of ITEM_ROWS rows; cut segments where packed sequences meet so that no item straddles
+        two key sets."""
         skey = tuple(tuple(int(v) for v in s_) for s_ in segments) if segments is not None else None
-        key = (skey, item_rows, bool(split_keys))
+        key = skey
         p = self._plans.get(key)
         if p is None:
             segs = skey if skey is not None else tuple((b, 0, self.L) for b in range(self.B))
@@ -215,41 +207,23 @@ class PackedMask:
             for b, r0, r1 in segs:
                 if not (0 <= b < self.B and 0 <= r0 <= r1 <= self.L):
                     raise VgptError(f"attention plan: bad segment {(b, r0, r1)}")
-                items += [(b, r, min(item_rows, r1 - r), 0) for r in range(r0, r1, item_rows)]
+                items += [(b, r, min(ITEM_ROWS, r1 - r), 0) for r in range(r0, r1, ITEM_ROWS)]
             dev = self.bits.device
+            n_ = len(items)
+            it = torch.tensor(items, dtype=torch.int32).reshape(n_, 4).to(dev)
+            nbytes = int(_lib.load().vgpt_attn_plan_workspace_bytes(self.L, max(n_, 1)))
+            if nbytes < 0:
+                raise VgptError("vgpt_attn_plan_workspace_bytes: bad shape")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             nkt = (self.L + 63) // 64
-
-            def build(its):
-                n_ = len(its)
-                it_ = torch.tensor(its, dtype=torch.int32).reshape(n_, 4).to(dev)
-                summ_ = torch.empty(max(n_, 1), nkt, dtype=torch.int16, device=dev)
-                order_ = torch.empty(max(n_, 1), dtype=torch.int32, device=dev)
-                if n_:
-                    call("vgpt_attn_plan_build", self.bits.data_ptr(), self.B, self.L, it_.data_ptr(), n_, item_rows,
-                         summ_.data_ptr(), order_.data_ptr(), _stream())
-                return it_, summ_, order_
-            it, summ, order = build(items)
-            split_items, split_ws_floats = None, 0
-            if split_keys and item_rows == 128 and len(items) > 1 and nkt <= 1023:
-                counts = (summ[: len(items)] != 0).sum(1).cpu().tolist()          # one-time, per mask
-                full = [c for c, t in zip(counts, items) if t[2] == item_rows and c > 0]
-                if full:
-                    target = min(full)
-                    final, slots, pbase = [], [], 0
-                    for c, (b, r, nr, _) in zip(counts, items):
-                        nparts = min(int(-(-c // target)) if c >= 1.4 * target else 1, 8)
-                        if nparts > 1 and pbase + nparts < 32768:
-                            slots.append((b, r, nr, nparts | (pbase << 8)))
-                            final += [(b, r, nr, part | (nparts << 8) | (pbase << 16)) for part in range(nparts)]
-                            pbase += nparts
-                        else:
-                            final.append((b, r, nr, 0))
-                    if slots:
-                        items = final
-                        it, summ, order = build(items)
-                        split_items = torch.tensor(slots, dtype=torch.int32).reshape(len(slots), 4).to(dev)
-                        split_ws_floats = pbase * 128
-            p = self._plans[key] = AttnPlan(it, summ, order, len(items), item_rows, split_items, split_ws_floats)
+            s_bytes = (max(n_, 1) * nkt * 2 + 255) // 256 * 256
+            summ = ws[: max(n_, 1) * nkt * 2].view(torch.int16).view(max(n_, 1), nkt)
+            order = ws[s_bytes: s_bytes + max(n_, 1) * 4].view(torch.int32)
+            if n_:
+                call("vgpt_attn_plan_build", self.bits.data_ptr(), self.B, self.L, it.data_ptr(), n_,
+                     summ.data_ptr(), order.data_ptr(), _stream())
+            p = self._plans[key] = AttnPlan(it, summ, order, n_)
+            p.workspace = ws
         return p
 
     def order(self, q_start: int = 0) -> torch.Tensor:
@@ -332,9 +306,9 @@ def as_packed_mask(mask, device=None) -> PackedMask:
 
 
 def attention_qkv(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: int, head_dim: int,
-                  scale: Optional[float] = None, out: Optional[torch.Tensor] = None, variant: int = 0,
-                  split_keys: bool = False):
-    """Attention on the fused (B, L, (n_q+2n_kv)*hd) projection buffer (RoPE already applied)."""
+                  scale: Optional[float] = None, out: Optional[torch.Tensor] = None, variant: int = 0):
+    """Attention on the fused (B, L, (n_q+2n_kv)*hd) projection buffer (RoPE already applied).  variant 0: planned
+    launch; 2: aligned 128-row q blocks, longest first; 1: the slow V layout."""
     _chk(qkv, BF16, "attention.qkv")
     B, L, width = qkv.shape
     if width != (n_heads + 2 * n_kv_heads) * head_dim or B != pm.B or L != pm.L:
@@ -347,9 +321,9 @@ def attention_qkv(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: i
     kq = qkv.data_ptr() + n_heads * head_dim * es
     vq = kq + n_kv_heads * head_dim * es
     sb, ss = L * width, width
-    if variant in (0, 3):   # planned launch: 0 = 4-wave kernel on 128-row items, 3 = 8-wave kernel on 256-row items
+    if variant == 0:   # planned launch
         _attn_plan_call(qkv.data_ptr(), kq, vq, out.data_ptr(), None, pm,
-                        pm.plan(None, 256 if variant == 3 else 128, split_keys), B, L,
+                        pm.plan(None), B, L,
                         n_heads, n_kv_heads, head_dim,
                         (sb, head_dim, ss) * 3 + (L * n_heads * head_dim, head_dim, n_heads * head_dim), scale)
         return out
@@ -368,16 +342,13 @@ def attention_qkv(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: i
 
 def _attn_plan_call(q, k, v, o, lse, pm, plan, B, L, n_heads, n_kv_heads, head_dim, strides, scale):
     if plan.n_items:
-        ws = plan.workspace(n_heads, head_dim)
         call("vgpt_attn_fwd_plan", q, k, v, o, lse, pm.bits.data_ptr(), plan.items.data_ptr(), plan.summary.data_ptr(),
-             plan.order.data_ptr(), plan.n_items, plan.item_rows, _ptr(plan.split_items),
-             0 if plan.split_items is None else plan.split_items.shape[0], _ptr(ws), B, L, n_heads, n_kv_heads, head_dim,
+             plan.order.data_ptr(), plan.n_items, B, L, n_heads, n_kv_heads, head_dim,
              *strides, float(scale), _stream())
 
 
 def attention_qkv_range(qkv_full: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: int, head_dim: int,
-                        q_start: int, out_active: torch.Tensor, scale: Optional[float] = None, segments=None,
-                        item_rows: int = 128, split_keys: bool = False):
+                        q_start: int, out_active: torch.Tensor, scale: Optional[float] = None, segments=None):
     """Attention of query rows [q_start, L) against all L rows of the fused (1, L, 3H-like) buffer; `out_active`
     holds the L - q_start computed rows (condition-prefix reuse, see include/vgpt.h).  segments: optional
     ((0, row_begin, row_end), ...) covering [q_start, L), cut where packed sequences meet."""
@@ -391,7 +362,7 @@ def attention_qkv_range(qkv_full: torch.Tensor, pm: PackedMask, n_heads: int, n_
     kq = qkv_full.data_ptr() + hq * 2
     vq = kq + n_kv_heads * head_dim * 2
     o_base = out_active.data_ptr() - q_start * hq * 2   # absolute-row addressing of the active output buffer
-    plan = pm.plan(segments if segments is not None else ((0, q_start, L),), item_rows, split_keys)
+    plan = pm.plan(segments if segments is not None else ((0, q_start, L),))
     _attn_plan_call(qkv_full.data_ptr(), kq, vq, o_base, None, pm, plan, 1, L, n_heads, n_kv_heads, head_dim,
                     (L * width, head_dim, width) * 3 + (L * hq, head_dim, hq), scale)
     return out_active
@@ -417,9 +388,9 @@ def sdpa(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attn_mask=
     out = torch.empty(B, Hq, S, d, dtype=BF16, device=query.device)
     if scale is None:
         scale = 1.0 / math.sqrt(d)
-    if variant in (0, 3):
+    if variant == 0:
         _attn_plan_call(query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(), None, pm,
-                        pm.plan(None, 256 if variant == 3 else 128), B, S, Hq, Hkv,
+                        pm.plan(None), B, S, Hq, Hkv,
                         d, (query.stride(0), query.stride(1), query.stride(2), key.stride(0), key.stride(1), key.stride(2),
                             value.stride(0), value.stride(1), value.stride(2), out.stride(0), out.stride(1), out.stride(2)),
                         scale)
