@@ -134,49 +134,54 @@ def bench_pipeline(args, rank, world, device, M, P, D):
         torch.distributed.destroy_process_group()
 
 
-def bench_vae(args, rank, world, device, D):
-    """VAE decode / encode of 256^2 frames (sdxl-vae architecture, fp32 like the reference), 8 frames per step.
-    Algorithmic work per 256^2 frame: decode 0.622 TFLOP / 1.68 GB fp32 ideal-fusion traffic,
-    encode 0.273 TFLOP / 0.97 GB."""
-    V = importlib.import_module("video-gpt_amd.vae")
-    vae = V.AutoencoderKL()
+def measure_vae(steps, warmup, device, D, precision="bf16x3", nfr=8, world=1):
+    """VAE decode (+uint8) and encode of `nfr` 256^2 frames per step (sdxl-vae architecture, fp32 tensors like the
+    reference, LVM/pipeline.py:558-590 / 60-68).  Algorithmic work per 256^2 frame: decode 0.622 TFLOP /
+    1.68 GB fp32 ideal-fusion traffic, encode 0.273 TFLOP / 0.97 GB.  The 3x3 convolutions dominate; with
+    conv_precision "bf16x3" (default) each fp32 product is three bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the
+    matrix pipe ISSUES 3x the algorithmic FLOPs: priced against the dense bf16 peak; "fp32" uses the fp32-input MFMA
+    (157.3 TFLOP/s peak)."""
+    vae = synthetic_vae(device)
+    vae.conv_precision = precision
     g = torch.Generator("cpu").manual_seed(0)
-    with torch.no_grad():
-        for p_ in vae.parameters():
-            if p_.dim() > 1:
-                fan = p_[0].numel()
-                p_.copy_(torch.randn(p_.shape, generator=g) / fan ** 0.5)
-            else:
-                p_.copy_(1 + 0.05 * torch.randn(p_.shape, generator=g) if p_.shape[0] > 8 and "norm" in "" else 0.02 * torch.randn(p_.shape, generator=g))
-        for n_, p_ in vae.named_parameters():
-            if ("norm" in n_) and n_.endswith("weight"):
-                p_.copy_(1 + 0.1 * torch.randn(p_.shape, generator=g))
-    vae = vae.to(device, torch.float32).eval()
-    vae.conv_precision = args.vae_precision
-    nfr = 8
     z = torch.randn(nfr, 4, 32, 32, generator=g).to(device)
     x = (torch.rand(nfr, 3, 256, 256, generator=g) * 2 - 1).to(device)
-    res = {}
+    issued, peak, kern = (3.0, 2500.0, "conv_bx3_kernel (3x3 conv as implicit GEMM, 3 bf16 MFMA products per fp32 product)") \
+        if precision == "bf16x3" else (1.0, 157.3, "conv_kernel (3x3 conv as implicit GEMM on the fp32-input MFMA)")
+    res = {"conv_precision": precision, "frames_per_step": nfr, "kernel": kern}
     for name, fn, tf, gb in (("decode", lambda: vae.decode_to_uint8(z), 0.622, 1.68), ("encode", lambda: vae.encode(x), 0.273, 0.97)):
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             fn()
 
         def run():
-            for _ in range(args.steps):
+            for _ in range(steps):
                 fn()
         el = D.timed_region(run, torch.cuda.synchronize, device)
-        per_frame = el / args.steps / nfr
+        per_frame = el / steps / nfr
         res[name] = {"ms_per_frame": round(per_frame * 1e3, 3), "frames_per_s": round(world / per_frame, 1),
-                     "mfma_fp32": {"achieved_tflops": round(tf / per_frame, 1), "peak": 157.3, "frac": round(tf / per_frame / 157.3, 4)},
-                     "hbm_ideal_fusion": {"achieved_gbs": round(gb / per_frame, 1), "peak": 8000.0, "frac": round(gb / per_frame / 8000.0, 4)}}
+                     "mfma": {"alg_tflop_per_frame": tf, "issued_tflop_per_frame": round(issued * tf, 3),
+                              "achieved_issued_tflops": round(issued * tf / per_frame, 1), "peak": peak,
+                              "frac": round(issued * tf / per_frame / peak, 4),
+                              "alg_frac": round(tf / per_frame / peak, 4)},
+                     "hbm_ideal_fusion": {"gb_per_frame": gb, "achieved_gbs": round(gb / per_frame, 1), "peak": 8000.0,
+                                          "frac": round(gb / per_frame / 8000.0, 4)}}
+    return res
+
+
+def bench_vae(args, rank, world, device, D):
+    res = measure_vae(args.steps, args.warmup, device, D, args.vae_precision, world=world)
     if rank == 0:
         d = res["decode"]
+        nfr = res["frames_per_step"]
         print(json.dumps({"metric": f"VAE decode frames/sec (256^2, sdxl-vae, fp32 tensors, {args.vae_precision} convolutions)", "value": d["frames_per_s"], "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(d["ms_per_frame"] * nfr, 3),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32 (bf16x3 products)" if args.vae_precision == "bf16x3" else "f32", "data": "synthetic",
                           "config": {"workload": f"VAE decode+uint8 of {nfr} 256^2 frames per step (also encode)", "detail": res},
-                          "roofline": {"bound": "mfma", "kernel": "conv_kernel (fp32 MFMA implicit GEMM)", "achieved": d["mfma_fp32"]["achieved_tflops"],
-                                       "peak": 157.3, "unit": "TFLOP/s", "frac": d["mfma_fp32"]["frac"], "traffic": None,
+                          "roofline": {"bound": "mfma", "kernel": res["kernel"], "achieved": d["mfma"]["achieved_issued_tflops"],
+                                       "peak": d["mfma"]["peak"], "unit": "TFLOP/s", "frac": d["mfma"]["frac"], "traffic": None,
+                                       "note": "issued MFMA FLOPs (3x algorithmic for bf16x3) against the dense peak of the MFMA used; "
+                                               "alg_frac in config.detail prices the algorithmic FLOPs",
                                        "hbm_view": d["hbm_ideal_fusion"]}}), flush=True)
     if world > 1:
         D.barrier()
@@ -185,6 +190,8 @@ def bench_vae(args, rank, world, device, D):
 
 def bench_stage1(args, rank, world, device, M, P, D, ops):
     line = measure_stage1(args.steps, args.warmup, args.layers, rank, world, device, M, P, D)
+    if args.rehearse_on_one_gpu:
+        line["config"]["workload"] += " [REHEARSAL: ranks share one GPU over gloo: INVALID]"
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -243,6 +250,35 @@ def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=No
                 "roofline": {"bound": "mfma", "kernel": "whole step (fwd + bwd ~ 3 x fwd FLOPs)", "achieved": round(3 * fwd / (ms * 1e-3) / 1e12, 1),
                              "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(3 * fwd / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                              "traffic": None, "alg_tflop_per_step": round(3 * fwd / 1e12, 1)}}
+    # ---- data-parallel runs: how much of the gradient all-reduce is exposed.  Two more short legs AFTER the measurement
+    #      above: the same steps with the all-reduce skipped (the ranks' weights drift apart: timing only), and the
+    #      buckets reduced back to back with nothing to overlap with ----
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        trainer.skip_allreduce = True
+        trainer.step(batch, x1, x0, t, clean, x0i, ti)
+
+        def run_nocomm():
+            for _ in range(steps):
+                trainer.step(batch, x1, x0, t, clean, x0i, ti)
+        ms_nocomm = D.timed_region(run_nocomm, torch.cuda.synchronize, device) / max(steps, 1) * 1e3
+        trainer.skip_allreduce = False
+        buckets = list(trainer.layer_buckets) + [trainer.small_bucket]
+
+        def run_comm():
+            for _ in range(steps):
+                hs = [dist.all_reduce(b, async_op=True) for b in buckets]
+                for h in hs:
+                    h.wait()
+        run_comm()
+        ms_comm = D.timed_region(run_comm, torch.cuda.synchronize, device) / max(steps, 1) * 1e3
+        nbytes = sum(b.numel() * b.element_size() for b in buckets)
+        comm = {"ms_per_step_without_allreduce": round(ms_nocomm, 2), "exposed_ms_per_step": round(ms - ms_nocomm, 2),
+                "allreduce_alone_ms": round(ms_comm, 2), "allreduce_bytes_per_step": nbytes, "buckets": len(buckets),
+                "allreduce_alone_busbw_gbs": round(2 * (world - 1) / world * nbytes / (ms_comm * 1e-3) / 1e9, 1),
+                "hidden_frac": round(max(0.0, 1.0 - (ms - ms_nocomm) / ms_comm), 3) if ms_comm > 0 else None}
+    line["comm"] = comm
     del trainer
     return line
 
@@ -257,6 +293,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-stage1", action="store_true",
                     help="skip the short stage-1 data-parallel training measurement appended to the default line")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="debug only: all ranks share cuda:0 and talk over gloo (numbers are INVALID as a benchmark)")
+    ap.add_argument("--no-vae", action="store_true", help="infer workload: skip the VAE decode / encode leg of the JSON line")
     ap.add_argument("--no-prefix-reuse", action="store_true",
                     help="recompute the condition frames at every step exactly as the reference does")
     ap.add_argument("--no-hoist", action="store_true",
@@ -277,11 +316,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if args.rehearse_on_one_gpu:   # every rank on cuda:0, gloo collectives: exercises the N > 1 code path on a 1-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     importlib.import_module("video-gpt_amd")
     D = importlib.import_module("video-gpt_amd.dist_utils")
-    D.init_from_env("nccl", device)
+    D.init_from_env("gloo" if args.rehearse_on_one_gpu else "nccl", device)
     M = importlib.import_module("video-gpt_amd.model")
     P = importlib.import_module("video-gpt_amd.processor")
     E = importlib.import_module("video-gpt_amd.engine")
@@ -483,8 +524,16 @@ def main():
             stage1 = {k: s1[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup")}
             stage1["config"] = s1["config"]
             stage1["roofline"] = s1["roofline"]
+            stage1["comm"] = s1.get("comm")
         except Exception as e:  # keep the headline line even if the training leg fails
             stage1 = {"error": repr(e)[:300]}
+    # ---- the round's other stage (LVM/pipeline.py:558-590): VAE decode / encode per 256^2 frame, 5 steps of 8 frames ----
+    vae_obj = None
+    if not args.no_vae:
+        try:
+            vae_obj = measure_vae(5, 2, device, D, args.vae_precision, world=world)
+        except Exception as e:
+            vae_obj = {"error": repr(e)[:300]}
     if rank == 0:
         line = {"metric": "denoised clip-tokens/sec (256^2, 8-frame next-clip, CFG, x1)", "value": round(value, 1),
                 "unit": "clip-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -500,7 +549,7 @@ def main():
                            "per_clip_setup_ms": round(setup_s * 1e3, 2),
                            "ms_per_step_of_a_50_step_clip": round(((elapsed - setup_s) / max(args.steps, 1) * 50 + setup_s) / 50 * 1e3, 3),
                            "finite": finite},
-                "roofline": roof, "stage1_train": stage1}
+                "roofline": roof, "stage1_train": stage1, "vae": vae_obj}
         if breakdown:
             line["breakdown_ms_per_step"] = breakdown
         if not args.no_cpu_baseline and world == 1:

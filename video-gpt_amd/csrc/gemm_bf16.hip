@@ -558,12 +558,19 @@ struct BigPlan {
     int64_t rows_big;  // rows given to the big-tile kernel (M: no split)
     double cost;
 };
-BigPlan plan_big(int64_t M, int64_t n_out, int bn_out) {
+// Cost of a launch plan in units of one k-tile of a 256x256 workgroup tile.  Measured at M = 4096 over K = 1024 .. 8192
+// (scripts/gemm_k_sweep.py): a round of 256x256 tiles takes 1.0 per k-tile, a round of 256x192 tiles 0.77 (its 48 instead
+// of 64 MFMAs per wave), and every round pays about 7 more for its prologue and epilogue (nothing overlaps them with one
+// workgroup per CU); a round of the 128x128 kernel (two workgroups per CU) runs 0.62 of a 256x256 round.
+BigPlan plan_big(int64_t M, int64_t n_out, int bn_out, int64_t nk) {
     constexpr int CUS = 256;
-    const double round_cost = bn_out == 192 ? 0.97 : 1.0;
+    constexpr double FIXED = 7.0;
+    const double round_cost = (bn_out == 192 ? 0.77 : 1.0) * (double)nk + FIXED;
     const int64_t tiles_n = cdiv(n_out, bn_out), tiles_m = cdiv(M, 256), T = tiles_m * tiles_n;
     const int64_t full = T / CUS, rem = T % CUS;
-    auto small = [&](int64_t rows) { return (double)cdiv(cdiv(rows, 128) * cdiv(n_out, 128), 2 * CUS) * 0.62; };
+    auto small = [&](int64_t rows) {
+        return (double)cdiv(cdiv(rows, 128) * cdiv(n_out, 128), 2 * CUS) * 0.62 * ((double)nk + FIXED);
+    };
     const double whole = (double)cdiv(T, CUS) * round_cost;
     if (full >= 1 && rem > 0 && rem < (CUS * 85) / 100) {
         const int64_t rows_big = (full * CUS) / tiles_n;
@@ -585,14 +592,14 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const bool use256 = f == 256 || f == 257 || f == 192 || (f != 128 && big_tiles >= 128);
     if (!use256) return launch_cfg<MODE, Cfg128, false, ATR, WTR>(g, n_out, s, name);
     if (f == 257) return launch_cfg<MODE, Cfg256, false, ATR, WTR>(g, n_out, s, name);
-    BigPlan p256 = plan_big(g.M, n_out, MODE == MODE_GATED ? 128 : 256);
+    const int64_t nk = cdiv(g.K, BK);
+    BigPlan p256 = plan_big(g.M, n_out, MODE == MODE_GATED ? 128 : 256, nk);
     if (f == 256) p256.rows_big = g.M;
     bool use192 = false;
     BigPlan p = p256;
     if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
-        // 256 x 192 tiles when their rounds fit the problem clearly better (its loop moves ~15 % more operand bytes per
-        // FLOP, so a small estimated gain is not taken)
-        BigPlan p192 = plan_big(g.M, n_out, 192);
+        // 256 x 192 tiles when their rounds fit the problem better
+        BigPlan p192 = plan_big(g.M, n_out, 192, nk);
         if (f == 192) p192.rows_big = g.M;
         use192 = f == 192 || (f == 0 && p192.cost < 0.985 * p256.cost);
         if (use192) p = p192;

@@ -58,6 +58,7 @@ class Stage1Trainer:
         self.dev = model.llm.norm.weight.device
         self.step_count = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.skip_allreduce = False   # measurement only (bench.py's exposed-communication leg): ranks stop agreeing when set
         self.params = {n: p for n, p in model.named_parameters()}
         self._ws = {}
         self.last = {}
@@ -296,7 +297,7 @@ class Stage1Trainer:
             T.rmsnorm_bwd(hbuf[li], layer.input_layernorm.weight, dn, dh,
                           g[f"llm.layers.{li}.input_layernorm.weight"], layer.input_layernorm.variance_epsilon,
                           dres=dh_b)                                                     # dh (layer input)
-            if self.world > 1:
+            if self.world > 1 and not self.skip_allreduce:
                 handles.append(dist.all_reduce(self.layer_buckets[li], async_op=True))
         # heads fed by dseq = dh
         dseq = dh
@@ -306,7 +307,7 @@ class Stage1Trainer:
         if cl is not None:
             self._patch_bwd("input_x_embedder", T.gather_rows(dseq, prep["c_rows"], ntok), cl)
         T.embed_bwd(prep["ids"].view(-1), prep["keep"], dseq, g["llm.embed_tokens.weight"])
-        if self.world > 1:
+        if self.world > 1 and not self.skip_allreduce:
             handles.append(dist.all_reduce(self.small_bucket, async_op=True))
             for hd_ in handles:
                 hd_.wait()
