@@ -108,6 +108,7 @@ def bench_pipeline(args, rank, world, device, M, P, D):
     model = build_model(M, cfg, device, seed=0)
     pipe = PL.LVMPipeline(synthetic_vae(device), model, P.LVMProcessor(P.SpecialTokenizer(10, 11, 12)), device=device)
     pipe.vae.conv_precision = args.vae_precision
+    pipe.attention_precision = args.attn_precision
     g = torch.Generator("cpu").manual_seed(7 + rank)
     frames = [torch.rand(3, 256, 256, generator=g) * 2 - 1 for _ in range(4)]
     kw = dict(input_images=frames, height=256, width=256, num_inference_steps=args.steps, use_img_guidance=True,
@@ -124,9 +125,11 @@ def bench_pipeline(args, rank, world, device, M, P, D):
         print(json.dumps({"metric": "end-to-end denoised clip-tokens/sec incl. VAE encode/decode (256^2, 8-frame next-clip, CFG, x1)",
                           "value": round(world * n_gen * 256 * args.steps / elapsed, 1), "unit": "clip-tokens/s", "n_gpus": world,
                           "steps": args.rounds, "warmup": 1, "ms_per_step": round(elapsed / args.rounds * 1e3, 1),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "bf16" if args.attn_precision == "bf16" else "bf16 (attention operands MX-fp8 e4m3)", "data": "synthetic",
                           "config": {"workload": f"LVMPipeline next-clip rollout: {args.rounds} round(s) x 8 frames, {args.steps} Euler steps, "
-                                                 f"C=4 condition frames on round 0 then a 16-frame window, fp32 VAE ({args.vae_precision} convolutions), bf16 denoiser",
+                                                 f"C=4 condition frames on round 0 then a 16-frame window, fp32 VAE ({args.vae_precision} convolutions), bf16 denoiser"
+                                                 + (" with MX-fp8 attention in the sampler steps" if args.attn_precision == "fp8" else ""),
                                      "frames_returned": len(out[0]), "generated_frames_per_s": round(world * n_gen / elapsed, 2)},
                           "roofline": None}), flush=True)
     if world > 1:
@@ -293,6 +296,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-stage1", action="store_true",
                     help="skip the short stage-1 data-parallel training measurement appended to the default line")
+    ap.add_argument("--attn-precision", choices=["bf16", "fp8"], default="bf16",
+                    help="infer / pipeline workloads: operands of the sampler steps' attention (fp8 = the cfg-5 option; "
+                         "the headline metric is quoted on bf16)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug only: all ranks share cuda:0 and talk over gloo (numbers are INVALID as a benchmark)")
     ap.add_argument("--no-vae", action="store_true", help="infer workload: skip the VAE decode / encode leg of the JSON line")
@@ -364,7 +370,7 @@ def main():
                            batch["attention_mask"], cond, batch["input_image_sizes"],
                            batch["denoise_image_sizes"], batch["time_emb_inx"], len(z), hw, True, 1.6, "x1",
                            sigma=sched.sigma, reuse_condition_prefix=not args.no_prefix_reuse,
-                           hoist_special_rows=not args.no_hoist)
+                           hoist_special_rows=not args.no_hoist, attention_precision=args.attn_precision)
 
     B, L = batch["input_ids"].shape
     valid = batch["input_ids"] != 2
@@ -538,12 +544,13 @@ def main():
         line = {"metric": "denoised clip-tokens/sec (256^2, 8-frame next-clip, CFG, x1)", "value": round(value, 1),
                 "unit": "clip-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "vs_baseline": None, "dtype": "bf16" if args.attn_precision == "bf16" else "bf16 (attention operands MX-fp8 e4m3)",
+                "data": "synthetic",
                 "config": {"workload": "cfg-2 single-GPU inference: 256^2, C=4 cond + G=8 gen frames, CFG (B=2, L=3096, "
                                        f"{real_tokens} real tokens), Phi-3-mini-class denoiser {nl} layers, x1 prediction, "
                                        "hipGraph sampler step" + ("" if nl == 32 else " [DEBUG layer count: INVALID]"),
                            "global_batch": world, "parallelism": f"replicas x{world}", "graph": use_graph,
-                           "condition_prefix_reuse": reuse, "special_row_hoisting": hoisted,
+                           "condition_prefix_reuse": reuse, "special_row_hoisting": hoisted, "attention_precision": args.attn_precision,
                            "tokens_computed_per_step": rows_per_step,
                            "tokens_counted_per_step": real_tokens_step,
                            "per_clip_setup_ms": round(setup_s * 1e3, 2),

@@ -70,8 +70,14 @@ class StaticDenoiser:
     def __init__(self, model, input_ids, position_ids, attention_mask, input_img_latents, input_image_sizes,
                  denoise_image_sizes, time_emb_inx, n_frames: int, latent_hw, use_img_cfg: bool, img_cfg_scale: float,
                  prediction_type: str = "v", sigma: Optional[torch.Tensor] = None, pack_padding: bool = True,
-                 reuse_condition_prefix: bool = False, hoist_special_rows: bool = True):
+                 reuse_condition_prefix: bool = False, hoist_special_rows: bool = True,
+                 attention_precision: str = "bf16"):
         model._check_ready()
+        if attention_precision not in ("bf16", "fp8"):
+            raise VgptError(f"StaticDenoiser: attention_precision must be 'bf16' or 'fp8' (got {attention_precision!r})")
+        # "fp8": the per-step attention of the sampler runs on MX-fp8 operands (csrc/attn_fp8.hip; the cfg-5 option of
+        # SURVEY.md §8d).  The per-clip passes (prefill, time rows) stay bf16.
+        self.attn_fp8 = attention_precision == "fp8"
         self.model = model
         cfg = model.llm.config
         self.cfg = cfg
@@ -454,10 +460,16 @@ class StaticDenoiser:
                 full = self.qkv_full[li_]
                 live = full[S:]                                  # this step's q/k/v rows, behind the cached prefix
                 ops.linear_qkv_rope(self.nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=live)
-                ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, S, self.ctx, segments=self.seg_live)
+                if self.attn_fp8:
+                    ops.attention_qkv_fp8(full.view(1, self.L, -1), self.pm, nq, nk, hd, out=self.ctx, q_start=S,
+                                          segments=self.seg_live)
+                else:
+                    ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, S, self.ctx, segments=self.seg_live)
             else:
                 ops.linear_qkv_rope(self.nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=self.qkv)
-                if self.seg_all is not None:
+                if self.attn_fp8:
+                    ops.attention_qkv_fp8(self.qkv, self.pm, nq, nk, hd, out=self.ctx, segments=self.seg_all)
+                elif self.seg_all is not None:
                     ops.attention_qkv_range(self.qkv, self.pm, nq, nk, hd, 0, self.ctx, segments=self.seg_all)
                 else:
                     ops.attention_qkv(self.qkv, self.pm, nq, nk, hd, out=self.ctx)

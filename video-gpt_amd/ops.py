@@ -368,6 +368,45 @@ def attention_qkv_range(qkv_full: torch.Tensor, pm: PackedMask, n_heads: int, n_
     return out_active
 
 
+_FP8_WS = {}
+
+
+def attention_qkv_fp8(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: int, head_dim: int,
+                      scale: Optional[float] = None, out: Optional[torch.Tensor] = None, q_start: int = 0, segments=None):
+    """MX-fp8 attention (include/vgpt.h, vgpt_attn_fp8_quantize + vgpt_attn_fwd_plan_fp8) on the fused
+    (B, L, (n_q + 2 n_kv) * hd) projection buffer (RoPE applied): rows [q_start, L) of `segments` (default: all of
+    them) against all L keys.  `out` holds rows [q_start, L).  Inference only; tolerance of fp8 operands."""
+    _chk(qkv, BF16, "attention.qkv")
+    B, L, width = qkv.shape
+    if width != (n_heads + 2 * n_kv_heads) * head_dim or B != pm.B or L != pm.L:
+        raise VgptError("attention_fp8: qkv / mask shape mismatch")
+    if q_start and B != 1:
+        raise VgptError("attention_fp8: q_start needs the packed single-row layout")
+    hq = n_heads * head_dim
+    if out is None:
+        out = torch.empty(B, L - q_start, hq, dtype=BF16, device=qkv.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(head_dim)
+    nbytes = int(_lib.load().vgpt_attn_fp8_workspace_bytes(B, L, n_heads, n_kv_heads, head_dim))
+    if nbytes < 0:
+        raise VgptError(f"attention_fp8: unsupported shape (head_dim {head_dim}: the fp8 kernel is built for 96)")
+    key = (qkv.device, nbytes)
+    ws = _FP8_WS.get(key)
+    if ws is None:
+        ws = _FP8_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+    kq = qkv.data_ptr() + hq * 2
+    vq = kq + n_kv_heads * head_dim * 2
+    sb, ss = L * width, width
+    call("vgpt_attn_fp8_quantize", qkv.data_ptr(), kq, vq, ws.data_ptr(), B, L, n_heads, n_kv_heads, head_dim,
+         sb, head_dim, ss, sb, head_dim, ss, sb, head_dim, ss, float(scale), _stream())
+    plan = pm.plan(segments if segments is not None else (tuple((b, q_start, L) for b in range(B))))
+    if plan.n_items:
+        call("vgpt_attn_fwd_plan_fp8", ws.data_ptr(), out.data_ptr() - q_start * hq * 2, pm.bits.data_ptr(),
+             plan.items.data_ptr(), plan.summary.data_ptr(), plan.order.data_ptr(), plan.n_items, B, L, n_heads, n_kv_heads,
+             head_dim, (L - q_start) * hq if B > 1 else L * hq, head_dim, hq, _stream())
+    return out
+
+
 def sdpa(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attn_mask=None, dropout_p: float = 0.0,
          is_causal: bool = False, scale: Optional[float] = None, variant: int = 0):
     """Drop-in for the `local_attn` slot (F.scaled_dot_product_attention) on (B, heads, S, d) tensors.

@@ -40,6 +40,7 @@ class LVMPipeline:
         self.model_cpu_offload = False
         self.last_latents = None
         self.mask_format = "layout"   # "bool": have the collator paint the reference's dense (B,L,L) mask instead
+        self.attention_precision = "bf16"   # "fp8": MX-fp8 attention in the sampler steps (scheduler.LVMScheduler)
 
     @classmethod
     def from_pretrained(cls, model_name, vae_path: str = None, load_llm_ckpt=True):
@@ -163,6 +164,7 @@ class LVMPipeline:
                                 img_cfg_scale=img_guidance_scale, use_img_cfg=use_img_guidance, use_kv_cache=use_kv_cache,
                                 offload_model=False)
             scheduler = LVMScheduler(num_steps=num_inference_steps, time_shifting_factor=time_shifting_factor)
+            scheduler.attention_precision = self.attention_precision
             samples = scheduler(latents, self.model.forward_with_cfg, model_kwargs, use_kv_cache=use_kv_cache,
                                 offload_kv_cache=offload_kv_cache, prediction_type=prediction_type, vae=self.vae)
             samples = samples.chunk(1 + num_cfg, dim=0)[0]
@@ -254,6 +256,7 @@ class LVMPipeline:
                 img_cfg_scale=img_guidance_scale, use_img_cfg=use_img_guidance, use_kv_cache=use_kv_cache,
                 offload_model=False, vae=self.vae)
             scheduler = LVMScheduler(num_steps=num_inference_steps, time_shifting_factor=time_shifting_factor)
+            scheduler.attention_precision = self.attention_precision
             samples = scheduler(latents, self.model.frame_block_forward_with_cfg, model_kwargs,
                                 use_kv_cache=use_kv_cache, offload_kv_cache=offload_kv_cache,
                                 prediction_type=prediction_type, vae=self.vae)

@@ -34,6 +34,7 @@ class LVMScheduler:
         self.pack_padding = True
         self.reuse_condition_prefix = True   # compute the step-invariant condition rows once per clip (engine.py)
         self.hoist_special_rows = True       # ... and the <|diffusion|> / time rows of all steps in one pass (needs a TokenLayout mask)
+        self.attention_precision = "bf16"    # "fp8": MX-fp8 attention in the sampler steps of the fast path (cfg-5 option)
         self.last_engine = None
 
     # ---- fast path ----
@@ -58,7 +59,8 @@ class LVMScheduler:
                               tuple(z[0].shape[-2:]), model_kwargs["use_img_cfg"], model_kwargs["img_cfg_scale"],
                               prediction_type, sigma=self.sigma, pack_padding=self.pack_padding,
                               reuse_condition_prefix=self.reuse_condition_prefix,
-                              hoist_special_rows=self.hoist_special_rows)
+                              hoist_special_rows=self.hoist_special_rows,
+                              attention_precision=self.attention_precision)
 
     def __call__(self, z, func, model_kwargs, use_kv_cache: bool = True, offload_kv_cache: bool = True,
                  prediction_type: str = "v", vae=None, noise_level=None):
