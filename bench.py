@@ -77,7 +77,25 @@ def cpu_baseline(cfg_full, batch, layers_sample=2):
         R.transformer(p, oc, x, batch["attention_mask"], batch["position_ids"])
         dt = time.perf_counter() - t0
     step_s = dt * cfg_full.num_hidden_layers / layers_sample
-    return {"value": 8 * 256 / step_s, "unit": "clip-tokens/s", "cores": threads, "kind": "port",
+    # cfg-1 of BASELINE.json (4 condition frames, ONE denoise step, CPU fp32, VAE included): the VAE restatement
+    # (oracle/vae_ref.py, sdxl-vae configuration) timed on one 256^2 frame each way, composed with the step above
+    from oracle import vae_ref as VR
+    vc = VR.VaeCfg()
+    vp = VR.make_vae_params(vc, seed=0)
+    gen = torch.Generator("cpu").manual_seed(2)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        VR.vae_encode(vp, vc, torch.rand(1, 3, 256, 256, generator=gen) * 2 - 1, torch.randn(1, 4, 32, 32, generator=gen))
+        enc_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        VR.decode_to_uint8(vp, vc, torch.randn(1, 4, 32, 32, generator=gen))
+        dec_s = time.perf_counter() - t0
+    cfg1 = {"vae_encode_s_per_frame": round(enc_s, 3), "vae_decode_s_per_frame": round(dec_s, 3),
+            "denoise_step_s": round(step_s, 1),
+            "round_s": round(4 * enc_s + step_s + 8 * dec_s, 1),
+            "what": "cfg-1 shape (4 condition frames encoded, 1 denoise step of the 8-frame clip with CFG, 8 frames decoded), "
+                    "fp32 on the host cores: measured pieces composed, the step scaled from the layer sample"}
+    return {"value": 8 * 256 / step_s, "unit": "clip-tokens/s", "cores": threads, "kind": "port", "cfg1_cpu_round": cfg1,
             "sample": f"{layers_sample} of {cfg_full.num_hidden_layers} decoder layers (fp32, torch CPU) over the full "
                       f"B=2 x L={L} cfg-2 sequence took {dt:.2f}s; scaled x{cfg_full.num_hidden_layers // layers_sample} "
                       "to one denoise step (embedders/final layer/Euler update are <0.1% and omitted)"}
@@ -462,7 +480,7 @@ def main():
         achieved = alg / t_gemm / 1e12
         traffic = None  # per-launch bytes beyond L2 of that kernel from the committed PMC passes (scripts/pmc_traffic.py)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v3.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 recs = [(rec["launches"], rec["traffic_bytes_per_launch"]) for name, rec in json.load(f)["kernels"].items()
                         if "gemm_bf16_kernel<0" in name and "TileCfg<256" in name]
                 if recs:
@@ -471,7 +489,7 @@ def main():
             traffic = None
         mfma_busy = None  # matrix-pipe busy fraction of that kernel from the committed SQ counter pass (scripts/pmc_mfma.py)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_mfma.json")) as f:
                 recs = [(rec["launches"], rec["mfma_busy_frac"]) for name, rec in json.load(f)["kernels"].items()
                         if "gemm_bf16_kernel<0" in name and "TileCfg<256" in name]
                 if recs:
@@ -551,6 +569,10 @@ def main():
                                        "hipGraph sampler step" + ("" if nl == 32 else " [DEBUG layer count: INVALID]"),
                            "global_batch": world, "parallelism": f"replicas x{world}", "graph": use_graph,
                            "condition_prefix_reuse": reuse, "special_row_hoisting": hoisted, "attention_precision": args.attn_precision,
+                           "counting_note": "value counts the clip's 8 x 256 image tokens per step; the roofline's algorithmic FLOPs are "
+                                            "those of tokens_counted_per_step rows although a hoisted step computes "
+                                            "tokens_computed_per_step and the per-clip passes (timed) cover the special rows of "
+                                            "warmup + steps steps: an over-count of about 0.25 %",
                            "tokens_computed_per_step": rows_per_step,
                            "tokens_counted_per_step": real_tokens_step,
                            "per_clip_setup_ms": round(setup_s * 1e3, 2),

@@ -348,7 +348,9 @@ int vgpt_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* d
 /* C[m][n] = alpha * sum_k A[m*sa_m + k*sa_k] * B[k*sb_k + n*sb_n] (+ C); *_f32: 0 = bf16, 1 = fp32.  For the
  * small heads (patch embeds, timestep MLPs, adaLN, final Linear) whose backward is not worth an MFMA kernel.
  * splitk_ws (NULL or ws_floats floats): workspace that lets long reductions with few outputs be sliced over the chip
- * (slices are added in a fixed order: deterministic). */
+ * (slices are added in a fixed order: deterministic).  vgpt_matmul_generic_workspace_bytes(M, N, K) is the size with which
+ * a problem gets all the slices it can use (0: it runs unsliced); a smaller workspace means fewer slices. */
+int64_t vgpt_matmul_generic_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int vgpt_matmul_generic(const void* A, int a_f32, int64_t sa_m, int64_t sa_k, const void* B, int b_f32, int64_t sb_k,
                         int64_t sb_n, void* C, int c_f32, int64_t sc_m, int64_t sc_n, int64_t M, int64_t N, int64_t K,
                         float alpha, int accumulate, float* splitk_ws, int64_t ws_floats, void* stream);

@@ -181,3 +181,18 @@ def test_hoist_plan_permutation_matches_dense_permutation():
     # a layout whose tail is not whole noisy frames is refused
     bad = {0: batch["denoise_image_sizes"][0][:-1], 1: batch["denoise_image_sizes"][1]}
     assert E.StaticDenoiser._hoist_plan(lay, S0, lay.L, row_of, bad, batch["time_emb_inx"]) is None
+
+
+def test_left_pads_are_not_inferred_from_rows_that_merely_see_everything():
+    """Leading all-ones rows are padding only in the collator's pattern (the first real row masks the pad columns,
+    LVM/processor.py:722-727): a caller's full bidirectional mask, or a mask whose first real rows see everything, keeps
+    every token."""
+    L = 6
+    assert E.count_left_pads(torch.ones(2, L, L, dtype=torch.bool)) == [0, 0]
+    m = torch.ones(1, L, L, dtype=torch.bool)
+    m[0, 3:, :] = torch.tril(torch.ones(3, L, dtype=torch.bool), diagonal=3)   # rows 0..2 all ones, row 3 still sees cols 0..2
+    assert E.count_left_pads(m) == [0]
+    ref = torch.zeros(1, L, L, dtype=torch.bool)                               # the collator's pattern: 2 pad rows
+    ref[0, :2] = True
+    ref[0, 2:, 2:] = torch.tril(torch.ones(4, 4, dtype=torch.bool))
+    assert E.count_left_pads(ref) == [2]

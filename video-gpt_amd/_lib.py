@@ -83,6 +83,7 @@ SIGNATURES = {
     "vgpt_act_fwd": (c_int, [_P, _P, _I64, c_int, _P]),
     "vgpt_act_bwd": (c_int, [_P, _P, _P, _I64, c_int, _P]),
     "vgpt_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, c_float, _P]),
+    "vgpt_matmul_generic_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "vgpt_matmul_generic": (c_int, [_P, c_int, _I64, _I64, _P, c_int, _I64, _I64, _P, c_int, _I64, _I64, _I64, _I64,
                                     _I64, c_float, c_int, _P, _I64, _P]),
     "vgpt_colsum": (c_int, [_P, c_int, _P, _I64, _I64, _I64, c_int, _P]),

@@ -672,6 +672,18 @@ VGPT_EXPORT int vgpt_rmsnorm_bwd(const void* x, const void* w, const void* dy, c
     LAUNCH_OK("vgpt_rmsnorm_bwd");
 }
 
+// slices the split-K form would use with an unlimited workspace (0: the problem runs unsliced)
+static int64_t matmul_splits_wanted(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K < 512 || M * N > (1 << 18)) return 0;
+    const int64_t splits = std::min<int64_t>({(int64_t)64, K / 64, cdiv((int64_t)256 * 1024, M * N)});
+    return splits >= 2 ? splits : 0;
+}
+
+VGPT_EXPORT int64_t vgpt_matmul_generic_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M < 0 || N < 0 || K < 0) return -1;
+    return matmul_splits_wanted(M, N, K) * M * N * (int64_t)sizeof(float);
+}
+
 VGPT_EXPORT int vgpt_matmul_generic(const void* A, int a_f32, int64_t sa_m, int64_t sa_k, const void* B, int b_f32,
                                     int64_t sb_k, int64_t sb_n, void* C, int c_f32, int64_t sc_m, int64_t sc_n,
                                     int64_t M, int64_t N, int64_t K, float alpha, int accumulate, float* splitk_ws,
@@ -682,8 +694,8 @@ VGPT_EXPORT int vgpt_matmul_generic(const void* A, int a_f32, int64_t sa_m, int6
     dim3 grid((unsigned)cdiv(M * N, 256));
     hipStream_t s = (hipStream_t)stream;
     // long reduction, few outputs: slice K so that the grid fills the chip
-    if (splitk_ws && K >= 512 && M * N <= (1 << 18)) {
-        int64_t splits = std::min<int64_t>({(int64_t)64, K / 64, ws_floats / (M * N), cdiv((int64_t)256 * 1024, M * N)});
+    if (splitk_ws && matmul_splits_wanted(M, N, K)) {
+        int64_t splits = std::min<int64_t>(matmul_splits_wanted(M, N, K), ws_floats / (M * N));
         if (splits >= 2) {
             const int kc = (int)cdiv(K, splits);
             splits = cdiv(K, kc);

@@ -38,8 +38,15 @@ def count_left_pads(attention_mask) -> List[int]:
     B, L, _ = attention_mask.shape
     if L <= 1:
         return [0] * B
-    lead = torch.cumprod(attention_mask.to(torch.bool).all(-1).to(torch.int64), dim=1).sum(1)
-    return [int(v) for v in lead.tolist()]
+    mb = attention_mask.to(torch.bool)
+    lead = [int(v) for v in torch.cumprod(mb.all(-1).to(torch.int64), dim=1).sum(1).tolist()]
+    # leading all-ones rows are padding only in the collator's pattern, where the first real row does not see the pad
+    # columns (LVM/processor.py:722-727).  A mask whose first rows simply see everything (a caller's full bidirectional
+    # mask) has no padding: packing it would drop real tokens.
+    for b, n in enumerate(lead):
+        if n and (n >= L or bool(mb[b, n, :n].any())):
+            lead[b] = 0
+    return lead
 
 
 def pack_left_padded(input_ids, position_ids, attention_mask, pads: List[int]):

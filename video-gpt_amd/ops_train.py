@@ -8,6 +8,7 @@ from typing import Optional
 
 import torch
 
+from . import _lib
 from .ops import BF16, VgptError, _chk, _ptr, _stream, call, linear
 
 F32 = torch.float32
@@ -120,9 +121,11 @@ def matmul(a, b, out=None, ta=False, tb=False, alpha=1.0, accumulate=False, out_
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
     sa_m, sa_k = (a.stride(1), a.stride(0)) if ta else (a.stride(0), a.stride(1))
     sb_k, sb_n = (b.stride(1), b.stride(0)) if tb else (b.stride(0), b.stride(1))
+    # split-K reduction slices: sized by the C ABI's own query (include/vgpt.h), grown on demand, shared per device
+    need = int(_lib.load().vgpt_matmul_generic_workspace_bytes(M, N, K)) // 4
     ws = _splitk_ws.get(a.device)
-    if ws is None:
-        ws = _splitk_ws[a.device] = torch.empty(4 << 20, dtype=F32, device=a.device)   # 16 MiB of reduction slices
+    if ws is None or ws.numel() < need:
+        ws = _splitk_ws[a.device] = torch.empty(max(need, 1 << 18), dtype=F32, device=a.device)
     call("vgpt_matmul_generic", a.data_ptr(), _f32flag(a), sa_m, sa_k, b.data_ptr(), _f32flag(b), sb_k, sb_n,
          out.data_ptr(), _f32flag(out), out.stride(0), out.stride(1), M, N, K, float(alpha), int(accumulate),
          ws.data_ptr(), ws.numel(), _stream())
