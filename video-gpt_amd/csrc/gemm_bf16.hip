@@ -27,8 +27,17 @@
 #ifndef VGPT_GEMM_SETPRIO
 #define VGPT_GEMM_SETPRIO 0
 #endif
+// 1: the big-tile NT launches use the two-group ("ping-pong") loop (PIPE == 2 below) instead of the 4-phase loop.
+// EXPERIMENT, not compiled into the product (make gemm-variant-VGPT_GEMM_PP): parity-green, and with the LDS-DMA left out
+// 8 % faster than the 4-phase loop without its DMA (61.6 vs 67.5 us for 4096 x 3072 x 3072), but 20-25 % SLOWER with it
+// (97 vs 79 us; 230 vs 194 at K = 8192; 372 vs 330 for gate_up) wherever the issues are placed and with or without the
+// counted waits: an LDS-DMA issue blocks its wave for 60-185 cycles, and under strict alternation nobody fills the matrix
+// pipe meanwhile -- the free-running 4-phase loop lets the partner wave's MFMAs cover it.
+#ifndef VGPT_GEMM_PP
+#define VGPT_GEMM_PP 0
+#endif
 // Diagnostics build (make gemm-debug-N, results are garbage): 1 = skip the LDS-DMA staging, 2 = skip the LDS fragment
-// reads, 3 = both.  A COMPILE-time switch: as a run-time flag the skipped reads became conditional, and at the join
+// reads, 3 = both, 4 = skip the epilogue.  A COMPILE-time switch: as a run-time flag the skipped reads became conditional, and at the join
 // hipcc's s_waitcnt insertion assumes the shorter path — every MFMA phase then waited for the fragment reads issued
 // right in front of it (lgkmcnt(3..0) instead of (7..4)), exposing the LDS latency twice per k-tile.
 #ifndef VGPT_GEMM_DEBUG_BUILD
@@ -144,7 +153,7 @@ constexpr bool getenv_prio = VGPT_GEMM_SETPRIO;
 // its natural [64 reduction rows][256 columns] layout and its MFMA fragments come from ds_read_b64_tr_b16; the
 // 32-byte units of a row are XOR-swizzled with ((row>>3)&1)<<2 | (row&3) (on the DMA source address and on the
 // read) so that the 8 rows x 32 B a half-wave reads transposed hit 64 different banks.
-template <int MODE, typename C, bool PIPE, bool ATR = false, bool WTR = false>
+template <int MODE, typename C, int PIPE, bool ATR = false, bool WTR = false>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     static_assert(!(ATR || WTR) || MODE == MODE_PLAIN, "transposed operands: plain kernel only");
     constexpr bool ROPE = MODE == MODE_ROPE;
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     };
 
     const int nk = (g.K + BK - 1) / BK;  // a partial last k-tile exists only with transposed operands (zero rows)
-    if constexpr (!PIPE) {
+    if constexpr (PIPE == 0) {
         // one barrier per k-tile: wait for tile kt, issue tile kt+1's DMA, compute tile kt
         stage(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -305,6 +314,206 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
             }
         }
+    } else if constexpr (PIPE == 2) {
+        // Two wave groups in alternation ("ping-pong"): the four waves of tile row 0 and the four of tile row 1 sit one
+        // per SIMD each; while one group runs a cluster of 16 (or 8) MFMAs at raised priority the other reads fragments
+        // from LDS and issues LDS-DMA, and every hand-over is a workgroup barrier (group 1 runs one barrier behind).
+        // A k-tile is four phases = the four quadrants of the wave tile, (m0,n0) (m0,n1) (m1,n1) (m1,n0), each over the
+        // whole K = 64.  The tile lives in LDS as four 16-KiB half-tile images that die one per phase -- W.n0 after the
+        // fragment reads of phase 4 of the tile before (its fragments wait in registers), A.m0 after phase 1, W.n1 after
+        // phase 2, A.m1 after phase 3 -- and each is re-staged with the data of two tiles ahead three phases after its
+        // last read, five to six phases before its first: W.n1(t+1) in phase 1, A.m1(t+1) in 2, W.n0(t+2) in 3,
+        // A.m0(t+2) in 4.  Every phase issues exactly two LDS-DMA instructions (dummies into a scratch area where the
+        // schedule has nothing to fetch), so `s_waitcnt vmcnt(6)` at the end of a phase's load part always means "all
+        // but the last three half-tiles have landed" -- what the NEXT phase reads -- and nothing ever drains.
+        static_assert(!ATR && !WTR && MI == 8 && (NI == 4 || NI == 3), "ping-pong loop: NT operands, 2x4-wave tiles");
+        constexpr int HT = 16384;
+        constexpr int STRIDE = C::A_BYTES + C::W_BYTES;
+        constexpr int AM0 = 0, AM1 = HT, WN0 = 2 * HT, WN1 = 3 * HT;
+        const uint32_t scratch = lds_base + 2 * STRIDE + wave * 2048;
+        auto a_row_off = [&](int r_local) {
+            const int r = min(r_local, g.M - 1 - m0);
+            return (uint32_t)(r * (int)g.lda + schunk * 8) * 2u;
+        };
+        auto w_row_off = [&](int r) {
+            int wr;
+            if constexpr (ROPE) wr = min(rope_col_of_slot(n0 + r, g.rope_cols, g.head_dim), n_rows_w - 1);
+            else wr = min(w_row_of_slot<MODE>(n0, r, g.I), n_rows_w - 1) - (MODE == MODE_GATED ? 0 : n0);
+            return (uint32_t)(wr * (int)g.ldw + schunk * 8) * 2u;
+        };
+        // this wave stages pieces `wave` and `wave + 8` (8 rows x 128 B each) of every half-tile
+        uint32_t oA[2][2], oW0[2], oW1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int lr = (wave + 8 * u) * 8 + srow;   // row inside the 128-row half-tile image
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) oA[mh][u] = a_row_off((lr >> 6) * 128 + mh * 64 + (lr & 63));
+            oW0[u] = w_row_off((lr >> 5) * (NI * 16) + (lr & 31));
+            if constexpr (NI == 4) oW1[u] = w_row_off((lr >> 5) * 64 + 32 + (lr & 31));
+            else oW1[u] = u == 0 ? w_row_off((lr >> 4) * 48 + 32 + (lr & 15)) : 0u;   // 64-row image: pieces 0..7 only
+        }
+        auto dummy = [&]() {
+            if constexpr ((kDebug & 1) == 0) glds16_asm(a_org, oA[0][0], scratch);
+        };
+        // one of the two pieces (u) this wave stages of a half-tile; past the last k-tile a dummy keeps the count uniform
+        auto stage_a = [&](int buf, int kt, int mh, int u) {
+            if constexpr ((kDebug & 1) != 0) return;
+            if (kt < nk) glds16_asm(a_org + kt * a_step, oA[mh][u], lds_base + (uint32_t)(buf * STRIDE + (mh ? AM1 : AM0) + (wave + 8 * u) * 1024));
+            else dummy();
+        };
+        auto stage_w0 = [&](int buf, int kt, int u) {
+            if constexpr ((kDebug & 1) != 0) return;
+            if (kt < nk) glds16_asm(w_org + kt * w_step, oW0[u], lds_base + (uint32_t)(buf * STRIDE + WN0 + (wave + 8 * u) * 1024));
+            else dummy();
+        };
+        auto stage_w1 = [&](int buf, int kt, int u) {
+            if constexpr ((kDebug & 1) != 0) return;
+            if (kt < nk && (NI == 4 || u == 0)) glds16_asm(w_org + kt * w_step, oW1[u], lds_base + (uint32_t)(buf * STRIDE + WN1 + (wave + 8 * u) * 1024));
+            else dummy();
+        };
+        constexpr int NI1 = NI - 2;   // n sub-tiles of the second n half
+        bf16x8 W0[2][2], W0n[2][2], W1[NI1][2], Af[4][2];   // [sub-tile][k-step]
+        const int a_rd = (wm * 64 + frow) * 128, w0_rd = (wn * 32 + frow) * 128, w1_rd = (wn * (NI1 * 16) + frow) * 128;
+        auto rd = [&](const char* img, int sub, int ks) {
+            return *reinterpret_cast<const bf16x8*>(img + sub * 2048 + ((ks * 4 + fk) ^ sw) * 16);
+        };
+        auto load_end = [&]() {   // end of a phase's load part
+            if constexpr ((kDebug & 16) == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mma_end = [&]() {
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+        };
+
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_w0(0, 0, u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_a(0, 0, 0, u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_w1(0, 0, u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_a(0, 0, 1, u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_w0(1, 1, u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_a(1, 1, 0, u);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W.n0 and A.m0 of tile 0 have landed
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) W0n[i][ks] = rd(smem + WN0 + w0_rd, i, ks);
+        if (wm == 1) {   // the stagger: group 1 runs one barrier behind group 0
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            const char* tb = smem + buf * STRIDE;
+            // ---- phase 1: quadrant (m0, n0) ----
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) W0[i][ks] = W0n[i][ks];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) Af[j][ks] = rd(tb + AM0 + a_rd, j, ks);
+            load_end();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W0[i][ks], Af[j][ks], acc[i][j], 0, 0, 0);
+                // the LDS-DMA of this phase goes out under the cluster: its issue (~60 cycles each) would otherwise
+                // lengthen the load part, which the other group's cluster has to cover
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) stage_w1(buf ^ 1, kt + 1, 0); else stage_w1(buf ^ 1, kt + 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma_end();
+            // ---- phase 2: (m0, n1) ----
+#pragma unroll
+            for (int i = 0; i < NI1; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) W1[i][ks] = rd(tb + WN1 + w1_rd, i, ks);
+            load_end();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < NI1; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W1[i][ks], Af[j][ks], acc[2 + i][j], 0, 0, 0);
+                // the LDS-DMA of this phase goes out under the cluster: its issue (~60 cycles each) would otherwise
+                // lengthen the load part, which the other group's cluster has to cover
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) stage_a(buf ^ 1, kt + 1, 1, 0); else stage_a(buf ^ 1, kt + 1, 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma_end();
+            // ---- phase 3: (m1, n1) ----
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) Af[j][ks] = rd(tb + AM1 + a_rd, j, ks);
+            load_end();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < NI1; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W1[i][ks], Af[j][ks], acc[2 + i][4 + j], 0, 0, 0);
+                // the LDS-DMA of this phase goes out under the cluster: its issue (~60 cycles each) would otherwise
+                // lengthen the load part, which the other group's cluster has to cover
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) stage_w0(buf, kt + 2, 0); else stage_w0(buf, kt + 2, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma_end();
+            // ---- phase 4: (m1, n0); the W.n0 fragments of the next tile are fetched here ----
+            if (kt + 1 < nk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) W0n[i][ks] = rd(smem + (buf ^ 1) * STRIDE + WN0 + w0_rd, i, ks);
+            }
+            load_end();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W0[i][ks], Af[j][ks], acc[i][4 + j], 0, 0, 0);
+                // the LDS-DMA of this phase goes out under the cluster: its issue (~60 cycles each) would otherwise
+                // lengthen the load part, which the other group's cluster has to cover
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) stage_a(buf, kt + 2, 0, 0); else stage_a(buf, kt + 2, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma_end();
+        }
+        if (wm == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummies of the last phases
     } else {
         // Software-pipelined 4-phase loop (256x256 tile, wave tile 128(m) x 64(n)).  A k-tile is four
         // phases of 16 MFMAs: (ks0,m-half0) (ks0,m-half1) (ks1,m-half0) (ks1,m-half1).  The fragments
@@ -407,6 +616,15 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         }
     }
 
+    if constexpr ((kDebug & 4) != 0) {   // diagnostics: no epilogue (one store keeps the accumulators alive)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sum == 12345.678f) g.C[0] = f2bf(sum);
+        return;
+    }
     // ---- epilogue: lane holds m = lane&15, n = (lane>>4)*4 + reg of each 16x16 sub-tile ----
     const int em = lane & 15, en = (lane >> 4) * 4;
     if constexpr (ROPE) {
@@ -516,12 +734,12 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
-template <int MODE, typename C, bool PIPE, bool ATR = false, bool WTR = false>
+template <int MODE, typename C, int PIPE, bool ATR = false, bool WTR = false>
 int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + (PIPE == 2 ? 16384 : 0));
         if (e != hipSuccess) {
             vgpt_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return VGPT_ERR_HIP;
@@ -531,7 +749,7 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     g.tiles_m = (int)cdiv(g.M, C::BM);
     g.tiles_n = (int)cdiv(n_out, MODE == MODE_GATED ? C::BN / 2 : C::BN);
     hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>), dim3(g.tiles_m * g.tiles_n), dim3(C::THREADS),
-                       C::LDS_BYTES, s, g);
+                       C::LDS_BYTES + (PIPE == 2 ? 16384 : 0), s, g);
     VGPT_CHECK_LAUNCH(name);
     return VGPT_OK;
 }
@@ -590,8 +808,8 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const int64_t tiles_m = cdiv(g.M, 256);
     const int64_t big_tiles = tiles_m * tiles_n;
     const bool use256 = f == 256 || f == 257 || f == 192 || (f != 128 && big_tiles >= 128);
-    if (!use256) return launch_cfg<MODE, Cfg128, false, ATR, WTR>(g, n_out, s, name);
-    if (f == 257) return launch_cfg<MODE, Cfg256, false, ATR, WTR>(g, n_out, s, name);
+    if (!use256) return launch_cfg<MODE, Cfg128, 0, ATR, WTR>(g, n_out, s, name);
+    if (f == 257) return launch_cfg<MODE, Cfg256, 0, ATR, WTR>(g, n_out, s, name);
     const int64_t nk = cdiv(g.K, BK);
     BigPlan p256 = plan_big(g.M, n_out, MODE == MODE_GATED ? 128 : 256, nk);
     if (f == 256) p256.rows_big = g.M;
@@ -606,9 +824,12 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     }
     auto big = [&](const GemmArgs& ga) {
         if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
-            if (use192) return launch_cfg<MODE, Cfg192, true, ATR, WTR>(ga, n_out, s, name);
+            if (use192) return launch_cfg<MODE, Cfg192, (VGPT_GEMM_PP ? 2 : 1), ATR, WTR>(ga, n_out, s, name);
         }
-        return launch_cfg<MODE, Cfg256, true, ATR, WTR>(ga, n_out, s, name);
+        if constexpr (!ATR && !WTR && VGPT_GEMM_PP) {
+            if (ga.K >= 2 * BK) return launch_cfg<MODE, Cfg256, 2, ATR, WTR>(ga, n_out, s, name);
+        }
+        return launch_cfg<MODE, Cfg256, 1, ATR, WTR>(ga, n_out, s, name);
     };
     if (p.rows_big >= g.M) return big(g);
     GemmArgs g1 = g, g2 = g;
@@ -624,7 +845,7 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     }
     int rc = big(g1);
     if (rc != VGPT_OK) return rc;
-    return launch_cfg<MODE, Cfg128, false, ATR, WTR>(g2, n_out, s, name);
+    return launch_cfg<MODE, Cfg128, 0, ATR, WTR>(g2, n_out, s, name);
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
