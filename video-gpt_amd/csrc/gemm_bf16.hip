@@ -37,7 +37,7 @@
 #define VGPT_GEMM_PP 0
 #endif
 // Diagnostics build (make gemm-debug-N, results are garbage): 1 = skip the LDS-DMA staging, 2 = skip the LDS fragment
-// reads, 3 = both, 4 = skip the epilogue.  A COMPILE-time switch: as a run-time flag the skipped reads became conditional, and at the join
+// reads, 3 = both, 4 = skip the epilogue, 16 = no wait for the LDS-DMA (what the per-tile drain costs).  A COMPILE-time switch: as a run-time flag the skipped reads became conditional, and at the join
 // hipcc's s_waitcnt insertion assumes the shorter path — every MFMA phase then waited for the fragment reads issued
 // right in front of it (lgkmcnt(3..0) instead of (7..4)), exposing the LDS latency twice per k-tile.
 #ifndef VGPT_GEMM_DEBUG_BUILD
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             // phase 4: (ks1, m-half 1) — every wave has its last fragments of this tile in registers and
             // its share of tile kt+1 has landed: after the barrier buffer `buf` is free for tile kt+2
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr ((kDebug & 16) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // 16: timing without the drain
             __syncthreads();
             if (kt + 2 < nk) stage_half(buf, kt + 2, 0);
             if (kt + 1 < nk) {

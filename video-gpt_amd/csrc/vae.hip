@@ -154,21 +154,27 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 // (torch.backends.cudnn.allow_tf32).  Three v_mfma_f32_16x16x32_bf16 (16 cycles each) replace eight
 // v_mfma_f32_16x16x4_f32 (32 cycles each) per 32 reduction elements.
 //
-// K order inside a chunk of 32 input channels: k = tap * 32 + channel, so one MFMA k-step is ONE tap and a lane's 8
-// consecutive k are 8 consecutive channels: with the patch stored [py][px][channel] and the (pre-split, pre-ordered)
-// weights stored [co][tap][channel], both fragments are single ds_read_b128 per hi / lo plane.  Pixel rows are 96 B
-// and weight rows 608 B apart (24 mod 64 dwords): the 16-lane b128 groups read conflict-free.
-// Same tile (64 output channels x 4 x 32 pixels, 4 waves), same GroupNorm(+SiLU) / upsample prologue and
-// bias + residual epilogue as conv_kernel.
-constexpr int BX_CK = 32, BX_PH = TH + 2, BX_PW = TW + 2;
-constexpr int BX_PSTRIDE = 96;                       // bytes per pixel in one patch plane (64 used)
-constexpr int BX_WROW = (9 * BX_CK + 16) * 2;         // bytes per output channel in one weight plane (576 used)
+// Tile: 64 output channels x (8 rows x 32 pixels), four waves of two rows (acc 4 x 4 sub-tiles); the reduction runs in
+// chunks of 16 input channels.  K order inside a chunk: k = tap * 16 + channel with TEN tap slots (the tenth is zero
+// weights), so one MFMA k-step (32) is two taps x 16 channels and a lane's 8 consecutive k are 8 consecutive channels
+// of ONE tap: with the patch stored [py][px][channel] and the (pre-split, pre-ordered) weights stored
+// [co][tap slot][channel], both fragments are single ds_read_b128 per hi / lo plane.  Pixel rows are 48 B and weight
+// rows 336 B apart (12 and 84 dwords: the 16-lane b128 groups read conflict-free).
+// What the shape buys over the first version (4 x 32 pixels, 32-channel chunks, 76-KiB weight image per chunk and
+// workgroup: 88 B/clk/CU of LDS-DMA at the matrix pipe's rate -- several times what a CU can take in; one workgroup per
+// CU, so nothing covered its GroupNorm / SiLU / split pass either): the weight image is 44 KiB per 2 x the MFMAs
+// (11 B/clk/CU), and at 78 KiB of LDS two workgroups share a CU, one's staging under the other's MFMAs.
+// Same GroupNorm(+SiLU) / upsample prologue and bias + residual epilogue as conv_kernel.
+constexpr int BX_TH = 8;                             // rows of a tile (TW = 32 pixels, TCO = 64 channels as above)
+constexpr int BX_CK = 16, BX_TAPS = 10, BX_PH = BX_TH + 2, BX_PW = TW + 2;
+constexpr int BX_PSTRIDE = 48;                       // bytes per pixel in one patch plane (32 used)
+constexpr int BX_WROW = (BX_TAPS * BX_CK + 8) * 2;   // bytes per output channel in one weight plane (320 used)
 constexpr int BX_P_BYTES = BX_PH * BX_PW * BX_PSTRIDE, BX_W_BYTES = TCO * BX_WROW;
-
-constexpr int BX_IMG = 2 * BX_W_BYTES;               // one (co tile, channel chunk) weight image: hi plane, lo plane
-constexpr int BX_GN_OFF = 2 * (BX_P_BYTES + BX_W_BYTES), BX_GN_MAX = 1024;   // per-channel GroupNorm scale / shift table
-constexpr int BX_LDS_TOTAL = BX_GN_OFF + 2 * BX_GN_MAX * 4;
-static_assert(BX_IMG % 4096 == 0, "weight image must split into whole 1-KiB pieces per wave");
+constexpr int BX_IMG = 44 * 1024;                    // one (co tile, channel chunk) weight image: hi plane, lo plane, padding
+constexpr int BX_GN_OFF = BX_IMG + 2 * BX_P_BYTES;   // scale / shift of the chunk's 16 channels
+constexpr int BX_LDS_TOTAL = BX_GN_OFF + 2 * BX_CK * 4;
+static_assert(2 * BX_W_BYTES <= BX_IMG && BX_IMG % 4096 == 0, "weight image must split into whole 1-KiB pieces per wave");
+static_assert(2 * BX_LDS_TOTAL <= 160 * 1024, "two workgroups per CU");
 
 struct ConvBxArgs {
     const float* x; const char* wimg; const float* bias; const float* resid;
@@ -188,47 +194,38 @@ __device__ __forceinline__ void bx_glds16(const char* base, uint32_t voffset, ui
         : "memory");
 }
 
-// Per chunk of 32 input channels:  [barrier]  raw patch values (prefetched into registers under the previous chunk's
-// MFMAs) -> GroupNorm/SiLU/split -> LDS;  the pre-packed weight image of the chunk arrives meanwhile by LDS-DMA;
-// [vmcnt(0), barrier]  issue the raw patch loads of the NEXT chunk;  9 taps x 24 MFMAs.
-__global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
+// Per chunk of 16 input channels:  [barrier]  the chunk's weight image goes out by LDS-DMA;  raw patch values
+// (prefetched into registers under the previous chunk's MFMAs) -> GroupNorm/SiLU/split -> LDS;  [vmcnt(0), barrier]
+// issue the raw patch loads of the NEXT chunk;  5 k-steps x 48 MFMAs.
+__global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvBxArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sWh = smem;
     char* sWl = sWh + BX_W_BYTES;
-    char* sPh = sWl + BX_W_BYTES;
+    char* sPh = smem + BX_IMG;
     char* sPl = sPh + BX_P_BYTES;
-    float* sGN = reinterpret_cast<float*>(smem + BX_GN_OFF);   // [scale Cin][shift Cin]
+    float* sGN = reinterpret_cast<float*>(smem + BX_GN_OFF);   // [scale 16][shift 16] of the current chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y; bid /= a.tiles_y;
     const int tco = bid % a.tiles_co;
     const int n = bid / a.tiles_co;
-    const int co0 = tco * TCO, oy0 = ty * TH, ox0 = tx * TW;
+    const int co0 = tco * TCO, oy0 = ty * BX_TH, ox0 = tx * TW;
     const int Hv = a.Hin << a.upsample, Wv = a.Win << a.upsample;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const float* xn = a.x + (int64_t)n * a.Cin * a.Hin * a.Win;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    const int cpg = a.gn_groups ? a.Cin / a.gn_groups : 1;
 
-    if (a.gn_groups) {   // GroupNorm as one FMA per element: scale = rstd * gamma, shift = beta - mean * scale
-        const int cpg = a.Cin / a.gn_groups;
-        for (int ci = tid; ci < a.Cin; ci += 256) {
-            const float* st = a.gn_stats + ((int64_t)n * a.gn_groups + ci / cpg) * 2;
-            const float sc = st[1] * a.gn_gamma[ci];
-            sGN[ci] = sc;
-            sGN[BX_GN_MAX + ci] = a.gn_beta[ci] - st[0] * sc;
-        }
-    }
-
-    f32x4 acc[4][2];
+    f32x4 acc[4][4];   // [co sub-tile][2 * row + pixel half]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kq = lane >> 4, l16 = lane & 15;
 
-    // staging item = (pixel of the 6 x 34 patch, group of 8 channels); 816 items over 256 threads: 4 per thread
-    constexpr int NPIX = BX_PH * BX_PW, ITEMS = NPIX * 4, PER_T = (ITEMS + 255) / 256;
+    // staging item = (pixel of the 10 x 34 patch, group of 8 channels); 680 items over 256 threads: 3 per thread
+    constexpr int NPIX = BX_PH * BX_PW, ITEMS = NPIX * 2, PER_T = (ITEMS + 255) / 256;
     float praw[PER_T][8];
     int64_t pofs[PER_T];   // element offset of channel 0 of the chunk at this item's pixel, -1 = outside the image
 #pragma unroll
@@ -253,6 +250,13 @@ __global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
     };
     load_raw(0);
     const char* wimg = a.wimg + (int64_t)tco * a.nch * BX_IMG;
+    // patch offset of a lane's tap in k-step s: tap = 2 s + (kq >> 1) (the zero tenth slot reads the ninth tap's pixels)
+    int tap_off[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int t = min(2 * s + (kq >> 1), 8);
+        tap_off[s] = ((t / 3) * BX_PW + t % 3) * BX_PSTRIDE + (kq & 1) * 16;
+    }
 
     for (int c = 0; c < a.nch; ++c) {
         const int c0 = c * BX_CK;
@@ -261,8 +265,8 @@ __global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
         for (int it = 0; it < PER_T; ++it)
 #pragma unroll
             for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(praw[it][j]));
-        __syncthreads();   // every wave is done reading the previous chunk's LDS images (and sGN is written)
-        // ---- weight image of this chunk: 76 KiB, 19 x 1-KiB pieces per wave, straight into its LDS layout ----
+        __syncthreads();   // every wave is done reading the previous chunk's LDS images
+        // ---- weight image of this chunk: 44 KiB, 11 x 1-KiB pieces per wave, straight into its LDS layout ----
         {
             const uint64_t sa = (uint64_t)(uintptr_t)(wimg + (int64_t)c * BX_IMG);   // wave-uniform: keep it in SGPRs
             const char* src = reinterpret_cast<const char*>(
@@ -274,6 +278,15 @@ __global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
                 bx_glds16(src, off + lane * 16, lds_base + off);
             }
         }
+        // ---- GroupNorm as one FMA per element: scale = rstd * gamma, shift = beta - mean * scale (this chunk's channels)
+        if (a.gn_groups && tid < BX_CK) {
+            const int ci = min(c0 + tid, a.Cin - 1);
+            const float* st = a.gn_stats + ((int64_t)n * a.gn_groups + ci / cpg) * 2;
+            const float sc = st[1] * a.gn_gamma[ci];
+            sGN[tid] = sc;
+            sGN[BX_CK + tid] = a.gn_beta[ci] - st[0] * sc;
+        }
+        if (a.gn_groups) __syncthreads();
         // ---- patch: GroupNorm(+SiLU), split into hi / lo, [pixel][channel] planes ----
 #pragma unroll
         for (int it = 0; it < PER_T; ++it) {
@@ -281,12 +294,20 @@ __global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
             if (i >= ITEMS) continue;
             const int pix = i % NPIX, q = i / NPIX;
             bf16x8 vh, vl;
+            f32x4 sc[2], sh[2];
+            if (a.gn_groups) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    sc[u] = *reinterpret_cast<const f32x4*>(sGN + q * 8 + 4 * u);
+                    sh[u] = *reinterpret_cast<const f32x4*>(sGN + BX_CK + q * 8 + 4 * u);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float v = praw[it][j];
                 const int ci = c0 + q * 8 + j;
                 if (a.gn_groups && pofs[it] >= 0 && ci < a.Cin) {
-                    v = __builtin_fmaf(v, sGN[ci], sGN[BX_GN_MAX + ci]);
+                    v = __builtin_fmaf(v, sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
                     if (a.gn_silu) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
                 }
                 const bf16 hi = f2bf(v);
@@ -301,57 +322,52 @@ __global__ __launch_bounds__(256) void conv_bx3_kernel(ConvBxArgs a) {
         __syncthreads();
         if (c + 1 < a.nch) load_raw(c0 + BX_CK);            // in flight under the MFMAs below
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dy = t / 3, dx = t % 3;
-            bf16x8 wh[4], wl[4], ph[2], pl[2];
+        for (int s = 0; s < 5; ++s) {
+            bf16x8 wh[4], wl[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int o = (i * 16 + l16) * BX_WROW + (t * BX_CK + kq * 8) * 2;
+                const int o = (i * 16 + l16) * BX_WROW + (s * 32 + kq * 8) * 2;
                 wh[i] = *reinterpret_cast<const bf16x8*>(sWh + o);
                 wl[i] = *reinterpret_cast<const bf16x8*>(sWl + o);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int o = ((wave + dy) * BX_PW + j * 16 + l16 + dx) * BX_PSTRIDE + kq * 16;
-                ph[j] = *reinterpret_cast<const bf16x8*>(sPh + o);
-                pl[j] = *reinterpret_cast<const bf16x8*>(sPl + o);
-            }
+            for (int j = 0; j < 4; ++j) {   // j = 2 * row + pixel half
+                const int o = ((2 * wave + (j >> 1)) * BX_PW + (j & 1) * 16 + l16) * BX_PSTRIDE + tap_off[s];
+                const bf16x8 ph = *reinterpret_cast<const bf16x8*>(sPh + o);
+                const bf16x8 pl = *reinterpret_cast<const bf16x8*>(sPl + o);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ph[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], pl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], ph[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ph, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], pl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], ph, acc[i][j], 0, 0, 0);
                 }
+            }
         }
     }
 
     // ---- epilogue: lane holds pixel l16 of sub-tile j, channels (kq*4 + r) of sub-tile i ----
-    const int oy = oy0 + wave;
-    if (oy < a.Hout) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ox = ox0 + j * 16 + l16;
-            if (ox >= a.Wout) continue;
+    for (int j = 0; j < 4; ++j) {
+        const int oy = oy0 + 2 * wave + (j >> 1), ox = ox0 + (j & 1) * 16 + l16;
+        if (oy >= a.Hout || ox >= a.Wout) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + i * 16 + kq * 4 + r;
-                    if (co >= a.Cout) continue;
-                    const int64_t o = (((int64_t)n * a.Cout + co) * a.Hout + oy) * a.Wout + ox;
-                    float v = acc[i][j][r];
-                    if (a.bias) v += a.bias[co];
-                    if (a.resid) v += a.resid[o];
-                    a.y[o] = v;
-                }
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + i * 16 + kq * 4 + r;
+                if (co >= a.Cout) continue;
+                const int64_t o = (((int64_t)n * a.Cout + co) * a.Hout + oy) * a.Wout + ox;
+                float v = acc[i][j][r];
+                if (a.bias) v += a.bias[co];
+                if (a.resid) v += a.resid[o];
+                a.y[o] = v;
+            }
     }
 }
 
-// w (Cout, Cin, 3, 3) fp32 -> LDS-ready images: for every (64-channel co tile, 32-channel chunk) the hi plane then the lo
-// plane, each [co_local 64][BX_WROW bytes] with k = tap * 32 + channel (zeros for channels / output channels past the end)
+// w (Cout, Cin, 3, 3) fp32 -> LDS-ready images: for every (64-channel co tile, 16-channel chunk) the hi plane then the lo
+// plane, each [co_local 64][BX_WROW bytes] with k = tap * 16 + channel (zeros for the tenth tap slot and for channels /
+// output channels past the end; the caller zero-fills the buffer)
 __global__ void conv_pack_bx3_kernel(const float* __restrict__ w, char* __restrict__ img, int Cout, int Cin, int nch,
                                      int tiles_co) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one (tile, chunk, co_local, tap, channel)
@@ -578,8 +594,6 @@ VGPT_EXPORT int vgpt_conv2d_bx3_fwd(const float* x, const void* packed, const fl
     VGPT_REQUIRE(N >= 0 && Cin > 0 && Hin > 0 && Win > 0 && Cout > 0, VGPT_ERR_INVALID, "vgpt_conv2d_bx3_fwd: bad shape");
     VGPT_REQUIRE(gn_groups == 0 || (gn_stats && gn_gamma && gn_beta && Cin % gn_groups == 0), VGPT_ERR_INVALID,
                  "vgpt_conv2d_bx3_fwd: GroupNorm prologue needs stats/gamma/beta and Cin %% groups == 0");
-    VGPT_REQUIRE(gn_groups == 0 || Cin <= BX_GN_MAX, VGPT_ERR_UNSUPPORTED,
-                 "vgpt_conv2d_bx3_fwd: at most %d input channels with the GroupNorm prologue", BX_GN_MAX);
     VGPT_REQUIRE(((uintptr_t)packed & 15) == 0, VGPT_ERR_UNSUPPORTED, "vgpt_conv2d_bx3_fwd: packed weights must be 16-byte aligned");
     if (N == 0) return VGPT_OK;
     static bool attr_set = false;
@@ -598,7 +612,7 @@ VGPT_EXPORT int vgpt_conv2d_bx3_fwd(const float* x, const void* packed, const fl
     a.upsample = upsample ? 1 : 0;
     a.Hout = Hin << a.upsample; a.Wout = Win << a.upsample;
     a.gn_groups = gn_groups; a.gn_silu = gn_silu;
-    a.tiles_x = (int)cdiv(a.Wout, TW); a.tiles_y = (int)cdiv(a.Hout, TH); a.tiles_co = (int)cdiv(Cout, TCO);
+    a.tiles_x = (int)cdiv(a.Wout, TW); a.tiles_y = (int)cdiv(a.Hout, BX_TH); a.tiles_co = (int)cdiv(Cout, TCO);
     const int64_t blocks = (int64_t)a.tiles_x * a.tiles_y * a.tiles_co * N;
     hipLaunchKernelGGL(conv_bx3_kernel, dim3((unsigned)blocks), dim3(256), BX_LDS_TOTAL, (hipStream_t)stream, a);
     VGPT_CHECK_LAUNCH("vgpt_conv2d_bx3_fwd");
