@@ -154,27 +154,29 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 // (torch.backends.cudnn.allow_tf32).  Three v_mfma_f32_16x16x32_bf16 (16 cycles each) replace eight
 // v_mfma_f32_16x16x4_f32 (32 cycles each) per 32 reduction elements.
 //
-// Tile: 64 output channels x (8 rows x 32 pixels), four waves of two rows (acc 4 x 4 sub-tiles); the reduction runs in
-// chunks of 16 input channels.  K order inside a chunk: k = tap * 16 + channel with TEN tap slots (the tenth is zero
-// weights), so one MFMA k-step (32) is two taps x 16 channels and a lane's 8 consecutive k are 8 consecutive channels
-// of ONE tap: with the patch stored [py][px][channel] and the (pre-split, pre-ordered) weights stored
-// [co][tap slot][channel], both fragments are single ds_read_b128 per hi / lo plane.  Pixel rows are 48 B and weight
-// rows 336 B apart (12 and 84 dwords: the 16-lane b128 groups read conflict-free).
-// What the shape buys over the first version (4 x 32 pixels, 32-channel chunks, 76-KiB weight image per chunk and
-// workgroup: 88 B/clk/CU of LDS-DMA at the matrix pipe's rate -- several times what a CU can take in; one workgroup per
-// CU, so nothing covered its GroupNorm / SiLU / split pass either): the weight image is 44 KiB per 2 x the MFMAs
-// (11 B/clk/CU), and at 78 KiB of LDS two workgroups share a CU, one's staging under the other's MFMAs.
+// Tile: 64 output channels x (16 rows x 32 pixels), EIGHT waves of two rows each (acc 4 x 4 sub-tiles; a template
+// variant with one row per wave, 8 x 32 pixels, serves images too small to fill the chip with the big tile); the
+// reduction runs in chunks of 16 input channels.  K order inside a chunk: k = tap * 16 + channel with TEN tap slots (the
+// tenth is zero weights), so one MFMA k-step (32) is two taps x 16 channels and a lane's 8 consecutive k are 8
+// consecutive channels of ONE tap: with the patch stored [py][px][channel] and the (pre-split, pre-ordered) weights
+// stored [co][tap slot][channel], both fragments are single ds_read_b128 per hi / lo plane.  Pixel rows are 48 B and
+// weight rows 336 B apart (12 and 84 dwords: the 16-lane b128 groups read conflict-free).
+// What the shape buys over the first version (4 x 32 pixels, four waves, 32-channel chunks: a 76-KiB weight image per
+// chunk and workgroup = 88 B/clk/CU of LDS-DMA at the matrix pipe's rate, several times what a CU can take in, fetched
+// and waited for inside every chunk; one wave per SIMD, so nothing covered the GroupNorm / SiLU / split pass either):
+// the weight image is 44 KiB (+4 padding) per 4 x the MFMAs, it is double-buffered -- the next chunk's image is in
+// flight for a whole chunk -- and two waves per SIMD share the matrix pipe.
 // Same GroupNorm(+SiLU) / upsample prologue and bias + residual epilogue as conv_kernel.
-constexpr int BX_TH = 8;                             // rows of a tile (TW = 32 pixels, TCO = 64 channels as above)
-constexpr int BX_CK = 16, BX_TAPS = 10, BX_PH = BX_TH + 2, BX_PW = TW + 2;
+constexpr int BX_CK = 16, BX_TAPS = 10, BX_PW = TW + 2;
 constexpr int BX_PSTRIDE = 48;                       // bytes per pixel in one patch plane (32 used)
 constexpr int BX_WROW = (BX_TAPS * BX_CK + 8) * 2;   // bytes per output channel in one weight plane (320 used)
-constexpr int BX_P_BYTES = BX_PH * BX_PW * BX_PSTRIDE, BX_W_BYTES = TCO * BX_WROW;
-constexpr int BX_IMG = 44 * 1024;                    // one (co tile, channel chunk) weight image: hi plane, lo plane, padding
-constexpr int BX_GN_OFF = BX_IMG + 2 * BX_P_BYTES;   // scale / shift of the chunk's 16 channels
-constexpr int BX_LDS_TOTAL = BX_GN_OFF + 2 * BX_CK * 4;
-static_assert(2 * BX_W_BYTES <= BX_IMG && BX_IMG % 4096 == 0, "weight image must split into whole 1-KiB pieces per wave");
-static_assert(2 * BX_LDS_TOTAL <= 160 * 1024, "two workgroups per CU");
+constexpr int BX_W_BYTES = TCO * BX_WROW;
+constexpr int BX_IMG = 48 * 1024;                    // one (co tile, channel chunk) weight image: hi plane, lo plane, padding
+constexpr int BX_P_MAX = (16 + 2) * BX_PW * BX_PSTRIDE;   // one patch plane of the 16-row tile
+constexpr int BX_GN_OFF = 2 * BX_IMG + 2 * BX_P_MAX;  // scale / shift of a chunk's 16 channels, two chunks
+constexpr int BX_LDS_TOTAL = BX_GN_OFF + 2 * 2 * BX_CK * 4;
+static_assert(2 * BX_W_BYTES <= BX_IMG && BX_IMG % 8192 == 0, "weight image must split into whole 1-KiB pieces per wave");
+static_assert(BX_LDS_TOTAL <= 160 * 1024, "LDS budget");
 
 struct ConvBxArgs {
     const float* x; const char* wimg; const float* bias; const float* resid;
@@ -194,62 +196,102 @@ __device__ __forceinline__ void bx_glds16(const char* base, uint32_t voffset, ui
         : "memory");
 }
 
-// Per chunk of 16 input channels:  [barrier]  the chunk's weight image goes out by LDS-DMA;  raw patch values
-// (prefetched into registers under the previous chunk's MFMAs) -> GroupNorm/SiLU/split -> LDS;  [vmcnt(0), barrier]
-// issue the raw patch loads of the NEXT chunk;  5 k-steps x 48 MFMAs.
-__global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvBxArgs a) {
+// Per chunk c of 16 input channels:  [barrier: the MFMAs of chunk c-1 are done, and every wave's share of weight image c,
+// issued a chunk ago, has landed]  weight image c+1 goes out by LDS-DMA into the other buffer;  raw patch values
+// (prefetched into registers under the previous chunk's MFMAs) -> GroupNorm/SiLU/split -> LDS;  [barrier]  issue the raw
+// patch loads of chunk c+1;  5 k-steps x 24 RPW MFMAs.
+template <int RPW>   // rows per wave: 2 (16 x 32 pixel tile) or 1 (8 x 32)
+__global__ __launch_bounds__(512, 1) void conv_bx3_kernel(ConvBxArgs a) {
+    constexpr int TH_ = 8 * RPW, PH_ = TH_ + 2, P_BYTES = PH_ * BX_PW * BX_PSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sWh = smem;
-    char* sWl = sWh + BX_W_BYTES;
-    char* sPh = smem + BX_IMG;
-    char* sPl = sPh + BX_P_BYTES;
-    float* sGN = reinterpret_cast<float*>(smem + BX_GN_OFF);   // [scale 16][shift 16] of the current chunk
+    char* sPh = smem + 2 * BX_IMG;
+    char* sPl = sPh + P_BYTES;
+    float* sGN = reinterpret_cast<float*>(smem + BX_GN_OFF);   // [chunk parity][scale 16 | shift 16]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y; bid /= a.tiles_y;
     const int tco = bid % a.tiles_co;
     const int n = bid / a.tiles_co;
-    const int co0 = tco * TCO, oy0 = ty * BX_TH, ox0 = tx * TW;
+    const int co0 = tco * TCO, oy0 = ty * TH_, ox0 = tx * TW;
     const int Hv = a.Hin << a.upsample, Wv = a.Win << a.upsample;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const float* xn = a.x + (int64_t)n * a.Cin * a.Hin * a.Win;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
     const int cpg = a.gn_groups ? a.Cin / a.gn_groups : 1;
 
-    f32x4 acc[4][4];   // [co sub-tile][2 * row + pixel half]
+    f32x4 acc[4][2 * RPW];   // [co sub-tile][2 * row + pixel half]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2 * RPW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kq = lane >> 4, l16 = lane & 15;
 
-    // staging item = (pixel of the 10 x 34 patch, group of 8 channels); 680 items over 256 threads: 3 per thread
-    constexpr int NPIX = BX_PH * BX_PW, ITEMS = NPIX * 2, PER_T = (ITEMS + 255) / 256;
+    // staging item = (pixel of the PH_ x 34 patch, group of 8 channels) over 512 threads.  Loads are unconditional from
+    // clamped addresses (a scalar base per channel + one 32-bit lane offset per item: no per-element address arithmetic,
+    // no branches): channels past Cin meet zero weights, pixels outside the image are zeroed after GroupNorm / SiLU.
+    constexpr int NPIX = PH_ * BX_PW, ITEMS = NPIX * 2, PER_T = (ITEMS + 511) / 512;
     float praw[PER_T][8];
-    int64_t pofs[PER_T];   // element offset of channel 0 of the chunk at this item's pixel, -1 = outside the image
+    uint32_t pofs[PER_T];   // element offset (pixel + 8 q channel planes) of this item inside one image of the batch
+    bool pin[PER_T];        // the pixel lies inside the image
+    const int64_t plane = (int64_t)a.Hin * a.Win;
 #pragma unroll
     for (int it = 0; it < PER_T; ++it) {
-        const int i = tid + 256 * it;
-        const int pix = i % NPIX, py = pix / BX_PW, px = pix % BX_PW;
+        const int i = min(tid + 512 * it, ITEMS - 1);
+        const int pix = i % NPIX, py = pix / BX_PW, px = pix % BX_PW, q = i / NPIX;
         const int iy = iy0 + py, ix = ix0 + px;
-        const bool inside = i < ITEMS && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-        pofs[it] = inside ? (int64_t)(iy >> a.upsample) * a.Win + (ix >> a.upsample) : -1;
+        pin[it] = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        const int cy = min(max(iy, 0), Hv - 1) >> a.upsample, cx = min(max(ix, 0), Wv - 1) >> a.upsample;
+        pofs[it] = (uint32_t)(cy * a.Win + cx) + (uint32_t)(q * 8) * (uint32_t)plane;
     }
-    const int64_t plane = (int64_t)a.Hin * a.Win;
+    const int c_last = a.Cin - 1;
+    const bool whole_chunks = (a.Cin % BX_CK) == 0;   // every layer but the 3- / 4-channel input convolutions
     auto load_raw = [&](int c0) {
-#pragma unroll
-        for (int it = 0; it < PER_T; ++it) {
-            const int q = (tid + 256 * it) / NPIX;
+        if (whole_chunks) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int ci = c0 + q * 8 + j;
-                praw[it][j] = (pofs[it] >= 0 && ci < a.Cin) ? xn[ci * plane + pofs[it]] : 0.f;
+                const float* base = xn + (int64_t)(c0 + j) * plane;   // channel c0 + j (+ 8 q through the lane offset)
+#pragma unroll
+                for (int it = 0; it < PER_T; ++it) praw[it][j] = base[pofs[it]];
+            }
+        } else {   // a partial chunk: per-lane clamped channel (the weights of channels past Cin are zero)
+#pragma unroll
+            for (int it = 0; it < PER_T; ++it) {
+                const int q = min(tid + 512 * it, ITEMS - 1) / NPIX;
+                const uint32_t pix_off = pofs[it] - (uint32_t)(q * 8) * (uint32_t)plane;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) praw[it][j] = xn[(int64_t)min(c0 + q * 8 + j, c_last) * plane + pix_off];
             }
         }
     };
-    load_raw(0);
     const char* wimg = a.wimg + (int64_t)tco * a.nch * BX_IMG;
+    auto stage_w = [&](int c) {   // weight image of chunk c: 48 KiB, 6 x 1-KiB pieces per wave, straight into its LDS layout
+        const uint64_t sa = (uint64_t)(uintptr_t)(wimg + (int64_t)c * BX_IMG);   // wave-uniform: keep it in SGPRs
+        const char* src = reinterpret_cast<const char*>(
+            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(sa >> 32)) << 32) |
+            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sa));
+#pragma unroll
+        for (int p = 0; p < BX_IMG / 8192; ++p) {
+            const uint32_t off = (uint32_t)((wave * (BX_IMG / 8192) + p) * 1024);
+            bx_glds16(src, off + lane * 16, lds_base + (uint32_t)((c & 1) * BX_IMG) + off);
+        }
+    };
+    auto gn_table = [&](int c) {   // GroupNorm as one FMA per element: scale = rstd * gamma, shift = beta - mean * scale
+        if (tid < BX_CK) {
+            float sc = 1.f, sh = 0.f;   // no GroupNorm: identity
+            if (a.gn_groups) {
+                const int ci = min(c * BX_CK + tid, a.Cin - 1);
+                const float* st = a.gn_stats + ((int64_t)n * a.gn_groups + ci / cpg) * 2;
+                sc = st[1] * a.gn_gamma[ci];
+                sh = a.gn_beta[ci] - st[0] * sc;
+            }
+            sGN[(c & 1) * 2 * BX_CK + tid] = sc;
+            sGN[(c & 1) * 2 * BX_CK + BX_CK + tid] = sh;
+        }
+    };
+    stage_w(0);
+    gn_table(0);
+    load_raw(0);
     // patch offset of a lane's tap in k-step s: tap = 2 s + (kq >> 1) (the zero tenth slot reads the ninth tap's pixels)
     int tap_off[5];
 #pragma unroll
@@ -260,56 +302,37 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvBxArgs a) {
 
     for (int c = 0; c < a.nch; ++c) {
         const int c0 = c * BX_CK;
-        // retire the raw loads HERE (before the DMA goes out): their wait would otherwise drain the DMA as well
+        // retire the raw loads of this chunk (the compiler's wait for them is vmcnt(0): weight image c, issued before
+        // them, has landed with it)
 #pragma unroll
         for (int it = 0; it < PER_T; ++it)
 #pragma unroll
             for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(praw[it][j]));
-        __syncthreads();   // every wave is done reading the previous chunk's LDS images
-        // ---- weight image of this chunk: 44 KiB, 11 x 1-KiB pieces per wave, straight into its LDS layout ----
-        {
-            const uint64_t sa = (uint64_t)(uintptr_t)(wimg + (int64_t)c * BX_IMG);   // wave-uniform: keep it in SGPRs
-            const char* src = reinterpret_cast<const char*>(
-                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(sa >> 32)) << 32) |
-                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sa));
-#pragma unroll
-            for (int p = 0; p < BX_IMG / 4096; ++p) {
-                const uint32_t off = (uint32_t)((wave * (BX_IMG / 4096) + p) * 1024);
-                bx_glds16(src, off + lane * 16, lds_base + off);
-            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave is done with chunk c-1's MFMAs; weight image c and the GroupNorm table c are complete
+        if (c + 1 < a.nch) {
+            stage_w(c + 1);
+            gn_table(c + 1);
         }
-        // ---- GroupNorm as one FMA per element: scale = rstd * gamma, shift = beta - mean * scale (this chunk's channels)
-        if (a.gn_groups && tid < BX_CK) {
-            const int ci = min(c0 + tid, a.Cin - 1);
-            const float* st = a.gn_stats + ((int64_t)n * a.gn_groups + ci / cpg) * 2;
-            const float sc = st[1] * a.gn_gamma[ci];
-            sGN[tid] = sc;
-            sGN[BX_CK + tid] = a.gn_beta[ci] - st[0] * sc;
-        }
-        if (a.gn_groups) __syncthreads();
         // ---- patch: GroupNorm(+SiLU), split into hi / lo, [pixel][channel] planes ----
+        const float* gn = sGN + (c & 1) * 2 * BX_CK;
 #pragma unroll
         for (int it = 0; it < PER_T; ++it) {
-            const int i = tid + 256 * it;
+            const int i = tid + 512 * it;
             if (i >= ITEMS) continue;
             const int pix = i % NPIX, q = i / NPIX;
             bf16x8 vh, vl;
             f32x4 sc[2], sh[2];
-            if (a.gn_groups) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    sc[u] = *reinterpret_cast<const f32x4*>(sGN + q * 8 + 4 * u);
-                    sh[u] = *reinterpret_cast<const f32x4*>(sGN + BX_CK + q * 8 + 4 * u);
-                }
+            for (int u = 0; u < 2; ++u) {
+                sc[u] = *reinterpret_cast<const f32x4*>(gn + q * 8 + 4 * u);
+                sh[u] = *reinterpret_cast<const f32x4*>(gn + BX_CK + q * 8 + 4 * u);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float v = praw[it][j];
-                const int ci = c0 + q * 8 + j;
-                if (a.gn_groups && pofs[it] >= 0 && ci < a.Cin) {
-                    v = __builtin_fmaf(v, sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
-                    if (a.gn_silu) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
-                }
+                float v = __builtin_fmaf(praw[it][j], sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
+                if (a.gn_silu) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+                v = pin[it] ? v : 0.f;   // zero padding applies to the normalised activation
                 const bf16 hi = f2bf(v);
                 vh[j] = hi;
                 vl[j] = f2bf(v - bf2f(hi));
@@ -318,9 +341,10 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvBxArgs a) {
             *reinterpret_cast<bf16x8*>(sPh + o) = vh;
             *reinterpret_cast<bf16x8*>(sPl + o) = vl;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the weight image has landed
         __syncthreads();
         if (c + 1 < a.nch) load_raw(c0 + BX_CK);            // in flight under the MFMAs below
+        const char* sWh = smem + (c & 1) * BX_IMG;
+        const char* sWl = sWh + BX_W_BYTES;
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
             bf16x8 wh[4], wl[4];
@@ -331,8 +355,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvBxArgs a) {
                 wl[i] = *reinterpret_cast<const bf16x8*>(sWl + o);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {   // j = 2 * row + pixel half
-                const int o = ((2 * wave + (j >> 1)) * BX_PW + (j & 1) * 16 + l16) * BX_PSTRIDE + tap_off[s];
+            for (int j = 0; j < 2 * RPW; ++j) {   // j = 2 * row + pixel half
+                const int o = ((RPW * wave + (j >> 1)) * BX_PW + (j & 1) * 16 + l16) * BX_PSTRIDE + tap_off[s];
                 const bf16x8 ph = *reinterpret_cast<const bf16x8*>(sPh + o);
                 const bf16x8 pl = *reinterpret_cast<const bf16x8*>(sPl + o);
 #pragma unroll
@@ -347,8 +371,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvBxArgs a) {
 
     // ---- epilogue: lane holds pixel l16 of sub-tile j, channels (kq*4 + r) of sub-tile i ----
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int oy = oy0 + 2 * wave + (j >> 1), ox = ox0 + (j & 1) * 16 + l16;
+    for (int j = 0; j < 2 * RPW; ++j) {
+        const int oy = oy0 + RPW * wave + (j >> 1), ox = ox0 + (j & 1) * 16 + l16;
         if (oy >= a.Hout || ox >= a.Wout) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -598,7 +622,9 @@ VGPT_EXPORT int vgpt_conv2d_bx3_fwd(const float* x, const void* packed, const fl
     if (N == 0) return VGPT_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_bx3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_TOTAL);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_bx3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_TOTAL);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)conv_bx3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_TOTAL);
         if (e != hipSuccess) {
             vgpt_set_error("vgpt_conv2d_bx3_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return VGPT_ERR_HIP;
@@ -612,9 +638,14 @@ VGPT_EXPORT int vgpt_conv2d_bx3_fwd(const float* x, const void* packed, const fl
     a.upsample = upsample ? 1 : 0;
     a.Hout = Hin << a.upsample; a.Wout = Win << a.upsample;
     a.gn_groups = gn_groups; a.gn_silu = gn_silu;
-    a.tiles_x = (int)cdiv(a.Wout, TW); a.tiles_y = (int)cdiv(a.Hout, BX_TH); a.tiles_co = (int)cdiv(Cout, TCO);
-    const int64_t blocks = (int64_t)a.tiles_x * a.tiles_y * a.tiles_co * N;
-    hipLaunchKernelGGL(conv_bx3_kernel, dim3((unsigned)blocks), dim3(256), BX_LDS_TOTAL, (hipStream_t)stream, a);
+    a.tiles_x = (int)cdiv(a.Wout, TW); a.tiles_co = (int)cdiv(Cout, TCO);
+    // 16-row tiles unless they leave CUs without a workgroup (one workgroup per CU: a launch wants >= 256 of them)
+    const int64_t per_row_tile = (int64_t)a.tiles_x * a.tiles_co * N;
+    const bool big = per_row_tile * cdiv(a.Hout, 16) >= 256;
+    a.tiles_y = (int)cdiv(a.Hout, big ? 16 : 8);
+    const int64_t blocks = per_row_tile * a.tiles_y;
+    if (big) hipLaunchKernelGGL(conv_bx3_kernel<2>, dim3((unsigned)blocks), dim3(512), BX_LDS_TOTAL, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_bx3_kernel<1>, dim3((unsigned)blocks), dim3(512), BX_LDS_TOTAL, (hipStream_t)stream, a);
     VGPT_CHECK_LAUNCH("vgpt_conv2d_bx3_fwd");
     return VGPT_OK;
 }
