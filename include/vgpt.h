@@ -294,8 +294,9 @@ int vgpt_conv2d_fwd(const float* x, const float* w, const float* bias, const flo
  * and the three leading product terms are accumulated in fp32 (~16 mantissa bits; the reference's torch/cuDNN default
  * for its fp32 VAE is TF32, 10 bits).  Same prologue (nearest x2 upsample, GroupNorm(+SiLU)) and epilogue (bias,
  * residual) as vgpt_conv2d_fwd.  Weights are pre-split once by vgpt_conv_pack_weights_bx3 into LDS-ready images:
- * w (Cout, Cin, 3, 3) fp32 -> `packed`, vgpt_conv_bx3_packed_bytes(Cout, Cin) bytes (one hi + lo image per 64-channel
- * output tile and 32-channel input chunk, copied into LDS by LDS-DMA). */
+ * w (Cout, Cin, 3, 3) fp32 -> `packed`, vgpt_conv_bx3_packed_bytes(Cout, Cin) bytes (one 48-KiB hi + lo image per
+ * 64-channel output tile and 16-channel input chunk, ten tap slots of 16 channels per output channel, copied into LDS by
+ * LDS-DMA; the format is private to the two functions below). */
 int64_t vgpt_conv_bx3_packed_bytes(int Cout, int Cin);
 int vgpt_conv_pack_weights_bx3(const float* w, void* packed, int Cout, int Cin, void* stream);
 int vgpt_conv2d_bx3_fwd(const float* x, const void* packed, const float* bias, const float* resid, const float* gn_stats,
