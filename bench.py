@@ -83,18 +83,18 @@ def cpu_baseline(cfg_full, batch, layers_sample=2):
     vc = VR.VaeCfg()
     vp = VR.make_vae_params(vc, seed=0)
     gen = torch.Generator("cpu").manual_seed(2)
-    with torch.no_grad():
+    with torch.no_grad():   # one 128^2 frame each way (a quarter of a 256^2 frame's pixels: the convolutions scale with them)
         t0 = time.perf_counter()
-        VR.vae_encode(vp, vc, torch.rand(1, 3, 256, 256, generator=gen) * 2 - 1, torch.randn(1, 4, 32, 32, generator=gen))
-        enc_s = time.perf_counter() - t0
+        VR.vae_encode(vp, vc, torch.rand(1, 3, 128, 128, generator=gen) * 2 - 1, torch.randn(1, 4, 16, 16, generator=gen))
+        enc_s = 4 * (time.perf_counter() - t0)
         t0 = time.perf_counter()
-        VR.decode_to_uint8(vp, vc, torch.randn(1, 4, 32, 32, generator=gen))
-        dec_s = time.perf_counter() - t0
+        VR.decode_to_uint8(vp, vc, torch.randn(1, 4, 16, 16, generator=gen))
+        dec_s = 4 * (time.perf_counter() - t0)
     cfg1 = {"vae_encode_s_per_frame": round(enc_s, 3), "vae_decode_s_per_frame": round(dec_s, 3),
             "denoise_step_s": round(step_s, 1),
             "round_s": round(4 * enc_s + step_s + 8 * dec_s, 1),
             "what": "cfg-1 shape (4 condition frames encoded, 1 denoise step of the 8-frame clip with CFG, 8 frames decoded), "
-                    "fp32 on the host cores: measured pieces composed, the step scaled from the layer sample"}
+                    "fp32 on the host cores: measured pieces composed, the step scaled from the layer sample, the VAE from one 128^2 frame x 4"}
     return {"value": 8 * 256 / step_s, "unit": "clip-tokens/s", "cores": threads, "kind": "port", "cfg1_cpu_round": cfg1,
             "sample": f"{layers_sample} of {cfg_full.num_hidden_layers} decoder layers (fp32, torch CPU) over the full "
                       f"B=2 x L={L} cfg-2 sequence took {dt:.2f}s; scaled x{cfg_full.num_hidden_layers // layers_sample} "
