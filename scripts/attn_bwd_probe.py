@@ -7,15 +7,22 @@ P = importlib.import_module("video-gpt_amd.processor"); ops = importlib.import_m
 T = importlib.import_module("video-gpt_amd.ops_train")
 dev = "cuda:0"; BF = torch.bfloat16
 F, hw, bs, nh, hd = 8, (32, 32), 2, 32, 96
-proc = P.LVMProcessor(P.SpecialTokenizer(10, 11, 12))
-rows = []
-for _ in range(bs):
-    prompt = "".join(f"<|diffusion|><|image_{i + 1}|><img><|image_{i + 1}|></img>" if i < F - 1 else f"<|diffusion|><|image_{i + 1}|>" for i in range(F))
-    rows.append(proc.process_multi_modal_prompt_training(prompt, [torch.zeros(3, 256, 256) for _ in range(F)]))
-batch = proc.collator.collate_stage1(rows, F)
-mask = batch["attention_mask"].to(dev)
-B, L = mask.shape[:2]
-pm = ops.pack_mask(mask)
+if "--cfg4" in sys.argv:   # 512^2, 16 frames, bs 1: L = 31 806 (mask from token attributes: the dense form is 1 GB)
+    LY = importlib.import_module("video-gpt_amd.layout")
+    F, N4 = 16, 1024
+    kinds, _ = P.plan_stage1(2 * F - 1)
+    B, L = 1, (2 * F - 1) * (N4 + 2)
+    pm = LY.TokenLayout.from_plans([(kinds, N4 + 2, 0)], L).packed_mask(dev)
+else:
+    proc = P.LVMProcessor(P.SpecialTokenizer(10, 11, 12))
+    rows = []
+    for _ in range(bs):
+        prompt = "".join(f"<|diffusion|><|image_{i + 1}|><img><|image_{i + 1}|></img>" if i < F - 1 else f"<|diffusion|><|image_{i + 1}|>" for i in range(F))
+        rows.append(proc.process_multi_modal_prompt_training(prompt, [torch.zeros(3, 256, 256) for _ in range(F)]))
+    batch = proc.collator.collate_stage1(rows, F)
+    mask = batch["attention_mask"].to(dev)
+    B, L = mask.shape[:2]
+    pm = ops.pack_mask(mask)
 summ = pm.summary.cpu()
 print("B", B, "L", L, "active (128-row block, 64-key tile) pairs per batch item:", int((summ != 0).sum()) // B, "of", summ[0].numel())
 qkv = torch.randn(B, L, 3 * nh * hd, device=dev).to(BF)
