@@ -84,3 +84,43 @@ def test_ulysses_all_to_all_layout_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(all(r[1:]) for r in res), res
+
+
+# ---- gradient buckets are bf16 (train.Stage1Trainer): what an 8-rank sum in bf16 costs against the exact mean ----
+def _bf16_sum_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1 << 16
+    grads = [(torch.randn(n, generator=torch.Generator().manual_seed(1000 + r)) * 0.02 + 0.01).to(torch.bfloat16) for r in range(world)]
+    bucket = grads[rank].clone()
+    dist.all_reduce(bucket)                               # what the trainer does: the bucket itself is the exchange buffer
+    exact = torch.stack([g_.double() for g_ in grads]).sum(0)
+    got = bucket.double()
+    rel = float((got - exact).norm() / exact.norm())
+    worst = float((got - exact).abs().max() / exact.abs().max())   # largest error against the largest value
+    q.put((rank, rel, worst, got.sum().item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_sum_over_8_ranks_stays_within_bf16_rounding():
+    """The data-parallel exchange sums bf16 buckets (7.5 GB per step instead of 15): with 8 ranks every element passes
+    through at most 7 bf16 roundings of partial sums.  Measured against the exact sum of the same bf16 inputs: rel-L2 of a
+    few 1e-3 (2^-9 per rounding, partly cancelling), every rank holding the identical result."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_sum_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rels = [r[1] for r in res]
+    assert max(rels) < 6e-3, rels                          # ~ sqrt(7) x 2^-9 / sqrt(3) = 3e-3 expected
+    assert max(r[2] for r in res) < 1e-2
+    assert len({r[3] for r in res}) == 1                   # all ranks agree bit for bit
