@@ -1,4 +1,4 @@
-"""Developer probe (GPU): attention forward on the cfg-2 engine layout (hoisted: 1152-row prefix, 4096 live rows, 32 heads
+"""Developer probe (GPU): attention forward on the cfg-2 engine layout (hoisted: 1152-row prefix, 4096 live rows (L = 5248), 32 heads
 x 96) and at L = 31 806 (cfg-4 shapes): bf16 kernel against the MX-fp8 path (quantise + kernel, and the kernel alone)."""
 import importlib, os, sys, torch
 import numpy as np

@@ -251,3 +251,41 @@ def test_engine_rejects_unknown_attention_precision():
 class _NotReady:
     def _check_ready(self):
         return None
+
+
+def test_attention_fp8_on_the_real_cfg2_mask(ops):
+    """The sampler's own layout at cfg-2 (256^2, C = 4 condition + G = 8 generated frames, CFG row packed behind, special
+    rows hoisted: L = 5248, 4096 live rows cut at the sequence seam) with 2 heads: fp8 attention of the live rows against
+    fp64 on the unquantised inputs for row bands around the seams, and against the bf16 kernel on every row."""
+    P = importlib.import_module("video-gpt_amd.processor")
+    LY = importlib.import_module("video-gpt_amd.layout")
+    nh, C, G, bl, N, nf = 2, 4, 8, 258, 256, 16
+    lay = LY.TokenLayout.from_plans([(P.plan_inference([C, G])[0], bl, 0), (P.plan_inference([0, G])[0], bl, C * bl)], (C + G) * bl)
+    packed, _ = lay.pack()
+    S0 = C * bl
+    x_old = [S0 + f * bl + 2 for f in range(G)] + [S0 + G * bl + f * bl + 2 for f in range(G)]
+    d_old = [x - 2 for x in x_old]; t_old = [x - 1 for x in x_old]
+    S = (S0 + 2 * nf + 127) // 128 * 128
+    perm = list(range(S0)) + d_old + t_old + [-1] * (S - S0 - 2 * nf) + [x + j for x in x_old for j in range(N)]
+    lp = packed.permute(np.array(perm))
+    pm = lp.packed_mask(DEV)
+    L = len(perm)
+    assert (L, S) == (5248, 1152)
+    qkv = torch.randn(1, L, 3 * nh * D, generator=g(21)).to(BF)
+    segs = ((0, S, S + 2048), (0, S + 2048, L))
+    out8 = torch.empty(1, L - S, nh * D, dtype=BF, device=DEV)
+    out16 = torch.empty_like(out8)
+    ops.attention_qkv_fp8(qkv.to(DEV), pm, nh, nh, D, out=out8, q_start=S, segments=segs)
+    ops.attention_qkv_range(qkv.to(DEV), pm, nh, nh, D, S, out16, segments=segs)
+    assert torch.isfinite(out8).all()
+    e16 = rel_l2(out8, out16)
+    dense = torch.from_numpy(lp.to_bool())                          # (1, L, L)
+    q, k, v = split_qkv(qkv.float(), nh, nh)
+    worst = 0.0
+    for r0 in (S, S + 1000, S + 2048 - 64, S + 2048, L - 128):      # first rows, mid, both sides of the seam, last rows
+        rows = slice(r0, r0 + 64)
+        ref = ref_attention(q[:, :, rows], k, v, dense[:, rows], 1 / math.sqrt(D)).transpose(1, 2).reshape(1, 64, nh * D)
+        worst = max(worst, rel_l2(out8[:, r0 - S:r0 - S + 64], ref))
+        assert rel_l2(out16[:, r0 - S:r0 - S + 64], ref) < 1e-2
+    print(f"fp8 attention on the cfg-2 layout: rel-L2 vs bf16 kernel {e16:.3e}, worst band vs fp64 {worst:.3e}")
+    assert e16 < 8e-2 and worst < 8e-2
