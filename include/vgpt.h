@@ -302,6 +302,16 @@ int vgpt_conv_pack_weights_bx3(const float* w, void* packed, int Cout, int Cin, 
 int vgpt_conv2d_bx3_fwd(const float* x, const void* packed, const float* bias, const float* resid, const float* gn_stats,
                         const float* gn_gamma, const float* gn_beta, float* y, int N, int Cin, int Hin, int Win, int Cout,
                         int upsample, int gn_groups, int gn_silu, void* stream);
+/* 1x1 convolution (resnet shortcuts, the mid-block attention's projections; diffusers ResnetBlock2D.conv_shortcut /
+ * Attention.to_q..to_out, call sites LVM/pipeline.py:565,578) in the same split-bf16 arithmetic and with the same
+ * GroupNorm(+SiLU) prologue / bias + residual epilogue; x (N, Cin, HW), y (N, Cout, HW) fp32, Cin % 32 == 0.
+ * w (Cout, Cin) fp32 is pre-split once: vgpt_conv1x1_bx3_packed_bytes(Cout, Cin) bytes. */
+int64_t vgpt_conv1x1_bx3_packed_bytes(int Cout, int Cin);
+int vgpt_conv1x1_pack_weights_bx3(const float* w, void* packed, int Cout, int Cin, void* stream);
+int vgpt_conv1x1_bx3_fwd(const float* x, const void* packed, const float* bias, const float* resid, const float* gn_stats,
+                         const float* gn_gamma, const float* gn_beta, float* y, int N, int Cin, int HW, int Cout,
+                         int gn_groups, int gn_silu, void* stream);
+
 /* In-place softmax over the KEY axis of S^T (N, keys, queries) with pre-scale (mid-block attention). */
 int vgpt_col_softmax(float* s, int N, int keys, int queries, float scale, void* stream);
 

@@ -69,6 +69,9 @@ SIGNATURES = {
     "vgpt_conv_bx3_packed_bytes": (c_int64, [c_int, c_int]),
     "vgpt_conv_pack_weights_bx3": (c_int, [_P, _P, c_int, c_int, _P]),
     "vgpt_conv2d_bx3_fwd": (c_int, [_P] * 8 + [c_int] * 8 + [_P]),
+    "vgpt_conv1x1_bx3_packed_bytes": (c_int64, [c_int, c_int]),
+    "vgpt_conv1x1_pack_weights_bx3": (c_int, [_P, _P, c_int, c_int, _P]),
+    "vgpt_conv1x1_bx3_fwd": (c_int, [_P] * 8 + [c_int] * 6 + [_P]),
     "vgpt_col_softmax": (c_int, [_P, c_int, c_int, c_int, c_float, _P]),
     "vgpt_vae_sample": (c_int, [_P, _P, _P, c_int, _I64, c_float, c_float, _P]),
     "vgpt_vae_postprocess_u8": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

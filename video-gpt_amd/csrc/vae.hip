@@ -407,6 +407,183 @@ __global__ void conv_pack_bx3_kernel(const float* __restrict__ w, char* __restri
     *reinterpret_cast<bf16*>(base + BX_W_BYTES) = f2bf(v - bf2f(h));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 convolution (channel mixing: the resnet shortcuts, the mid-block attention's q / k / v / out projections) in the
+// same split-bf16 arithmetic.  y[n][co][p] = sum_ci w[co][ci] x[n][ci][p] is a GEMM whose activation operand is
+// channel-major in memory, so it goes through the same register prefetch -> (GroupNorm / SiLU) -> hi / lo split ->
+// [pixel][channel] LDS planes as the 3x3 kernel's patch, without the halo.  Tile: 64 output channels x 512 consecutive
+// pixels of one image, eight waves of 64 pixels (acc 4 x 4 sub-tiles); chunks of 32 input channels = one MFMA k-step;
+// weight images of 16 KiB per (co tile, chunk) (rows of 32 channels + 16 B pad, hi plane then lo plane) double-buffered
+// by LDS-DMA.  At 256^2 these layers are HBM-bound (the 256 -> 128 shortcut moves 0.8 GB per 8 frames for 34 GFLOP); the
+// exact-fp32 MFMA kernel they ran on before reached a fifth of that.
+constexpr int B1_CK = 32, B1_TP = 512;
+constexpr int B1_ROW = B1_CK * 2 + 16;                 // bytes per pixel / per output channel in one plane (80: 20 dwords)
+constexpr int B1_P_BYTES = B1_TP * B1_ROW;              // 40 KiB per plane
+constexpr int B1_W_BYTES = TCO * B1_ROW;                // 5 KiB per plane
+constexpr int B1_IMG = 16 * 1024;
+constexpr int B1_GN_OFF = 2 * B1_IMG + 2 * B1_P_BYTES;
+constexpr int B1_LDS_TOTAL = B1_GN_OFF + 2 * 2 * B1_CK * 4;
+static_assert(2 * B1_W_BYTES <= B1_IMG && B1_LDS_TOTAL <= 160 * 1024, "LDS budget");
+
+struct Conv1Args {
+    const float* x; const char* wimg; const float* bias; const float* resid;
+    const float* gn_stats; const float* gn_gamma; const float* gn_beta;
+    float* y;
+    int N, Cin, nch, HW, Cout;
+    int gn_groups, gn_silu;
+    int tiles_p, tiles_co;
+};
+
+__global__ __launch_bounds__(512, 1) void conv1x1_bx3_kernel(Conv1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sPh = smem + 2 * B1_IMG;
+    char* sPl = sPh + B1_P_BYTES;
+    float* sGN = reinterpret_cast<float*>(smem + B1_GN_OFF);   // [chunk parity][scale 32 | shift 32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int tp = bid % a.tiles_p; bid /= a.tiles_p;
+    const int tco = bid % a.tiles_co;
+    const int n = bid / a.tiles_co;
+    const int co0 = tco * TCO, p0 = tp * B1_TP;
+    const float* xn = a.x + (int64_t)n * a.Cin * a.HW;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    const int cpg = a.gn_groups ? a.Cin / a.gn_groups : 1;
+    const int kq = lane >> 4, l16 = lane & 15;
+
+    f32x4 acc[4][4];   // [co sub-tile][pixel sub-tile of this wave's 64 pixels]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // thread = one pixel of the tile: its 32 channel values of a chunk (coalesced across the threads of a wave)
+    const uint32_t pofs = (uint32_t)min(p0 + tid, a.HW - 1);
+    float praw[B1_CK];
+    auto load_raw = [&](int c0) {   // Cin % 32 == 0 (checked on the host): no clamping
+#pragma unroll
+        for (int j = 0; j < B1_CK; ++j) praw[j] = (xn + (int64_t)(c0 + j) * a.HW)[pofs];
+    };
+    const char* wimg = a.wimg + (int64_t)tco * a.nch * B1_IMG;
+    auto stage_w = [&](int c) {   // 16 KiB image: 2 x 1-KiB pieces per wave
+        const uint64_t sa = (uint64_t)(uintptr_t)(wimg + (int64_t)c * B1_IMG);
+        const char* src = reinterpret_cast<const char*>(
+            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(sa >> 32)) << 32) |
+            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sa));
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint32_t off = (uint32_t)((wave * 2 + p) * 1024);
+            bx_glds16(src, off + lane * 16, lds_base + (uint32_t)((c & 1) * B1_IMG) + off);
+        }
+    };
+    auto gn_table = [&](int c) {
+        if (tid < B1_CK) {
+            float sc = 1.f, sh = 0.f;
+            if (a.gn_groups) {
+                const int ci = c * B1_CK + tid;
+                const float* st = a.gn_stats + ((int64_t)n * a.gn_groups + ci / cpg) * 2;
+                sc = st[1] * a.gn_gamma[ci];
+                sh = a.gn_beta[ci] - st[0] * sc;
+            }
+            sGN[(c & 1) * 2 * B1_CK + tid] = sc;
+            sGN[(c & 1) * 2 * B1_CK + B1_CK + tid] = sh;
+        }
+    };
+    stage_w(0);
+    gn_table(0);
+    load_raw(0);
+
+    for (int c = 0; c < a.nch; ++c) {
+#pragma unroll
+        for (int j = 0; j < B1_CK; ++j) asm volatile("" : "+v"(praw[j]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // chunk c-1's MFMAs are done; weight image c and GroupNorm table c are complete
+        if (c + 1 < a.nch) {
+            stage_w(c + 1);
+            gn_table(c + 1);
+        }
+        const float* gn = sGN + (c & 1) * 2 * B1_CK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // 8 channels -> one 16-byte store per plane
+            bf16x8 vh, vl;
+            f32x4 sc[2], sh[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                sc[u] = *reinterpret_cast<const f32x4*>(gn + q * 8 + 4 * u);
+                sh[u] = *reinterpret_cast<const f32x4*>(gn + B1_CK + q * 8 + 4 * u);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = __builtin_fmaf(praw[q * 8 + j], sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
+                if (a.gn_silu) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+                const bf16 hi = f2bf(v);
+                vh[j] = hi;
+                vl[j] = f2bf(v - bf2f(hi));
+            }
+            *reinterpret_cast<bf16x8*>(sPh + tid * B1_ROW + q * 16) = vh;
+            *reinterpret_cast<bf16x8*>(sPl + tid * B1_ROW + q * 16) = vl;
+        }
+        __syncthreads();
+        if (c + 1 < a.nch) load_raw((c + 1) * B1_CK);
+        const char* sWh = smem + (c & 1) * B1_IMG;
+        const char* sWl = sWh + B1_W_BYTES;
+        bf16x8 wh[4], wl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = (i * 16 + l16) * B1_ROW + kq * 16;
+            wh[i] = *reinterpret_cast<const bf16x8*>(sWh + o);
+            wl[i] = *reinterpret_cast<const bf16x8*>(sWl + o);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = (wave * 64 + j * 16 + l16) * B1_ROW + kq * 16;
+            const bf16x8 ph = *reinterpret_cast<const bf16x8*>(sPh + o);
+            const bf16x8 pl = *reinterpret_cast<const bf16x8*>(sPl + o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ph, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], pl, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], ph, acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds pixel l16 of sub-tile j, channels (kq*4 + r) of sub-tile i ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = p0 + wave * 64 + j * 16 + l16;
+        if (p >= a.HW) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + i * 16 + kq * 4 + r;
+                if (co >= a.Cout) continue;
+                const int64_t o = ((int64_t)n * a.Cout + co) * a.HW + p;
+                float v = acc[i][j][r];
+                if (a.bias) v += a.bias[co];
+                if (a.resid) v += a.resid[o];
+                a.y[o] = v;
+            }
+    }
+}
+
+// w (Cout, Cin) fp32 -> per (64-channel co tile, 32-channel chunk) a 16-KiB image: hi plane then lo plane, each
+// [co_local 64][B1_ROW bytes] (the caller zero-fills the buffer)
+__global__ void conv_pack_b1_kernel(const float* __restrict__ w, char* __restrict__ img, int Cout, int Cin, int nch,
+                                    int tiles_co) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one (tile, chunk, co_local, channel)
+    const int64_t total = (int64_t)tiles_co * nch * TCO * B1_CK;
+    if (i >= total) return;
+    const int cl = (int)(i % B1_CK), col = (int)((i / B1_CK) % TCO);
+    const int c = (int)((i / ((int64_t)B1_CK * TCO)) % nch), tc = (int)(i / ((int64_t)B1_CK * TCO * nch));
+    const int co = tc * TCO + col, ci = c * B1_CK + cl;
+    const float v = (co < Cout && ci < Cin) ? w[(int64_t)co * Cin + ci] : 0.f;
+    const bf16 h = f2bf(v);
+    char* base = img + ((int64_t)tc * nch + c) * B1_IMG + (int64_t)col * B1_ROW + cl * 2;
+    *reinterpret_cast<bf16*>(base) = h;
+    *reinterpret_cast<bf16*>(base + B1_W_BYTES) = f2bf(v - bf2f(h));
+}
+
 // ---- GroupNorm statistics: one 1024-thread block per (n, group), ONE pass over the group ----
 // Sums of d = x - K and d^2 with the shift K = the group's first element (close to the mean, so Q/n - (S/n)^2 does
 // not cancel), four independent 16-byte loads per thread and iteration; per-thread partial sums, then a wave / LDS
@@ -473,21 +650,33 @@ __global__ __launch_bounds__(1024) void gn_stats_kernel(const float* __restrict_
 }
 
 // ---- column softmax of S^T (n, keys, queries): softmax over keys for every query column, in place ----
+// block = 64 query columns x 4 key quarters (one wave each: a wave reads 64 consecutive floats of a key row); the four
+// partial (max, sum) pairs of a column meet in LDS, then every wave normalises its own quarter.
 __global__ __launch_bounds__(256) void col_softmax_kernel(float* __restrict__ s, int keys, int queries, float scale) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= queries) return;
-    float* p = s + (int64_t)blockIdx.y * keys * queries + q;
+    __shared__ float sm[4][64], sl[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + c;
+    const bool live = q < queries;
+    float* p = s + (int64_t)blockIdx.y * keys * queries + min(q, queries - 1);
+    const int per = (keys + 3) / 4, k0 = g * per, k1 = min(k0 + per, keys);
     float m = -INFINITY, l = 0.f;
-    for (int k = 0; k < keys; ++k) {
+    for (int k = k0; k < k1; ++k) {
         const float v = p[(int64_t)k * queries] * scale;
         const float mn = fmaxf(m, v);
         l = l * expf(m - mn) + expf(v - mn);
         m = mn;
     }
-    const float inv = 1.0f / l;
-    for (int k = 0; k < keys; ++k) {
+    sm[g][c] = m;
+    sl[g][c] = l;
+    __syncthreads();
+    float M = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c])), Lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Lsum += sm[i][c] == -INFINITY ? 0.f : sl[i][c] * expf(sm[i][c] - M);
+    const float inv = 1.0f / Lsum;
+    if (!live) return;
+    for (int k = k0; k < k1; ++k) {
         float* e = p + (int64_t)k * queries;
-        *e = expf(*e * scale - m) * inv;
+        *e = expf(*e * scale - M) * inv;
     }
 }
 
@@ -650,11 +839,62 @@ VGPT_EXPORT int vgpt_conv2d_bx3_fwd(const float* x, const void* packed, const fl
     return VGPT_OK;
 }
 
+VGPT_EXPORT int64_t vgpt_conv1x1_bx3_packed_bytes(int Cout, int Cin) {
+    return (int64_t)cdiv(Cout, TCO) * cdiv(Cin, B1_CK) * B1_IMG;
+}
+
+VGPT_EXPORT int vgpt_conv1x1_pack_weights_bx3(const float* w, void* packed, int Cout, int Cin, void* stream) {
+    VGPT_REQUIRE(w && packed && Cout > 0 && Cin > 0, VGPT_ERR_INVALID, "vgpt_conv1x1_pack_weights_bx3: bad argument");
+    const int tiles_co = (int)cdiv(Cout, TCO), nch = (int)cdiv(Cin, B1_CK);
+    hipError_t e = hipMemsetAsync(packed, 0, vgpt_conv1x1_bx3_packed_bytes(Cout, Cin), (hipStream_t)stream);
+    if (e != hipSuccess) {
+        vgpt_set_error("vgpt_conv1x1_pack_weights_bx3: memset: %s", hipGetErrorString(e));
+        return VGPT_ERR_HIP;
+    }
+    const int64_t n = (int64_t)tiles_co * nch * TCO * B1_CK;
+    hipLaunchKernelGGL(conv_pack_b1_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (char*)packed, Cout,
+                       Cin, nch, tiles_co);
+    VGPT_CHECK_LAUNCH("vgpt_conv1x1_pack_weights_bx3");
+    return VGPT_OK;
+}
+
+VGPT_EXPORT int vgpt_conv1x1_bx3_fwd(const float* x, const void* packed, const float* bias, const float* resid,
+                                     const float* gn_stats, const float* gn_gamma, const float* gn_beta, float* y, int N,
+                                     int Cin, int HW, int Cout, int gn_groups, int gn_silu, void* stream) {
+    VGPT_REQUIRE(x && packed && y, VGPT_ERR_INVALID, "vgpt_conv1x1_bx3_fwd: null pointer");
+    VGPT_REQUIRE(N >= 0 && Cin > 0 && HW > 0 && Cout > 0, VGPT_ERR_INVALID, "vgpt_conv1x1_bx3_fwd: bad shape");
+    VGPT_REQUIRE(Cin % B1_CK == 0, VGPT_ERR_UNSUPPORTED, "vgpt_conv1x1_bx3_fwd: Cin must be a multiple of %d (got %d)", B1_CK, Cin);
+    VGPT_REQUIRE(gn_groups == 0 || (gn_stats && gn_gamma && gn_beta && Cin % gn_groups == 0), VGPT_ERR_INVALID,
+                 "vgpt_conv1x1_bx3_fwd: GroupNorm prologue needs stats/gamma/beta and Cin %% groups == 0");
+    VGPT_REQUIRE(((uintptr_t)packed & 15) == 0, VGPT_ERR_UNSUPPORTED, "vgpt_conv1x1_bx3_fwd: packed weights must be 16-byte aligned");
+    VGPT_REQUIRE((int64_t)Cin * HW < (1ll << 31), VGPT_ERR_UNSUPPORTED, "vgpt_conv1x1_bx3_fwd: image too large");
+    if (N == 0) return VGPT_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv1x1_bx3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_TOTAL);
+        if (e != hipSuccess) {
+            vgpt_set_error("vgpt_conv1x1_bx3_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return VGPT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    Conv1Args a;
+    a.x = x; a.wimg = (const char*)packed; a.bias = bias; a.resid = resid;
+    a.gn_stats = gn_stats; a.gn_gamma = gn_gamma; a.gn_beta = gn_beta; a.y = y;
+    a.N = N; a.Cin = Cin; a.nch = Cin / B1_CK; a.HW = HW; a.Cout = Cout;
+    a.gn_groups = gn_groups; a.gn_silu = gn_silu;
+    a.tiles_p = (int)cdiv(HW, B1_TP); a.tiles_co = (int)cdiv(Cout, TCO);
+    const int64_t blocks = (int64_t)a.tiles_p * a.tiles_co * N;
+    hipLaunchKernelGGL(conv1x1_bx3_kernel, dim3((unsigned)blocks), dim3(512), B1_LDS_TOTAL, (hipStream_t)stream, a);
+    VGPT_CHECK_LAUNCH("vgpt_conv1x1_bx3_fwd");
+    return VGPT_OK;
+}
+
 VGPT_EXPORT int vgpt_col_softmax(float* s, int N, int keys, int queries, float scale, void* stream) {
     VGPT_REQUIRE(s, VGPT_ERR_INVALID, "vgpt_col_softmax: null pointer");
     VGPT_REQUIRE(N >= 0 && keys > 0 && queries > 0, VGPT_ERR_INVALID, "vgpt_col_softmax: bad shape");
     if (N == 0) return VGPT_OK;
-    hipLaunchKernelGGL(col_softmax_kernel, dim3((unsigned)cdiv(queries, 256), N), dim3(256), 0, (hipStream_t)stream, s,
+    hipLaunchKernelGGL(col_softmax_kernel, dim3((unsigned)cdiv(queries, 64), N), dim3(256), 0, (hipStream_t)stream, s,
                        keys, queries, scale);
     VGPT_CHECK_LAUNCH("vgpt_col_softmax");
     return VGPT_OK;

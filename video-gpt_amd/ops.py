@@ -663,6 +663,41 @@ def conv2d_bx3(x: torch.Tensor, packed, bias: Optional[torch.Tensor] = None, res
     return out
 
 
+def conv1x1_pack_bx3(weight: torch.Tensor):
+    """(Cout, Cin[, 1, 1]) fp32 -> split-bf16 weight images for conv1x1_bx3 (include/vgpt.h)."""
+    _chk(weight, F32, "conv1x1_pack_bx3.weight")
+    Cout, Cin = weight.shape[:2]
+    if weight.numel() != Cout * Cin:
+        raise VgptError("conv1x1_pack_bx3: 1x1 kernels only")
+    from ._lib import load
+    packed = torch.empty(int(load().vgpt_conv1x1_bx3_packed_bytes(Cout, Cin)), dtype=torch.uint8, device=weight.device)
+    call("vgpt_conv1x1_pack_weights_bx3", weight.data_ptr(), packed.data_ptr(), Cout, Cin, _stream())
+    return packed, Cout, Cin
+
+
+def conv1x1_bx3(x: torch.Tensor, packed, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, gn=None,
+                out: Optional[torch.Tensor] = None):
+    """1x1 convolution with split-bf16 operands on the bf16 MFMA (fp32 in / out, Cin % 32 == 0); packed = conv1x1_pack_bx3(w)."""
+    _chk(x, F32, "conv1x1_bx3.x")
+    img, cout, cin = packed
+    N, Cin, Hin, Win = x.shape
+    if cin != Cin:
+        raise VgptError("conv1x1_bx3: packed weights do not match the input channels")
+    if out is None:
+        out = torch.empty(N, cout, Hin, Win, dtype=F32, device=x.device)
+    if resid is not None:
+        _chk(resid, F32, "conv1x1_bx3.resid")
+        if resid.numel() != out.numel():
+            raise VgptError("conv1x1_bx3: residual shape mismatch")
+    stats = gamma = beta = None
+    groups = silu = 0
+    if gn is not None:
+        stats, gamma, beta, groups, silu = gn
+    call("vgpt_conv1x1_bx3_fwd", x.data_ptr(), img.data_ptr(), _ptr(bias), _ptr(resid), _ptr(stats), _ptr(gamma), _ptr(beta),
+         out.data_ptr(), N, Cin, Hin * Win, cout, int(groups), int(silu), _stream())
+    return out
+
+
 def col_softmax(s: torch.Tensor, scale: float):
     _chk(s, F32, "col_softmax.s")
     N, keys, queries = s.shape

@@ -47,6 +47,18 @@ def _conv3(mod, x, prec: str, **kw):
     return ops.conv2d(x, mod.weight, mod.bias, **kw)
 
 
+def _conv1(mod, x, prec: str, **kw):
+    """1x1 convolution of an nn.Conv2d / nn.Linear weight: the split-bf16 kernel when the precision asks for it and the
+    input channels are whole 32-channel chunks, the exact fp32 kernel otherwise (the 4- and 8-channel quant convolutions)."""
+    if prec == "bf16x3" and mod.weight.shape[1] % 32 == 0:
+        key = (mod.weight.data_ptr(), mod.weight._version)
+        if getattr(mod, "_bx1_key", None) != key:
+            mod._bx1 = ops.conv1x1_pack_bx3(mod.weight.detach().contiguous())
+            mod._bx1_key = key
+        return ops.conv1x1_bx3(x, mod._bx1, mod.bias, **kw)
+    return ops.conv2d(x, mod.weight, mod.bias, ksize=1, **kw)
+
+
 class _Resnet(nn.Module):
     def __init__(self, ci, co):
         super().__init__()
@@ -60,7 +72,7 @@ class _Resnet(nn.Module):
         h = _conv3(self.conv1, x, prec, gn=(st, self.norm1.weight, self.norm1.bias, groups, 1))
         skip = x
         if hasattr(self, "conv_shortcut"):
-            skip = ops.conv2d(x, self.conv_shortcut.weight, self.conv_shortcut.bias, ksize=1)
+            skip = _conv1(self.conv_shortcut, x, prec)
         st2 = ops.groupnorm_stats(h, groups, eps)
         return _conv3(self.conv2, h, prec, resid=skip, gn=(st2, self.norm2.weight, self.norm2.bias, groups, 1))
 
@@ -72,21 +84,21 @@ class _Attention(nn.Module):
         self.to_q, self.to_k, self.to_v = nn.Linear(c, c), nn.Linear(c, c), nn.Linear(c, c)
         self.to_out = nn.ModuleList([nn.Linear(c, c), nn.Identity()])
 
-    def run(self, x, groups, eps):
+    def run(self, x, groups, eps, prec="fp32"):
         N, C, H, W = x.shape
         HW = H * W
         st = ops.groupnorm_stats(x, groups, eps)
         gn = (st, self.group_norm.weight, self.group_norm.bias, groups, 0)
-        q = ops.conv2d(x, self.to_q.weight, self.to_q.bias, gn=gn, ksize=1)   # (N, C, H, W) = [c][pos]
-        k = ops.conv2d(x, self.to_k.weight, self.to_k.bias, gn=gn, ksize=1)
-        v = ops.conv2d(x, self.to_v.weight, self.to_v.bias, gn=gn, ksize=1)
+        q = _conv1(self.to_q, x, prec, gn=gn)   # (N, C, H, W) = [c][pos]
+        k = _conv1(self.to_k, x, prec, gn=gn)
+        v = _conv1(self.to_v, x, prec, gn=gn)
         # S^T[key][query] = sum_c K[c][key] Q[c][query]: "weights" = K stored [c][key] (transposed), input = Q
         # (a 1x1 conv is pointwise, so the HW query positions keep their (H, W) tiling)
         st_ = ops.conv2d(q, k, ksize=1, cout=HW, w_transposed=True, ldw=HW, w_batch_stride=C * HW)   # (N, HW, H, W)
         ops.col_softmax(st_.view(N, HW, HW), 1.0 / (C ** 0.5))
         # O[c][query] = sum_key V[c][key] P^T[key][query]
         o = ops.conv2d(st_, v, ksize=1, cout=C, ldw=HW, w_batch_stride=C * HW)                     # (N, C, H, W)
-        return ops.conv2d(o, self.to_out[0].weight, self.to_out[0].bias, resid=x, ksize=1)
+        return _conv1(self.to_out[0], o, prec, resid=x)
 
 
 class _Mid(nn.Module):
@@ -97,7 +109,7 @@ class _Mid(nn.Module):
 
     def run(self, x, groups, eps, prec="fp32"):
         x = self.resnets[0].run(x, groups, eps, prec)
-        x = self.attentions[0].run(x, groups, eps)
+        x = self.attentions[0].run(x, groups, eps, prec)
         return self.resnets[1].run(x, groups, eps, prec)
 
 
