@@ -200,6 +200,11 @@ __device__ __forceinline__ void bx_glds16(const char* base, uint32_t voffset, ui
 // issued a chunk ago, has landed]  weight image c+1 goes out by LDS-DMA into the other buffer;  raw patch values
 // (prefetched into registers under the previous chunk's MFMAs) -> GroupNorm/SiLU/split -> LDS;  [barrier]  issue the raw
 // patch loads of chunk c+1;  5 k-steps x 24 RPW MFMAs.
+// VGPT_BX_DEBUG (diagnostic builds, results are WRONG): 1 = no GroupNorm / SiLU / split arithmetic (values stored as
+// they come), 2 = no raw patch loads, 4 = no weight LDS-DMA, 8 = no epilogue, 16 = no MFMAs
+#ifndef VGPT_BX_DEBUG
+#define VGPT_BX_DEBUG 0
+#endif
 template <int RPW>   // rows per wave: 2 (16 x 32 pixel tile) or 1 (8 x 32)
 __global__ __launch_bounds__(512, 1) void conv_bx3_kernel(ConvBxArgs a) {
     constexpr int TH_ = 8 * RPW, PH_ = TH_ + 2, P_BYTES = PH_ * BX_PW * BX_PSTRIDE;
@@ -247,6 +252,7 @@ __global__ __launch_bounds__(512, 1) void conv_bx3_kernel(ConvBxArgs a) {
     const int c_last = a.Cin - 1;
     const bool whole_chunks = (a.Cin % BX_CK) == 0;   // every layer but the 3- / 4-channel input convolutions
     auto load_raw = [&](int c0) {
+        if constexpr ((VGPT_BX_DEBUG & 2) != 0) return;
         if (whole_chunks) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -272,6 +278,7 @@ __global__ __launch_bounds__(512, 1) void conv_bx3_kernel(ConvBxArgs a) {
             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sa));
 #pragma unroll
         for (int p = 0; p < BX_IMG / 8192; ++p) {
+            if constexpr ((VGPT_BX_DEBUG & 4) != 0) continue;
             const uint32_t off = (uint32_t)((wave * (BX_IMG / 8192) + p) * 1024);
             bx_glds16(src, off + lane * 16, lds_base + (uint32_t)((c & 1) * BX_IMG) + off);
         }
@@ -330,12 +337,15 @@ __global__ __launch_bounds__(512, 1) void conv_bx3_kernel(ConvBxArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float v = __builtin_fmaf(praw[it][j], sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
-                if (a.gn_silu) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
-                v = pin[it] ? v : 0.f;   // zero padding applies to the normalised activation
+                float v = praw[it][j];
+                if constexpr ((VGPT_BX_DEBUG & 1) == 0) {
+                    v = __builtin_fmaf(v, sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
+                    if (a.gn_silu) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+                    v = pin[it] ? v : 0.f;   // zero padding applies to the normalised activation
+                }
                 const bf16 hi = f2bf(v);
                 vh[j] = hi;
-                vl[j] = f2bf(v - bf2f(hi));
+                vl[j] = (VGPT_BX_DEBUG & 1) ? hi : f2bf(v - bf2f(hi));
             }
             const int o = pix * BX_PSTRIDE + q * 16;
             *reinterpret_cast<bf16x8*>(sPh + o) = vh;
@@ -361,31 +371,56 @@ __global__ __launch_bounds__(512, 1) void conv_bx3_kernel(ConvBxArgs a) {
                 const bf16x8 pl = *reinterpret_cast<const bf16x8*>(sPl + o);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ph, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], pl, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], ph, acc[i][j], 0, 0, 0);
+                    if constexpr ((VGPT_BX_DEBUG & 16) != 0) {
+                        acc[i][j][0] += bf2f(wl[i][0]) * bf2f(ph[0]) + bf2f(wh[i][1]) * bf2f(pl[1]);   // keeps the reads alive
+                        continue;
+                    }
+                    // pixels are the MFMA's rows: a lane ends up with FOUR CONSECUTIVE PIXELS (kq*4 + r) of channel l16
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, wl[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, wh[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, wh[i], acc[i][j], 0, 0, 0);
                 }
             }
         }
     }
 
-    // ---- epilogue: lane holds pixel l16 of sub-tile j, channels (kq*4 + r) of sub-tile i ----
-#pragma unroll
-    for (int j = 0; j < 2 * RPW; ++j) {
-        const int oy = oy0 + RPW * wave + (j >> 1), ox = ox0 + (j & 1) * 16 + l16;
-        if (oy >= a.Hout || ox >= a.Wout) continue;
+    if constexpr ((VGPT_BX_DEBUG & 8) != 0) {
+        float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + i * 16 + kq * 4 + r;
-                if (co >= a.Cout) continue;
-                const int64_t o = (((int64_t)n * a.Cout + co) * a.Hout + oy) * a.Wout + ox;
-                float v = acc[i][j][r];
-                if (a.bias) v += a.bias[co];
-                if (a.resid) v += a.resid[o];
-                a.y[o] = v;
+            for (int j = 0; j < 2 * RPW; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 12345.678f) a.y[0] = t;
+        return;
+    }
+    // ---- epilogue: lane holds channel l16 of sub-tile i, pixels kq*4 .. +3 of sub-tile j: 16-byte stores ----
+    const bool vec = (a.Wout & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = co0 + i * 16 + l16;
+        if (co >= a.Cout) continue;
+        const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2 * RPW; ++j) {
+            const int oy = oy0 + RPW * wave + (j >> 1), ox = ox0 + (j & 1) * 16 + kq * 4;
+            if (oy >= a.Hout || ox >= a.Wout) continue;
+            const int64_t o = (((int64_t)n * a.Cout + co) * a.Hout + oy) * a.Wout + ox;
+            f32x4 v = acc[i][j];
+            if (vec) {   // Wout % 4 == 0: the four pixels are inside the row together, 16-byte aligned
+                if (a.resid) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(a.resid + o);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bv;
+                *reinterpret_cast<f32x4*>(a.y + o) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ox + r < a.Wout) a.y[o + r] = v[r] + bv + (a.resid ? a.resid[o + r] : 0.f);
             }
+        }
     }
 }
 
@@ -540,30 +575,41 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bx3_kernel(Conv1Args a) {
             const bf16x8 pl = *reinterpret_cast<const bf16x8*>(sPl + o);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ph, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], pl, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], ph, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, wl[i], acc[i][j], 0, 0, 0);   // pixels = rows
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, wh[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, wh[i], acc[i][j], 0, 0, 0);
             }
         }
     }
 
-    // ---- epilogue: lane holds pixel l16 of sub-tile j, channels (kq*4 + r) of sub-tile i ----
+    // ---- epilogue: lane holds channel l16 of sub-tile i, pixels kq*4 .. +3 of sub-tile j: 16-byte stores ----
+    const bool vec = (a.HW & 3) == 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = p0 + wave * 64 + j * 16 + l16;
-        if (p >= a.HW) continue;
+    for (int i = 0; i < 4; ++i) {
+        const int co = co0 + i * 16 + l16;
+        if (co >= a.Cout) continue;
+        const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const int p = p0 + wave * 64 + j * 16 + kq * 4;
+            if (p >= a.HW) continue;
+            const int64_t o = ((int64_t)n * a.Cout + co) * a.HW + p;
+            f32x4 v = acc[i][j];
+            if (vec) {
+                if (a.resid) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(a.resid + o);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + i * 16 + kq * 4 + r;
-                if (co >= a.Cout) continue;
-                const int64_t o = ((int64_t)n * a.Cout + co) * a.HW + p;
-                float v = acc[i][j][r];
-                if (a.bias) v += a.bias[co];
-                if (a.resid) v += a.resid[o];
-                a.y[o] = v;
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bv;
+                *reinterpret_cast<f32x4*>(a.y + o) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (p + r < a.HW) a.y[o + r] = v[r] + bv + (a.resid ? a.resid[o + r] : 0.f);
             }
+        }
     }
 }
 
