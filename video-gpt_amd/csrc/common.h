@@ -63,7 +63,9 @@ __device__ __forceinline__ float half_sum(float v) {
 
 __device__ __forceinline__ float act_apply(float x, int act) {
     switch (act) {
-        case VGPT_ACT_SILU: return x / (1.0f + __expf(-x));
+        // x * rcp(1 + exp(-x)): v_rcp_f32 (1 ulp) instead of the IEEE division's correction sequence (half the
+        // instructions of the gated GEMM's epilogue); the result is rounded to bf16 right after
+        case VGPT_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
         case VGPT_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
         case VGPT_ACT_GELU_TANH: {
             float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
