@@ -214,7 +214,7 @@ def bench_vae(args, rank, world, device, D):
 
 
 def bench_stage1(args, rank, world, device, M, P, D, ops):
-    line = measure_stage1(args.steps, args.warmup, args.layers, rank, world, device, M, P, D)
+    line = measure_stage1(args.steps, args.warmup, args.layers, rank, world, device, M, P, D, grad_ckpt=args.grad_ckpt)
     if args.rehearse_on_one_gpu:
         line["config"]["workload"] += " [REHEARSAL: ranks share one GPU over gloo: INVALID]"
     if rank == 0:
@@ -224,7 +224,7 @@ def bench_stage1(args, rank, world, device, M, P, D, ops):
         torch.distributed.destroy_process_group()
 
 
-def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=None, F=8, hw=(32, 32), bs=2):
+def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=None, F=8, hw=(32, 32), bs=2, grad_ckpt=False):
     """cfg-3: stage-1 pre-training, bs 2 clips/GPU of F=8 frames at 256^2 (2 x 3870 tokens), bf16 params with fp32
     master AdamW, gradient all-reduce over RCCL (one bucket per decoder layer, overlapped with backward).
     One step = forward + backward + all-reduce + clip + AdamW.  samples/sec = 2*world*steps/time."""
@@ -247,7 +247,7 @@ def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=No
     x1, x0, clean, x0i = mk(nd), mk(nd), mk(nc), mk(nc)
     t = torch.rand(nd, generator=g).to(device)
     ti = (0.9 + 0.1 * torch.rand(nc, generator=g)).to(device)
-    trainer = TR.Stage1Trainer(model, lr=1e-4, weight_decay=0.1, max_grad_norm=1.0)
+    trainer = TR.Stage1Trainer(model, lr=1e-4, weight_decay=0.1, max_grad_norm=1.0, gradient_checkpointing=grad_ckpt)
     for _ in range(warmup):
         loss = trainer.step(batch, x1, x0, t, clean, x0i, ti)
     losses = []
@@ -270,6 +270,7 @@ def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=No
                 "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"stage-1-layout pretrain step: bs {bs}/GPU x F={F} frames {hw[0] * 8}^2 ({real} tokens/GPU), "
                                        f"Phi-3-mini-class denoiser {nl} layers, bf16 + fp32-master AdamW, clip 1.0"
+                                       + (", gradient checkpointing per decoder layer" if grad_ckpt else "")
                                        + ("" if nl == 32 else " [DEBUG layer count: INVALID]"),
                            "global_batch": world * bs, "parallelism": f"dp{world}", "loss_first_last": loss_v},
                 "roofline": {"bound": "mfma", "kernel": "whole step (fwd + bwd ~ 3 x fwd FLOPs)", "achieved": round(3 * fwd / (ms * 1e-3) / 1e12, 1),
@@ -322,6 +323,8 @@ def main():
     ap.add_argument("--attn-precision", choices=["bf16", "fp8"], default="bf16",
                     help="infer / pipeline workloads: operands of the sampler steps' attention (fp8 = the cfg-5 option; "
                          "the headline metric is quoted on bf16)")
+    ap.add_argument("--grad-ckpt", action="store_true",
+                    help="stage1 / stage4 workloads: gradient checkpointing per decoder layer (OmniGen/transformer.py:182-192)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug only: all ranks share cuda:0 and talk over gloo (numbers are INVALID as a benchmark)")
     ap.add_argument("--no-vae", action="store_true", help="infer workload: skip the VAE decode / encode leg of the JSON line")
@@ -365,7 +368,9 @@ def main():
     if args.workload == "pipeline":
         return bench_pipeline(args, rank, world, device, M, P, D)
     if args.workload == "stage4":   # cfg-4 shapes: 512^2, 16-frame clips (L = 31 806), bs 1/GPU, stage-1 interleaved layout
-        line = measure_stage1(args.steps, args.warmup, args.layers, rank, world, device, M, P, D, F=16, hw=(64, 64), bs=1)
+        line = measure_stage1(args.steps, args.warmup, args.layers, rank, world, device, M, P, D, F=16, hw=(64, 64), bs=1,
+                              grad_ckpt=args.grad_ckpt)
+        line["peak_memory_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
         if rank == 0:
             print(json.dumps(line), flush=True)
         return
