@@ -186,3 +186,17 @@ def test_attention_backward_is_linear_in_dout(mods):
     r = torch.empty_like(qkv)
     T.attention_qkv_bwd(vfix, out, ones, lse, delta, r, pm, nh, nh, hd)
     assert float(r[..., : 2 * nh * hd].float().abs().max()) < 2e-2
+
+
+def test_fp8_attention_at_full_width(mods, cfg2):
+    """cfg-2 geometry, two full-width layers (32 heads x 96), 3 Euler steps: the sampler with MX-fp8 attention operands
+    against the bf16 sampler on the same noise.  The stated tolerance of the option on sampled latents is rel-L2 <= 6e-2
+    (tests/test_attn_fp8_gpu.py); graph replay equals eager launches bit for bit in this mode too."""
+    ref = _run(_engine(mods, cfg2, reuse_condition_prefix=True), use_graph=False)
+    e8 = _engine(mods, cfg2, reuse_condition_prefix=True, attention_precision="fp8")
+    out8 = _run(e8, use_graph=False)
+    e8g = _engine(mods, cfg2, reuse_condition_prefix=True, attention_precision="fp8")
+    assert torch.equal(_run(e8g, use_graph=True), out8)
+    rel = float((out8.double() - ref.double()).norm() / ref.double().norm())
+    print(f"fp8-attention sampler vs bf16 sampler at full width: rel-L2 {rel:.3e}")
+    assert torch.isfinite(out8).all() and 0 < rel < 6e-2
