@@ -185,13 +185,15 @@ int vgpt_attn_fwd_plan(const void* q, const void* k, const void* v, void* o, flo
  * scale, products on the block-scaled MFMA (2x the bf16 rate), fp32 scores / statistics / accumulator.  Two calls:
  * vgpt_attn_fp8_quantize turns the (RoPE-rotated) q / k / v views into `workspace`
  * (vgpt_attn_fp8_workspace_bytes(B, L, n_heads, n_kv_heads, head_dim) bytes, 256-byte aligned; the softmax scale is
- * folded into Q there), vgpt_attn_fwd_plan_fp8 computes the rows of a plan (items / item_summary / order of
+ * folded into Q there; only rows >= row_begin, a multiple of 64, are (re)written: a cached prefix keeps its bytes),
+ * vgpt_attn_fwd_plan_fp8 computes the rows of a plan (items / item_summary / order of
  * vgpt_attn_plan_build) from it.  No LSE output: the training path stays bf16.  Replaces the same reference lines as
  * vgpt_attn_blockmask_fwd (LVM/transform/sdpa_transform.py:78-86,152). */
 int64_t vgpt_attn_fp8_workspace_bytes(int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim);
-int vgpt_attn_fp8_quantize(const void* q, const void* k, const void* v, void* workspace, int64_t B, int64_t L, int n_heads,
-                           int n_kv_heads, int head_dim, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
-                           int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, float scale, void* stream);
+int vgpt_attn_fp8_quantize(const void* q, const void* k, const void* v, void* workspace, int64_t B, int64_t L,
+                           int64_t row_begin, int n_heads, int n_kv_heads, int head_dim, int64_t q_sb, int64_t q_sh,
+                           int64_t q_ss, int64_t k_sb, int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss,
+                           float scale, void* stream);
 int vgpt_attn_fwd_plan_fp8(const void* workspace, void* o, const uint32_t* bits, const int32_t* items,
                            const uint16_t* item_summary, const int32_t* order, int64_t n_items, int64_t B, int64_t L,
                            int n_heads, int n_kv_heads, int head_dim, int64_t o_sb, int64_t o_sh, int64_t o_ss, void* stream);

@@ -33,7 +33,7 @@ def report(name, us, flops):
 
 def fp8_kernel_only(qkv, pm, plan, out, q_start):
     B, L, w = qkv.shape
-    ws = ops._FP8_WS[(qkv.device, int(L_.load().vgpt_attn_fp8_workspace_bytes(B, L, nh, nh, hd)))]
+    ws = ops._FP8_WS[(qkv.device, B, L, nh, nh, hd)]
     hq = nh * hd
     return lambda: L_.call("vgpt_attn_fwd_plan_fp8", ws.data_ptr(), out.data_ptr() - q_start * hq * 2, pm.bits.data_ptr(),
                            plan.items.data_ptr(), plan.summary.data_ptr(), plan.order.data_ptr(), plan.n_items, B, L, nh, nh, hd,

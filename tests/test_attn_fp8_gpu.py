@@ -108,7 +108,7 @@ def test_quantiser_layout_and_rounding(ops):
     w = (nh + 2 * nkv) * D
     kq = dq.data_ptr() + nh * D * 2
     vq = kq + nkv * D * 2
-    L_.call("vgpt_attn_fp8_quantize", dq.data_ptr(), kq, vq, ws.data_ptr(), B, L, nh, nkv, D, L * w, D, w, L * w, D, w, L * w, D, w,
+    L_.call("vgpt_attn_fp8_quantize", dq.data_ptr(), kq, vq, ws.data_ptr(), B, L, 0, nh, nkv, D, L * w, D, w, L * w, D, w, L * w, D, w,
             float(scale), ops._stream())
     raw = ws.cpu().numpy()
     tab = e4m3_table()
@@ -203,6 +203,24 @@ def test_attention_fp8_late_spike_and_masked_first_tile(ops):
     ref = ref_attention(q, k, v, torch.from_numpy(m), 1 / math.sqrt(D)).transpose(1, 2).reshape(B, L, -1)
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 8e-2
+
+
+def test_quantiser_row_begin_keeps_earlier_rows(ops):
+    """vgpt_attn_fp8_quantize(row_begin): rows below row_begin keep the bytes the workspace holds (the engine's cached
+    prefix), rows from it on are rewritten; same result as one full pass."""
+    B, L, nh, nkv = 1, 300, 2, 2
+    qkv = torch.randn(B, L, (nh + 2 * nkv) * D, generator=g(31)).to(BF).to(DEV)
+    full = ops.attention_fp8_workspace(B, L, nh, nkv, D, DEV).zero_()
+    ops.attention_fp8_quantize(qkv, full, nh, nkv, D)
+    part = full.clone()
+    qkv2 = qkv.clone()
+    qkv2[:, 128:] = torch.randn(B, L - 128, qkv.shape[-1], generator=g(32)).to(BF).to(DEV)   # rows >= 128 change
+    ops.attention_fp8_quantize(qkv2, part, nh, nkv, D, row_begin=128)
+    want = ops.attention_fp8_workspace(B, L, nh, nkv, D, DEV).zero_()
+    ops.attention_fp8_quantize(qkv2, want, nh, nkv, D)
+    assert torch.equal(part, want) and not torch.equal(part, full)
+    with pytest.raises(Exception, match="multiple of 64"):
+        ops.attention_fp8_quantize(qkv, full, nh, nkv, D, row_begin=100)
 
 
 def test_attention_fp8_rejects_other_head_dims(ops):

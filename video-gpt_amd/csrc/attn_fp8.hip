@@ -56,6 +56,7 @@ struct QuantArgs {
     const bf16* q; const bf16* k; const bf16* v;
     uint8_t* q8; uint8_t* qs; uint8_t* kv;
     int B, L, n_heads, n_kv_heads, nkt;
+    int kt0;   // first key tile / 64-row query block to (re)quantise: earlier rows keep what the workspace holds
     int64_t q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss;
     float q_mul;   // softmax scale * log2(e), folded into Q before rounding
 };
@@ -63,10 +64,11 @@ struct QuantArgs {
 // grid.x < B * n_kv_heads * nkt: one K/V tile record; the remaining blocks: 64 query rows of one head each
 __global__ __launch_bounds__(256) void attn_fp8_quantize_kernel(QuantArgs a) {
     const int tid = threadIdx.x;
-    const int n_rec = a.B * a.n_kv_heads * a.nkt;
+    const int nt = a.nkt - a.kt0;   // tiles / row blocks this launch covers
+    const int n_rec = a.B * a.n_kv_heads * nt;
     if ((int)blockIdx.x < n_rec) {
-        const int kt = blockIdx.x % a.nkt, kvh = (blockIdx.x / a.nkt) % a.n_kv_heads, b = blockIdx.x / (a.nkt * a.n_kv_heads);
-        uint8_t* rec = a.kv + (int64_t)blockIdx.x * REC;
+        const int kt = a.kt0 + blockIdx.x % nt, kvh = (blockIdx.x / nt) % a.n_kv_heads, b = blockIdx.x / (nt * a.n_kv_heads);
+        uint8_t* rec = a.kv + (((int64_t)b * a.n_kv_heads + kvh) * a.nkt + kt) * REC;
         // the V tile (64 keys x 96 d) goes through LDS: it is read by columns below, and from global memory that would be
         // 2-byte accesses a row stride apart
         __shared__ __attribute__((aligned(16))) bf16 vt[64 * D];
@@ -128,9 +130,8 @@ __global__ __launch_bounds__(256) void attn_fp8_quantize_kernel(QuantArgs a) {
     }
     // Q: block = 64 rows of one (batch, head); thread = (row, block of 32 d) for tid < 192
     if (tid >= 192) return;
-    const int blocks_per_head = (a.L + 63) / 64;
     const int qb = blockIdx.x - n_rec;
-    const int rb = qb % blocks_per_head, head = (qb / blocks_per_head) % a.n_heads, b = qb / (blocks_per_head * a.n_heads);
+    const int rb = a.kt0 + qb % nt, head = (qb / nt) % a.n_heads, b = qb / (nt * a.n_heads);
     const int row = rb * 64 + tid / 3, blk = tid % 3;
     if (row >= a.L) return;
     const bf16* p = a.q + (int64_t)b * a.q_sb + (int64_t)head * a.q_sh + (int64_t)row * a.q_ss + blk * 32;
@@ -336,28 +337,31 @@ VGPT_EXPORT int64_t vgpt_attn_fp8_workspace_bytes(int64_t B, int64_t L, int n_he
 }
 
 VGPT_EXPORT int vgpt_attn_fp8_quantize(const void* q, const void* k, const void* v, void* workspace, int64_t B, int64_t L,
-                                       int n_heads, int n_kv_heads, int head_dim, int64_t q_sb, int64_t q_sh, int64_t q_ss,
-                                       int64_t k_sb, int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss,
-                                       float scale, void* stream) {
+                                       int64_t row_begin, int n_heads, int n_kv_heads, int head_dim, int64_t q_sb,
+                                       int64_t q_sh, int64_t q_ss, int64_t k_sb, int64_t k_sh, int64_t k_ss, int64_t v_sb,
+                                       int64_t v_sh, int64_t v_ss, float scale, void* stream) {
     VGPT_REQUIRE(q && k && v && workspace, VGPT_ERR_INVALID, "vgpt_attn_fp8_quantize: null pointer");
     VGPT_REQUIRE(head_dim == D, VGPT_ERR_UNSUPPORTED, "vgpt_attn_fp8_quantize: head_dim must be 96 (got %d)", head_dim);
     VGPT_REQUIRE(B > 0 && L > 0 && L <= (1 << 22) && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0,
                  VGPT_ERR_INVALID, "vgpt_attn_fp8_quantize: bad shape");
     VGPT_REQUIRE(scale > 0.f, VGPT_ERR_INVALID, "vgpt_attn_fp8_quantize: scale must be positive");
+    VGPT_REQUIRE(row_begin >= 0 && row_begin <= L && row_begin % 64 == 0, VGPT_ERR_INVALID,
+                 "vgpt_attn_fp8_quantize: row_begin must be a multiple of 64 in [0, L]");
+    if (row_begin >= L) return VGPT_OK;
     const int64_t strides[] = {q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss};
     for (int64_t st : strides)
         VGPT_REQUIRE(st % 8 == 0, VGPT_ERR_UNSUPPORTED, "vgpt_attn_fp8_quantize: q/k/v strides must be multiples of 8 elements");
     VGPT_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)workspace) & 15) == 0, VGPT_ERR_UNSUPPORTED,
                  "vgpt_attn_fp8_quantize: q, k, v and the workspace must be 16-byte aligned");
-    const int64_t nkt = cdiv(L, 64);
-    const int64_t n_rec = B * n_kv_heads * nkt, n_q = B * n_heads * nkt;
+    const int64_t nkt = cdiv(L, 64), nt = nkt - row_begin / 64;
+    const int64_t n_rec = B * n_kv_heads * nt, n_q = B * n_heads * nt;
     VGPT_REQUIRE(n_rec + n_q < (1ll << 31), VGPT_ERR_UNSUPPORTED, "vgpt_attn_fp8_quantize: problem too large");
     QuantArgs a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v;
     a.q8 = (uint8_t*)workspace;
     a.qs = a.q8 + align256(B * n_heads * L * D);
     a.kv = a.qs + align256(B * n_heads * L * 4);
-    a.B = (int)B; a.L = (int)L; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.nkt = (int)nkt;
+    a.B = (int)B; a.L = (int)L; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.nkt = (int)nkt; a.kt0 = (int)(row_begin / 64);
     a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
     a.v_sb = v_sb; a.v_sh = v_sh; a.v_ss = v_ss;
     a.q_mul = scale * 1.4426950408889634f;

@@ -235,6 +235,12 @@ class StaticDenoiser:
             Ma = self.Ma
             self.hid, self.nrm, self.ctx, self.act = e(1, Ma, H), e(1, Ma, H), e(1, Ma, nq * hd), e(1, Ma, I)
             self.qkv_full = torch.zeros(cfg.num_hidden_layers, L, (nq + 2 * nk) * hd, dtype=BF16, device=dev)
+            if self.attn_fp8:
+                # one fp8 workspace per layer (51 MB at cfg-2): prefill() quantises the step-invariant rows once, a step
+                # only the rows from the first one it writes on (the time rows of a hoisted layout sit below S)
+                self.fp8_ws = [ops.attention_fp8_workspace(1, L, nq, nk, hd, dev) for _ in range(cfg.num_hidden_layers)]
+                first = (self.S0 + self.hoist["nf"]) if self.hoist else S
+                self.fp8_from = first // 64 * 64
         else:
             self.hid = e(B, L, H)
             self.nrm = e(B, L, H)
@@ -280,6 +286,8 @@ class StaticDenoiser:
             full = self.qkv_full[li]
             ops.rmsnorm(hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=nrm)
             ops.linear_qkv_rope(nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=full[:S])
+            if self.attn_fp8:   # the sampler steps read the prefix's K / V from the fp8 workspace of this layer
+                ops.attention_fp8_quantize(full.view(1, self.L, -1), self.fp8_ws[li], nq, nk, hd)
             ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, 0, ctx, segments=seg)
             ops.linear(ctx, at.o_proj.weight, residual=hid, out=hid)
             ops.rmsnorm(hid, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon, out=nrm)
@@ -468,8 +476,9 @@ class StaticDenoiser:
                 live = full[S:]                                  # this step's q/k/v rows, behind the cached prefix
                 ops.linear_qkv_rope(self.nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=live)
                 if self.attn_fp8:
+                    # the prefix rows were quantised once by prefill(); a step re-quantises from the first row it writes
                     ops.attention_qkv_fp8(full.view(1, self.L, -1), self.pm, nq, nk, hd, out=self.ctx, q_start=S,
-                                          segments=self.seg_live)
+                                          segments=self.seg_live, workspace=self.fp8_ws[li_], quant_from=self.fp8_from)
                 else:
                     ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, S, self.ctx, segments=self.seg_live)
             else:

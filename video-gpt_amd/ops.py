@@ -368,14 +368,40 @@ def attention_qkv_range(qkv_full: torch.Tensor, pm: PackedMask, n_heads: int, n_
     return out_active
 
 
+def attention_fp8_workspace(B: int, L: int, n_heads: int, n_kv_heads: int, head_dim: int, device) -> torch.Tensor:
+    """Caller-owned workspace of the MX-fp8 attention, sized by the library (vgpt_attn_fp8_workspace_bytes)."""
+    nbytes = int(_lib.load().vgpt_attn_fp8_workspace_bytes(B, L, n_heads, n_kv_heads, head_dim))
+    if nbytes < 0:
+        raise VgptError(f"attention_fp8: unsupported shape (head_dim {head_dim}: the fp8 kernel is built for 96)")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def attention_fp8_quantize(qkv: torch.Tensor, ws: torch.Tensor, n_heads: int, n_kv_heads: int, head_dim: int,
+                           scale: Optional[float] = None, row_begin: int = 0):
+    """Q / K / V of the fused (B, L, .) buffer, rows >= row_begin (a multiple of 64), into the fp8 workspace."""
+    _chk(qkv, BF16, "attention.qkv")
+    B, L, width = qkv.shape
+    hq = n_heads * head_dim
+    kq = qkv.data_ptr() + hq * 2
+    vq = kq + n_kv_heads * head_dim * 2
+    sb, ss = L * width, width
+    if scale is None:
+        scale = 1.0 / math.sqrt(head_dim)
+    call("vgpt_attn_fp8_quantize", qkv.data_ptr(), kq, vq, ws.data_ptr(), B, L, int(row_begin), n_heads, n_kv_heads, head_dim,
+         sb, head_dim, ss, sb, head_dim, ss, sb, head_dim, ss, float(scale), _stream())
+
+
 _FP8_WS = {}
 
 
 def attention_qkv_fp8(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: int, head_dim: int,
-                      scale: Optional[float] = None, out: Optional[torch.Tensor] = None, q_start: int = 0, segments=None):
+                      scale: Optional[float] = None, out: Optional[torch.Tensor] = None, q_start: int = 0, segments=None,
+                      workspace: Optional[torch.Tensor] = None, quant_from: int = 0):
     """MX-fp8 attention (include/vgpt.h, vgpt_attn_fp8_quantize + vgpt_attn_fwd_plan_fp8) on the fused
     (B, L, (n_q + 2 n_kv) * hd) projection buffer (RoPE applied): rows [q_start, L) of `segments` (default: all of
-    them) against all L keys.  `out` holds rows [q_start, L).  Inference only; tolerance of fp8 operands."""
+    them) against all L keys.  `out` holds rows [q_start, L).  workspace / quant_from: a caller-owned workspace whose rows
+    below quant_from (a multiple of 64) already hold their quantised form (the engine's cached prefix); by default a
+    shared scratch workspace is filled from row 0.  Inference only; tolerance of fp8 operands."""
     _chk(qkv, BF16, "attention.qkv")
     B, L, width = qkv.shape
     if width != (n_heads + 2 * n_kv_heads) * head_dim or B != pm.B or L != pm.L:
@@ -385,20 +411,15 @@ def attention_qkv_fp8(qkv: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_head
     hq = n_heads * head_dim
     if out is None:
         out = torch.empty(B, L - q_start, hq, dtype=BF16, device=qkv.device)
-    if scale is None:
-        scale = 1.0 / math.sqrt(head_dim)
-    nbytes = int(_lib.load().vgpt_attn_fp8_workspace_bytes(B, L, n_heads, n_kv_heads, head_dim))
-    if nbytes < 0:
-        raise VgptError(f"attention_fp8: unsupported shape (head_dim {head_dim}: the fp8 kernel is built for 96)")
-    key = (qkv.device, nbytes)
-    ws = _FP8_WS.get(key)
+    ws = workspace
     if ws is None:
-        ws = _FP8_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
-    kq = qkv.data_ptr() + hq * 2
-    vq = kq + n_kv_heads * head_dim * 2
-    sb, ss = L * width, width
-    call("vgpt_attn_fp8_quantize", qkv.data_ptr(), kq, vq, ws.data_ptr(), B, L, n_heads, n_kv_heads, head_dim,
-         sb, head_dim, ss, sb, head_dim, ss, sb, head_dim, ss, float(scale), _stream())
+        if quant_from:
+            raise VgptError("attention_fp8: quant_from needs a caller-owned workspace")
+        key = (qkv.device, B, L, n_heads, n_kv_heads, head_dim)
+        ws = _FP8_WS.get(key)
+        if ws is None:
+            ws = _FP8_WS[key] = attention_fp8_workspace(B, L, n_heads, n_kv_heads, head_dim, qkv.device)
+    attention_fp8_quantize(qkv, ws, n_heads, n_kv_heads, head_dim, scale, quant_from)
     plan = pm.plan(segments if segments is not None else (tuple((b, q_start, L) for b in range(B))))
     if plan.n_items:
         call("vgpt_attn_fwd_plan_fp8", ws.data_ptr(), out.data_ptr() - q_start * hq * 2, pm.bits.data_ptr(),
