@@ -539,6 +539,8 @@ def main():
                 "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "mfma_busy_pmc": mfma_busy,
                 "launches": n_launch, "avg_launch_us": round(t_gemm / max(n_launch, 1) * 1e6, 1),
+                "peak_note": "2500 = nominal dense bf16 peak (MI355X_MICROARCH.md); nothing-but-MFMA loops on random operands "
+                             "sustain 1840-1930 TFLOP/s on this part (scripts/probes/mfma_shape_rate.hip, DESIGN.md section 4)",
                 "avg_launch_us_by_kind_back_to_back": b2b,
                 "avg_launch_us_event_pair_per_launch": round(t_bracketed / max(n_launch, 1) * 1e6, 1),
                 "alg_flops_per_launch": alg / max(n_launch, 1),
