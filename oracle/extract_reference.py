@@ -367,3 +367,104 @@ def reference_single_target_batch(n_images: int, side: int, out_hw, use_cfg: boo
                           use_img_cfg=use_cfg)
     return P.prompt_condition_inference(proc, [prompt, ""], [images, None] if images is not None else None,
                                         height=out_hw[0], width=out_hw[1], use_img_cfg=use_cfg)
+
+
+# ------------------------------------------------------------------------------------------------
+# LVMPipeline.prompt_condition_frame_block_autoregressive_inference (LVM/pipeline.py:347-595) -- the reference's own
+# orchestration (windowing, prompts, noise draws, re-noising, CFG duplication, halving, decode / uint8), executed on CPU
+# with the reference's LVMProcessor, LVMCollator, LVMScheduler and LVM.  Stand-ins for what the container lacks:
+#   * torchvision.transforms -> the three transforms the processor composes (Lambda, ToTensor, Normalize), restated;
+#   * the tokenizer -> StubTokenizer above;  * diffusers' AutoencoderKL -> the oracle's VAE restatement (oracle/vae_ref.py:
+#     third-party arithmetic, unpinned as DESIGN.md §2 says) behind the three members the pipeline touches
+#     (.config, .encode(x).latent_dist.sample(), .decode(z).sample), logging the noise every sample() draws.
+# ------------------------------------------------------------------------------------------------
+class _Transforms:
+    """torchvision.transforms.{Compose, Lambda, ToTensor, Normalize} as LVM/processor.py:31-35 uses them."""
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class Lambda:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def __call__(self, x):
+            return self.fn(x)
+
+    class ToTensor:
+        def __call__(self, pil):   # HWC uint8 -> CHW float in [0, 1]
+            return torch.from_numpy(np.ascontiguousarray(np.array(pil))).permute(2, 0, 1).float().div(255.0)
+
+    class Normalize:
+        def __init__(self, mean, std, inplace=False):
+            self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+        def __call__(self, t):
+            return (t - self.mean) / self.std
+
+
+class OracleVaeStandIn(torch.nn.Module):
+    """The members of diffusers' AutoencoderKL that LVMPipeline touches, over oracle/vae_ref.py."""
+
+    def __init__(self, params, cfg):
+        super().__init__()
+        self.p, self.cfg = params, cfg
+        self.config = types.SimpleNamespace(scaling_factor=cfg.scaling_factor, shift_factor=cfg.shift_factor)
+        self.noise_log = []
+
+    def encode(self, x):
+        from . import vae_ref as VR
+        mean, logvar = VR.encode_moments(self.p, self.cfg, x.float())
+        log = self.noise_log
+
+        class _Dist:
+            def sample(self_inner):
+                n = torch.randn(mean.shape)      # diffusers draws from the global generator (randn_tensor, generator=None)
+                log.append(n.clone())
+                return VR.sample_latent(mean, logvar, n)
+        return types.SimpleNamespace(latent_dist=_Dist())
+
+    def decode(self, z):
+        from . import vae_ref as VR
+        return types.SimpleNamespace(sample=VR.decode(self.p, self.cfg, z.float()))
+
+
+def reference_pipeline(cfg, params, vae_params, vae_cfg):
+    """(pipe, log): the reference's LVMPipeline over its own processor / collator / scheduler / LVM (tiny, CPU fp32);
+    log collects, per round, what the scheduler was called with and returned."""
+    from PIL import Image
+    model, ns = build_reference_model(cfg, params, "LVM")
+    proc_ns = _extract("LVM/processor.py", ["LVMCollator", "LVMProcessor"],
+                       extra_ns={"PreTrainedTokenizer": object, "Image": Image, "transforms": _Transforms,
+                                 "InterpolationMode": None, "snapshot_download": None, "AutoTokenizer": None, "os": os,
+                                 "logging": None})
+    sched_cls = scheduler_class()
+    log = {"rounds": []}
+
+    class RecordingScheduler(sched_cls):
+        def __call__(self, z, func, model_kwargs, **kw):
+            z_in = [t.clone() for t in z]      # the reference sampler updates the list in place
+            out = super().__call__(z, func, model_kwargs, **kw)
+            log["rounds"].append({"latents": z_in,
+                                  "input_img_latents": [t.clone() for t in model_kwargs["input_img_latents"]],
+                                  "samples": [t.clone() for t in out]})
+            return out
+
+    logger = types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None)
+    import inspect
+    pns = _extract("LVM/pipeline.py", ["LVMPipeline"],
+                   extra_ns={"Image": Image, "os": os, "inspect": inspect, "Any": object, "Callable": object,
+                             "snapshot_download": None, "LoraConfig": None, "PeftModel": None, "AutoencoderKL": object,
+                             "load_file": None, "LVMProcessor": proc_ns.LVMProcessor, "LVM": ns.LVM,
+                             "LVMScheduler": RecordingScheduler, "hccl_info": ns.hccl_info, "logger": logger,
+                             "EXAMPLE_DOC_STRING": "", "replace_example_docstring": lambda s: (lambda f: f)})
+    vae = OracleVaeStandIn(vae_params, vae_cfg)
+    processor = proc_ns.LVMProcessor(StubTokenizer())
+    pipe = pns.LVMPipeline(vae, model, processor, device=torch.device("cpu"))
+    return pipe, log

@@ -257,6 +257,67 @@ def loss_vectors():
     np.savez_compressed(os.path.join(OUT, "ref_loss_fbtrain_tiny.npz"), **out)
 
 
+def pipeline_vectors():
+    """The reference's LVMPipeline.prompt_condition_frame_block_autoregressive_inference (LVM/pipeline.py:347-595) executed
+    on CPU fp32 (oracle/extract_reference.py::reference_pipeline): two chained rounds (gen_nums [2, 1], window 4, CFG 1.6,
+    x1 prediction, 2 Euler steps, condition re-noising 0.1) on the tiny denoiser + tiny /8 VAE stand-in.  use_kv_cache is
+    off: the reference sampler passes past_key_values=None at every step (LVM/scheduler.py:174), so its cache only ever
+    holds one call's keys and changes no result, and the installed transformers' DynamicCache lacks the 4.47.1 methods
+    new_forward calls on it.  Recorded: input frames, every global-generator noise draw in order (VAE posterior samples,
+    re-noising), per round what the scheduler received and returned, the returned images."""
+    from PIL import Image
+    from oracle import vae_ref as VR
+    cfg, vcfg = R.TINY, VR.TINY_VAE8
+    p = {k: v.to(torch.bfloat16).float() for k, v in R.make_params(cfg, 0).items()}
+    vp = VR.make_vae_params(vcfg, seed=2)
+    pipe, log = X.reference_pipeline(cfg, p, vp, vcfg)
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
+    renoise = []
+    orig = torch.randn_like
+
+    def recording_randn_like(t, *a, **k):
+        n = orig(t, *a, **k)
+        renoise.append(n.clone())
+        return n
+    torch.randn_like = recording_randn_like
+    torch.manual_seed(1234)
+    try:
+        out = pipe.prompt_condition_frame_block_autoregressive_inference(
+            input_images=[Image.fromarray(f) for f in frames], height=64, width=64, gen_nums=[2, 1], num_inference_steps=2,
+            use_img_guidance=True, img_guidance_scale=1.6, dtype=torch.float32, seed=42, output_type="pil",
+            prediction_type="x1", clean_image_noise_level=0.1, max_frame_window=4, use_kv_cache=False)
+    finally:
+        torch.randn_like = orig
+    d = {"frames_in": frames, "vae_noise": torch.stack(pipe.vae.noise_log).numpy(), "renoise": torch.stack(renoise).numpy(),
+         "images_out": np.stack([np.array(im) for im in out]), "n_rounds": np.array(len(log["rounds"]))}
+    for k, r in enumerate(log["rounds"]):
+        d[f"r{k}_latents"] = torch.cat(r["latents"]).numpy()
+        d[f"r{k}_input_img_latents"] = torch.cat(r["input_img_latents"]).numpy()
+        d[f"r{k}_samples"] = torch.cat(r["samples"]).numpy()
+    np.savez_compressed(os.path.join(OUT, "ref_pipeline_tiny.npz"), **d)
+
+    # LVMPipeline.__call__ (LVM/pipeline.py:138-343): single-target rounds, every generated image joining the conditions
+    pipe, log = X.reference_pipeline(cfg, p, vp, vcfg)
+    frames = np.random.default_rng(6).integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
+    renoise.clear()
+    torch.randn_like = recording_randn_like
+    torch.manual_seed(99)
+    try:
+        out = pipe(input_images=[Image.fromarray(f) for f in frames], height=64, width=64, gen_num=2, num_inference_steps=2,
+                   use_img_guidance=True, img_guidance_scale=1.6, dtype=torch.float32, seed=42, output_type="pil",
+                   prediction_type="x1", clean_image_noise_level=0.1, use_kv_cache=False)
+    finally:
+        torch.randn_like = orig
+    d = {"frames_in": frames, "vae_noise": torch.stack(pipe.vae.noise_log).numpy(), "renoise": torch.stack(renoise).numpy(),
+         "images_out": np.stack([np.array(im) for im in out]), "n_rounds": np.array(len(log["rounds"]))}
+    for k, r in enumerate(log["rounds"]):
+        d[f"r{k}_latents"] = torch.stack(r["latents"]).numpy()
+        d[f"r{k}_input_img_latents"] = torch.cat(r["input_img_latents"]).numpy()
+        d[f"r{k}_samples"] = torch.stack(r["samples"]).numpy()
+    np.savez_compressed(os.path.join(OUT, "ref_pipeline_call_tiny.npz"), **d)
+
+
 def oracle_e2e_vectors():
     """Tiny next-clip case (tests/smoke_case.py) frozen from the restatement."""
     from tests import smoke_case as SC
@@ -285,6 +346,7 @@ if __name__ == "__main__":
     leaf_vectors()
     lvm_glue_vectors()
     loss_vectors()
+    pipeline_vectors()
     oracle_e2e_vectors()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -248,3 +248,48 @@ def test_restatement_matches_reference_loss_and_gradients(name):
         assert np.abs(GC.sampled_grad(gr) - d[key]).max() <= 1e-5 * max(1.0, float(np.abs(d[key]).max())), name_
         checked += 1
     assert checked == len([k for k in pr if k != "pos_embed"])
+
+
+def test_oracle_round_composition_matches_reference_pipeline():
+    """The reference's LVMPipeline.prompt_condition_frame_block_autoregressive_inference, executed (two chained rounds,
+    tests/golden/ref_pipeline_tiny.npz), against the composition of oracle pieces the GPU pipeline tests use: condition
+    frames -> VAE posterior sample (logged noise) -> re-noising from round 1 on -> seeded clip noise -> CFG sampler -> halving
+    -> decode / uint8, the window of round 1 being the last 3 returned frames.  VAE arithmetic is the oracle's own on both
+    sides (diffusers is absent); everything else on the reference side is reference code."""
+    from oracle import vae_ref as VR
+    from tests import smoke_case as SC
+    d = np.load(os.path.join(GOLD, "ref_pipeline_tiny.npz"))
+    cfg, vcfg = R.TINY, VR.TINY_VAE8
+    p = {k: v.to(torch.bfloat16).float() for k, v in R.make_params(cfg, 0).items()}
+    vp = VR.make_vae_params(vcfg, seed=2)
+    to_t = lambda u8: (torch.from_numpy(u8.copy()).permute(2, 0, 1).float().div(255.0) - 0.5) / 0.5
+    images = [d["frames_in"][i] for i in range(2)]          # what the pipeline has "returned" so far (HWC uint8)
+    vn, rn = list(torch.from_numpy(d["vae_noise"])), list(torch.from_numpy(d["renoise"]))
+    out_images = []
+    for k, G in enumerate((2, 1)):
+        # round 1 re-encodes what round 0 RETURNED: the reference's own frames (the oracle's may differ by one grey level
+        # at a rounding edge, which would move the re-encoded latents by 1e-3)
+        prompt = images if k == 0 else [d["images_out"][i] for i in range(len(out_images))]
+        if len(prompt) + G > 4:
+            prompt = prompt[G + len(prompt) - 4:]
+        C = len(prompt)
+        cond = []
+        for img in prompt:
+            lat = VR.vae_encode(vp, vcfg, to_t(img)[None], vn.pop(0))
+            if k > 0:
+                lat = (1 - 0.1) * lat + 0.1 * rn.pop(0)
+            cond.append(lat)
+        assert torch.allclose(torch.cat(cond), torch.from_numpy(d[f"r{k}_input_img_latents"]), atol=GLUE_TOL)
+        gen = torch.Generator("cpu").manual_seed(42)        # re-seeded every round (LVM/pipeline.py:470-473)
+        z = [torch.randn(1, 4, 8, 8, generator=gen) for _ in range(G)] * 2
+        assert torch.equal(torch.cat(z), torch.from_numpy(d[f"r{k}_latents"]))
+        batch = R.collate_inference(C, G, 16, use_cfg=True, pad_id=2)
+        samples = SC.oracle_sample(cfg, p, batch, z, cond, 2, "x1")
+        assert torch.allclose(torch.cat(samples), torch.from_numpy(d[f"r{k}_samples"]), atol=GLUE_TOL)
+        if k == 0:
+            out_images += [VR.decode_to_uint8(vp, vcfg, x)[0].numpy() for x in cond]
+        out_images += [VR.decode_to_uint8(vp, vcfg, x)[0].numpy() for x in samples[:G]]
+    assert not vn and not rn
+    got = np.stack(out_images)
+    assert got.shape == d["images_out"].shape
+    assert np.abs(got.astype(np.int32) - d["images_out"].astype(np.int32)).max() <= 1   # float rounding at a grey-level edge

@@ -106,7 +106,8 @@ class LVMPipeline:
                  offload_kv_cache: bool = True, use_input_image_size_as_output: bool = False,
                  dtype: torch.dtype = torch.bfloat16, seed: int = None, output_type: str = "pil",
                  time_shifting_factor: float = 1.0, prediction_type: str = "v", clean_image_noise_level: float = None,
-                 generator_device: str = "cuda", vae_noise: Optional[List[torch.Tensor]] = None):
+                 generator_device: str = "cuda", vae_noise: Optional[List[torch.Tensor]] = None,
+                 renoise_noise: Optional[List[torch.Tensor]] = None):
         """Single-target generation, one image per round, every generated image joining the condition images of the next
         round (LVM/pipeline.py:138-343): sequence [<img> image </img> ... <|diffusion|> | time token | target tokens]
         through `LVM.forward_with_cfg`; CFG row = the empty prompt.  Returns the decoded condition images of the first
@@ -122,6 +123,7 @@ class LVMPipeline:
             use_img_guidance = False
         ori_use_img_guidance = use_img_guidance
         self.last_latents, self.last_samples = [], []
+        n_renoised = 0
         for gen_idx in range(gen_num):
             if len(output_images) != 0:
                 ori_input_images = [output_image] if ori_input_images is None else ori_input_images + [output_image]
@@ -151,7 +153,11 @@ class LVMPipeline:
                 self.last_latents.append(lat)
                 if idx >= prompt_img_len:   # a generated image fed back as a condition is re-noised (pipeline.py:256-257)
                     c = clean_image_noise_level
-                    noise = torch.randn(lat.shape, device=lat.device, dtype=torch.float32)
+                    if renoise_noise is not None:   # replay of a recorded reference run (tests)
+                        noise = renoise_noise[n_renoised].to(lat.device, torch.float32).reshape(lat.shape)
+                        n_renoised += 1
+                    else:
+                        noise = torch.randn(lat.shape, device=lat.device, dtype=torch.float32)
                     cvec = torch.full((lat.shape[0],), float(c), device=lat.device, dtype=torch.float32)
                     lat = ops_train.lerp_frames(noise, lat.float().contiguous(), cvec,
                                                  torch.empty(lat.shape, device=lat.device, dtype=torch.bfloat16)).to(dtype)
@@ -186,7 +192,10 @@ class LVMPipeline:
             dtype: torch.dtype = torch.bfloat16, seed: int = None, output_type: str = "pil",
             time_shifting_factor: float = 1.0, prediction_type: str = "v", clean_image_noise_level: float = None,
             max_frame_window: int = 16, generator_device: str = "cuda", vae_noise: Optional[List[torch.Tensor]] = None,
-            halve_without_cfg: bool = True):
+            halve_without_cfg: bool = True, renoise_noise: Optional[List[torch.Tensor]] = None):
+        """LVM/pipeline.py:347-595.  Not in the reference's signature: generator_device, vae_noise / renoise_noise (the
+        noise of the VAE posterior samples and of the condition re-noising, in draw order, for tests that replay a recorded
+        reference run) and halve_without_cfg."""
         if not use_input_image_size_as_output:
             assert height % 16 == 0 and width % 16 == 0, "The height and width must be a multiple of 16."
         if dtype != torch.bfloat16:
@@ -197,6 +206,7 @@ class LVMPipeline:
         if input_images is None:
             use_img_guidance = False
         self.last_latents, self.last_samples = [], []
+        n_renoised = 0
         for k, gen_num in enumerate(gen_nums):
             if k > 0:
                 input_images = output_images
@@ -241,7 +251,11 @@ class LVMPipeline:
                 if k > 0:  # re-noise the re-encoded condition frames (pipeline.py:496-497); 16 KB blend, torch RNG
                     c = clean_image_noise_level
                     # (1 - c) * lat + c * noise through the HIP lerp kernel (fp32 in, bf16 out); the noise is torch's RNG
-                    noise = torch.randn(lat.shape, device=lat.device, dtype=torch.float32)
+                    if renoise_noise is not None:
+                        noise = renoise_noise[n_renoised].to(lat.device, torch.float32).reshape(lat.shape)
+                        n_renoised += 1
+                    else:
+                        noise = torch.randn(lat.shape, device=lat.device, dtype=torch.float32)
                     cvec = torch.full((lat.shape[0],), float(c), device=lat.device, dtype=torch.float32)
                     lat = ops_train.lerp_frames(noise, lat.float().contiguous(), cvec,
                                                  torch.empty(lat.shape, device=lat.device, dtype=torch.bfloat16)).to(dtype)
