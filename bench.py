@@ -290,6 +290,17 @@ def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=No
                 trainer.step(batch, x1, x0, t, clean, x0i, ti)
         ms_nocomm = D.timed_region(run_nocomm, torch.cuda.synchronize, device) / max(steps, 1) * 1e3
         trainer.skip_allreduce = False
+        # the same steps with every bucket reduced BEHIND the backward instead of under it (VGPT_DP_OVERLAP=0): tells whether
+        # the overlap pays on this node or RCCL's kernels cost the backward's GEMMs more CUs than they hide
+        was = trainer.overlap_allreduce
+        trainer.overlap_allreduce = False
+        trainer.step(batch, x1, x0, t, clean, x0i, ti)
+
+        def run_serial():
+            for _ in range(steps):
+                trainer.step(batch, x1, x0, t, clean, x0i, ti)
+        ms_serial = D.timed_region(run_serial, torch.cuda.synchronize, device) / max(steps, 1) * 1e3
+        trainer.overlap_allreduce = was
         buckets = list(trainer.layer_buckets) + [trainer.small_bucket]
 
         def run_comm():
@@ -301,7 +312,8 @@ def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=No
         ms_comm = D.timed_region(run_comm, torch.cuda.synchronize, device) / max(steps, 1) * 1e3
         nbytes = sum(b.numel() * b.element_size() for b in buckets)
         comm = {"ms_per_step_without_allreduce": round(ms_nocomm, 2), "exposed_ms_per_step": round(ms - ms_nocomm, 2),
-                "allreduce_alone_ms": round(ms_comm, 2), "allreduce_bytes_per_step": nbytes, "buckets": len(buckets),
+                "allreduce_alone_ms": round(ms_comm, 2), "ms_per_step_allreduce_after_backward": round(ms_serial, 2),
+                "allreduce_bytes_per_step": nbytes, "buckets": len(buckets),
                 "allreduce_alone_busbw_gbs": round(2 * (world - 1) / world * nbytes / (ms_comm * 1e-3) / 1e9, 1),
                 "hidden_frac": round(max(0.0, 1.0 - (ms - ms_nocomm) / ms_comm), 3) if ms_comm > 0 else None}
     line["comm"] = comm

@@ -18,6 +18,8 @@ optimizer to DeepSpeed's bf16 AdamW (fp32 master weights).  Here:
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional
 
 import torch
@@ -59,6 +61,9 @@ class Stage1Trainer:
         self.step_count = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.skip_allreduce = False   # measurement only (bench.py's exposed-communication leg): ranks stop agreeing when set
+        # VGPT_DP_OVERLAP=0: all buckets are reduced behind the backward instead of layer by layer under it (for A/B runs on a
+        # multi-GPU node: RCCL's kernels share the CUs with the backward's GEMMs while they overlap)
+        self.overlap_allreduce = os.environ.get("VGPT_DP_OVERLAP", "1") != "0"
         self.params = {n: p for n, p in model.named_parameters()}
         self._ws = {}
         self.last = {}
@@ -297,7 +302,7 @@ class Stage1Trainer:
             T.rmsnorm_bwd(hbuf[li], layer.input_layernorm.weight, dn, dh,
                           g[f"llm.layers.{li}.input_layernorm.weight"], layer.input_layernorm.variance_epsilon,
                           dres=dh_b)                                                     # dh (layer input)
-            if self.world > 1 and not self.skip_allreduce:
+            if self.world > 1 and not self.skip_allreduce and self.overlap_allreduce:
                 handles.append(dist.all_reduce(self.layer_buckets[li], async_op=True))
         # heads fed by dseq = dh
         dseq = dh
@@ -308,6 +313,8 @@ class Stage1Trainer:
             self._patch_bwd("input_x_embedder", T.gather_rows(dseq, prep["c_rows"], ntok), cl)
         T.embed_bwd(prep["ids"].view(-1), prep["keep"], dseq, g["llm.embed_tokens.weight"])
         if self.world > 1 and not self.skip_allreduce:
+            if not self.overlap_allreduce:
+                handles += [dist.all_reduce(b, async_op=True) for b in reversed(self.layer_buckets)]
             handles.append(dist.all_reduce(self.small_bucket, async_op=True))
             for hd_ in handles:
                 hd_.wait()
