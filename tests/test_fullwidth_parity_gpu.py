@@ -181,3 +181,53 @@ def test_cfg4_attention_forward_backward_on_row_bands():
     assert float(dq_c[other, : nh * hd].abs().max()) == 0.0
     # forward on rows outside the bands: self-consistency with the logsumexp (rows sum to one) is covered by the
     # size-independent properties in tests/test_fullsize_gpu.py
+
+
+def test_cfg4_training_step_with_and_without_gradient_checkpointing():
+    """BASELINE config 4's shapes (512^2, 16-frame clip, bs 1: L = 31 806; mask as token attributes, the dense form is
+    1 GB) through `Stage1Trainer.step` at full width with one decoder layer: finite loss, every gradient finite and
+    non-zero, and gradient checkpointing (OmniGen/transformer.py:182-192) gives bit-identical loss and gradients.
+    (Values at this length are pinned piecewise: attention on row bands above, the layer's GEMMs / norms at cfg-3.)"""
+    cfg = R.Phi3Cfg(hidden_size=3072, intermediate_size=8192, num_hidden_layers=1, num_attention_heads=32,
+                    num_key_value_heads=32, vocab_size=64, pos_embed_max_size=32)   # 64 x 64 latents: 32 x 32 patches
+    p = {k: v.to(BF).float() for k, v in R.make_params(cfg, seed=12).items()}
+    P = importlib.import_module("video-gpt_amd.processor")
+    TR = importlib.import_module("video-gpt_amd.train")
+    F, hw = 16, (64, 64)
+    proc = P.LVMProcessor(P.SpecialTokenizer(10, 11, 12))
+    proc.collator.mask_format = "layout"
+    prompt = "".join(f"<|diffusion|><|image_{i + 1}|><img><|image_{i + 1}|></img>" if i < F - 1
+                     else f"<|diffusion|><|image_{i + 1}|>" for i in range(F))
+    row = proc.process_multi_modal_prompt_training(prompt, [torch.zeros(3, hw[0] * 8, hw[1] * 8) for _ in range(F)])
+    batch = proc.collator.collate_stage1([row], F)
+    assert tuple(batch["input_ids"].shape) == (1, 31806)
+    batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items() if k not in ("input_pixel_values", "output_images")}
+    gen = torch.Generator("cpu").manual_seed(9)
+    mk = lambda n: torch.randn(n, 4, *hw, generator=gen).to(DEV)
+    x1, x0, clean, x0i = mk(F), mk(F), mk(F - 1), mk(F - 1)
+    t = torch.rand(F, generator=gen).to(DEV)
+    ti = (0.9 + 0.1 * torch.rand(F - 1, generator=gen)).to(DEV)
+    outs = {}
+    for ck in (False, True):
+        model = SC.build_product_model(cfg, p, DEV, cls_name="LVMTraining")
+        tr = TR.Stage1Trainer(model, lr=1e-4, weight_decay=0.1, gradient_checkpointing=ck)
+        loss = tr.step(batch, x1, x0, t, clean, x0i, ti, update=False)
+        outs[ck] = (loss.clone(), {k: v.clone() for k, v in tr.grads.items()})
+        del tr, model
+        torch.cuda.empty_cache()
+    loss0, g0 = outs[False]
+    loss1, g1 = outs[True]
+    assert torch.isfinite(loss0).all() and loss0.shape == (F,)
+    assert torch.equal(loss0, loss1)
+    # Bit for bit wherever the backward is a fixed-order reduction (every GEMM, attention, the patch embedders).  The norm
+    # weights, the adaLN modulation and what hangs off it (t_embedder) are summed over tokens with fp32 atomics
+    # (train.hip: one atomic per column and row strip), whose order varies from run to run at this size -- two runs
+    # WITHOUT checkpointing differ in exactly those (scripts/train_determinism_probe.py): equal to fp32 rounding there.
+    atomics = ("layernorm.weight", "llm.norm.weight", "t_embedder.", "final_layer.adaLN_modulation")
+    for k in g0:
+        assert torch.isfinite(g0[k]).all(), k
+        if any(a in k for a in atomics):
+            assert SC.rel_l2(g1[k], g0[k]) < 1e-3, k   # (a bf16 rounding of the modulation gradient sits behind the atomics)
+        else:
+            assert torch.equal(g0[k], g1[k]), k
+    assert float(g0["llm.layers.0.self_attn.qkv_proj.weight"].float().abs().sum()) > 0
