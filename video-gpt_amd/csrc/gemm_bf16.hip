@@ -40,6 +40,13 @@
 // reads, 3 = both, 4 = skip the epilogue, 16 = no wait for the LDS-DMA (what the per-tile drain costs).  A COMPILE-time switch: as a run-time flag the skipped reads became conditional, and at the join
 // hipcc's s_waitcnt insertion assumes the shorter path — every MFMA phase then waited for the fragment reads issued
 // right in front of it (lgkmcnt(3..0) instead of (7..4)), exposing the LDS latency twice per k-tile.
+// EXPERIMENT, not compiled into the product (make gemm-variant-VGPT_GEMM_RS [VAL=2]): operand tiles fetched into registers
+// (global_load_dwordx4) and written to LDS with ds_write_b128 instead of LDS-DMA -- PIPE == 3 in the 4-phase loop, with
+// VAL=2 also PIPE == 4, the ping-pong schedule on 256 x 256 tiles.  Parity-green; within +-3 % of the LDS-DMA loop
+// (PIPE 3) and 9 % behind it (PIPE 4), DESIGN.md section 4.
+#ifndef VGPT_GEMM_RS
+#define VGPT_GEMM_RS 0
+#endif
 #ifndef VGPT_GEMM_DEBUG_BUILD
 #define VGPT_GEMM_DEBUG_BUILD 0
 #endif
@@ -314,7 +321,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
             }
         }
-    } else if constexpr (PIPE == 2) {
+    } else if constexpr (PIPE == 2 || PIPE == 4) {
+        constexpr bool RS = PIPE == 4;   // register-staged operands (see PIPE == 3) in the ping-pong schedule
         // Two wave groups in alternation ("ping-pong"): the four waves of tile row 0 and the four of tile row 1 sit one
         // per SIMD each; while one group runs a cluster of 16 (or 8) MFMAs at raised priority the other reads fragments
         // from LDS and issues LDS-DMA, and every hand-over is a workgroup barrier (group 1 runs one barrier behind).
@@ -355,30 +363,58 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         auto dummy = [&]() {
             if constexpr ((kDebug & 1) == 0) glds16_asm(a_org, oA[0][0], scratch);
         };
+        // RS: every staging site (image, u) owns one register quad; a site writes the piece it fetched one tile earlier and
+        // fetches the piece of the following tile (tile indices clamped to the last: the surplus writes hit dead images),
+        // so eight fetches are always in flight and `vmcnt(7)` means "the oldest has landed"
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        static_assert(!RS || NI == 4, "register-staged ping-pong: 256 x 256 tiles");
+        u32x4 Rw1[2], Ra1[2], Rw0[2], Ra0[2];
+        const int lane16 = lane * 16, last_kt = nk - 1;
+        auto gl = [&](u32x4& dst, const char* base, uint32_t voff) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base));
+        };
+        auto site = [&](u32x4& r, int lds_off, const char* next_base, uint32_t voff) {
+            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            *reinterpret_cast<u32x4*>(smem + lds_off + lane16) = r;
+            gl(r, next_base, voff);
+        };
         // one of the two pieces (u) this wave stages of a half-tile; past the last k-tile a dummy keeps the count uniform
         auto stage_a = [&](int buf, int kt, int mh, int u) {
             if constexpr ((kDebug & 1) != 0) return;
+            if constexpr (RS) {
+                site(mh ? Ra1[u] : Ra0[u], buf * STRIDE + (mh ? AM1 : AM0) + (wave + 8 * u) * 1024,
+                     a_org + min(kt + 1, last_kt) * a_step, oA[mh][u]);
+                return;
+            }
             if (kt < nk) glds16_asm(a_org + kt * a_step, oA[mh][u], lds_base + (uint32_t)(buf * STRIDE + (mh ? AM1 : AM0) + (wave + 8 * u) * 1024));
             else dummy();
         };
         auto stage_w0 = [&](int buf, int kt, int u) {
             if constexpr ((kDebug & 1) != 0) return;
+            if constexpr (RS) {
+                site(Rw0[u], buf * STRIDE + WN0 + (wave + 8 * u) * 1024, w_org + min(kt + 1, last_kt) * w_step, oW0[u]);
+                return;
+            }
             if (kt < nk) glds16_asm(w_org + kt * w_step, oW0[u], lds_base + (uint32_t)(buf * STRIDE + WN0 + (wave + 8 * u) * 1024));
             else dummy();
         };
         auto stage_w1 = [&](int buf, int kt, int u) {
             if constexpr ((kDebug & 1) != 0) return;
+            if constexpr (RS) {
+                site(Rw1[u], buf * STRIDE + WN1 + (wave + 8 * u) * 1024, w_org + min(kt + 1, last_kt) * w_step, oW1[u]);
+                return;
+            }
             if (kt < nk && (NI == 4 || u == 0)) glds16_asm(w_org + kt * w_step, oW1[u], lds_base + (uint32_t)(buf * STRIDE + WN1 + (wave + 8 * u) * 1024));
             else dummy();
         };
         constexpr int NI1 = NI - 2;   // n sub-tiles of the second n half
-        bf16x8 W0[2][2], W0n[2][2], W1[NI1][2], Af[4][2];   // [sub-tile][k-step]
+        bf16x8 W0[2][2], W0n[2][2], W1[NI1][2], Af[4][2];   // [sub-tile][k-step]  (W0n: DMA schedule only)
         const int a_rd = (wm * 64 + frow) * 128, w0_rd = (wn * 32 + frow) * 128, w1_rd = (wn * (NI1 * 16) + frow) * 128;
         auto rd = [&](const char* img, int sub, int ks) {
             return *reinterpret_cast<const bf16x8*>(img + sub * 2048 + ((ks * 4 + fk) ^ sw) * 16);
         };
         auto load_end = [&]() {   // end of a phase's load part
-            if constexpr ((kDebug & 16) == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if constexpr ((kDebug & 16) == 0 && !RS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -391,6 +427,109 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             asm volatile("" ::: "memory");
         };
 
+        if constexpr (RS) {
+            // With the operands waiting in registers nothing has to be in LDS more than two phases before its first read
+            // (two: group 1 runs a barrier behind), so plain double buffering is enough: during tile kt the images of tile
+            // kt+1 go to buffer buf^1 -- W.n0 in phase 1, A.m0 in 2 (both first read in phase 1 of the next tile), W.n1
+            // in 3, A.m1 in 4 -- and each site fetches its piece of tile kt+2 right behind its write.
+            const int k1 = min(1, last_kt);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                gl(Rw0[u], w_org, oW0[u]);
+                gl(Ra0[u], a_org, oA[0][u]);
+                gl(Rw1[u], w_org, oW1[u]);
+                gl(Ra1[u], a_org, oA[1][u]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pc = (wave + 8 * u) * 1024 + lane16;
+                *reinterpret_cast<u32x4*>(smem + WN0 + pc) = Rw0[u];
+                *reinterpret_cast<u32x4*>(smem + AM0 + pc) = Ra0[u];
+                *reinterpret_cast<u32x4*>(smem + WN1 + pc) = Rw1[u];
+                *reinterpret_cast<u32x4*>(smem + AM1 + pc) = Ra1[u];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) gl(Rw0[u], w_org + k1 * w_step, oW0[u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) gl(Ra0[u], a_org + k1 * a_step, oA[0][u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) gl(Rw1[u], w_org + k1 * w_step, oW1[u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) gl(Ra1[u], a_org + k1 * a_step, oA[1][u]);
+            if (wm == 1) {   // the stagger: group 1 runs one barrier behind group 0
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            auto mma_end_rs = [&]() {
+                __builtin_amdgcn_s_setprio(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this cluster's LDS writes
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" ::: "memory");
+            };
+            // 8 MFMAs of one k-step of a quadrant, then one staging site
+            auto cluster = [&](const bf16x8(&w)[2][2], const bf16x8(&a)[4][2], auto nh, auto mh, auto st) {
+                constexpr int NH = decltype(nh)::value, MH = decltype(mh)::value;
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[NH * 2 + i][MH * 4 + j] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][ks], a[j][ks], acc[NH * 2 + i][MH * 4 + j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    st(ks);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mma_end_rs();
+            };
+            using Z0 = std::integral_constant<int, 0>;
+            using Z1 = std::integral_constant<int, 1>;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int buf = kt & 1;
+                const char* tb = smem + buf * STRIDE;
+                // ---- phase 1: quadrant (m0, n0) ----
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) W0[i][ks] = rd(tb + WN0 + w0_rd, i, ks);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) Af[j][ks] = rd(tb + AM0 + a_rd, j, ks);
+                load_end();
+                cluster(W0, Af, Z0{}, Z0{}, [&](int u) { stage_w0(buf ^ 1, kt + 1, u); });
+                // ---- phase 2: (m0, n1) ----
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) W1[i][ks] = rd(tb + WN1 + w1_rd, i, ks);
+                load_end();
+                cluster(W1, Af, Z1{}, Z0{}, [&](int u) { stage_a(buf ^ 1, kt + 1, 0, u); });
+                // ---- phase 3: (m1, n1) ----
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) Af[j][ks] = rd(tb + AM1 + a_rd, j, ks);
+                load_end();
+                cluster(W1, Af, Z1{}, Z1{}, [&](int u) { stage_w1(buf ^ 1, kt + 1, u); });
+                // ---- phase 4: (m1, n0) ----
+                load_end();
+                cluster(W0, Af, Z0{}, Z1{}, [&](int u) { stage_a(buf ^ 1, kt + 1, 1, u); });
+            }
+            if (wm == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated fetches of the last tile
+        } else {
 #pragma unroll
         for (int u = 0; u < 2; ++u) stage_w0(0, 0, u);
 #pragma unroll
@@ -514,6 +653,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummies of the last phases
+        }
     } else {
         // Software-pipelined 4-phase loop (256x256 tile, wave tile 128(m) x 64(n)).  A k-tile is four
         // phases of 16 MFMAs: (ks0,m-half0) (ks0,m-half1) (ks1,m-half0) (ks1,m-half1).  The fragments
@@ -580,6 +720,125 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         using H0 = std::integral_constant<int, 0>;
         using H1 = std::integral_constant<int, 1>;
 
+        if constexpr (PIPE == 3) {
+            // Register-staged operands: each wave fetches its 8 (7) 1-KiB pieces of tile kt+2 into registers right after
+            // it has written those of tile kt+1 to LDS (phase 3 of tile kt), so a fetch has a whole tile of time to land
+            // and no instruction of the loop is an LDS-DMA.  Same LDS images, same single barrier per tile.
+            static_assert(!ATR && !WTR, "register staging: NT operands");
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            constexpr int NP = C::A_SLABS + C::W_SLABS;
+            u32x4 R[NP];
+            const int lane16 = lane * 16;
+            // the fetches are inline asm so that the waits are the counted ones written below (hipcc's own bookkeeping
+            // falls back to vmcnt(0) at the loop header, which would expose the latency of the youngest fetch every tile)
+            auto gl = [&](u32x4& dst, const char* base, uint32_t voff) {
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base));
+            };
+            auto gload = [&](int kt) {
+#pragma unroll
+                for (int p = 0; p < C::A_SLABS; ++p) gl(R[p], a_org + kt * a_step, a_off[p]);
+#pragma unroll
+                for (int p = 0; p < C::W_SLABS; ++p) gl(R[C::A_SLABS + p], w_org + kt * w_step, w_off[p]);
+            };
+            auto lwrite = [&](int buf) {
+#pragma unroll
+                for (int p = 0; p < C::A_SLABS; ++p)
+                    *reinterpret_cast<u32x4*>(sA + buf * C::A_BYTES + (wave * C::A_SLABS + p) * 1024 + lane16) = R[p];
+#pragma unroll
+                for (int p = 0; p < C::W_SLABS; ++p)
+                    *reinterpret_cast<u32x4*>(sW + buf * C::W_BYTES + (wave * C::W_SLABS + p) * 1024 + lane16) = R[C::A_SLABS + p];
+            };
+            // piece p of tile T goes to LDS in slot (p / 2 + 3) % 4 of the tile before (slot 3 = phase 4 of tile T-2 for
+            // pieces 0, 1 .. slot 2 = phase 3 of tile T-1 for pieces 6, 7) and the same piece of tile T+1 is fetched right
+            // behind it; past the last tile the fetches repeat tile nk-1 and the writes land in a dead buffer
+            auto gload1 = [&](auto pc, int kt) {
+                constexpr int p = decltype(pc)::value;
+                if constexpr (p < C::A_SLABS) gl(R[p], a_org + kt * a_step, a_off[p]);
+                else if constexpr (p < NP) gl(R[p], w_org + kt * w_step, w_off[p - C::A_SLABS]);
+            };
+            auto lwrite1 = [&](auto pc, int buf) {
+                constexpr int p = decltype(pc)::value;
+                if constexpr (p < C::A_SLABS)
+                    *reinterpret_cast<u32x4*>(sA + buf * C::A_BYTES + (wave * C::A_SLABS + p) * 1024 + lane16) = R[p];
+                else if constexpr (p < NP)
+                    *reinterpret_cast<u32x4*>(sW + buf * C::W_BYTES + (wave * C::W_SLABS + p - C::A_SLABS) * 1024 + lane16) = R[p];
+            };
+            // one phase: 16 (12) MFMAs with the fragment reads of the next phase in front, the LDS writes of pieces p, p+1
+            // (of the tile whose fetches are oldest) after the first half and the fetches of the same pieces of tile
+            // kt_next after three quarters
+            auto mma_part = [&](const bf16x8(&wf)[NI], const bf16x8(&af)[4], auto mh, auto q0, auto q1) {
+                constexpr int MH = decltype(mh)::value;
+#pragma unroll
+                for (int q = decltype(q0)::value; q < decltype(q1)::value; ++q)
+                    acc[q >> 2][MH * 4 + (q & 3)] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q >> 2], af[q & 3], acc[q >> 2][MH * 4 + (q & 3)], 0, 0, 0);
+            };
+            auto phase = [&](const bf16x8(&wf)[NI], const bf16x8(&af)[4], auto mh, auto pc, int buf, int kt_next) {
+                constexpr int p = decltype(pc)::value;
+                constexpr int Q = NI * 4;
+                using I0 = std::integral_constant<int, 0>;
+                using IA = std::integral_constant<int, Q / 2>;
+                using IB = std::integral_constant<int, Q * 3 / 4>;
+                using IQ = std::integral_constant<int, Q>;
+                __builtin_amdgcn_sched_barrier(0);
+                mma_part(wf, af, mh, I0{}, IA{});
+                __builtin_amdgcn_sched_barrier(0);
+                // NP fetches are in flight, oldest first the pieces written now: all but the NP - 2 (NP - 1) younger ones
+                if constexpr (p + 1 < NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP - 2) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP - 1) : "memory");
+                lwrite1(std::integral_constant<int, p>{}, buf);
+                lwrite1(std::integral_constant<int, p + 1>{}, buf);
+                mma_part(wf, af, mh, IA{}, IB{});
+                __builtin_amdgcn_sched_barrier(0);
+                gload1(std::integral_constant<int, p>{}, kt_next);
+                gload1(std::integral_constant<int, p + 1>{}, kt_next);
+                mma_part(wf, af, mh, IB{}, IQ{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using P0 = std::integral_constant<int, 0>;
+            using P2 = std::integral_constant<int, 2>;
+            using P4 = std::integral_constant<int, 4>;
+            using P6 = std::integral_constant<int, 6>;
+            const int last = nk - 1;
+            gload(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lwrite(0);
+            gload1(P0{}, min(1, last));
+            gload1(std::integral_constant<int, 1>{}, min(1, last));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lwrite1(P0{}, 1);
+            lwrite1(std::integral_constant<int, 1>{}, 1);
+            __syncthreads();
+            {   // the order the loop keeps (2..7 of the next tile, then 0, 1 of the one after): the counted waits hold from tile 0
+                const int k1 = min(1, last);
+                gload1(P2{}, k1);
+                gload1(std::integral_constant<int, 3>{}, k1);
+                gload1(P4{}, k1);
+                gload1(std::integral_constant<int, 5>{}, k1);
+                gload1(P6{}, k1);
+                gload1(std::integral_constant<int, 7>{}, k1);
+                gload1(P0{}, min(2, last));
+                gload1(std::integral_constant<int, 1>{}, min(2, last));
+            }
+            ldW(Wf[0], 0, 0);
+            ldA(Af[0], 0, 0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                const int buf = kt & 1;
+                const int k2 = min(kt + 2, last), k3 = min(kt + 3, last);
+                ldA(Af[1], buf, 0, 1);
+                phase(Wf[0], Af[0], H0{}, P2{}, buf ^ 1, k2);
+                ldW(Wf[1], buf, 1);
+                ldA(Af[0], buf, 1, 0);
+                phase(Wf[0], Af[1], H1{}, P4{}, buf ^ 1, k2);
+                ldA(Af[1], buf, 1, 1);
+                phase(Wf[1], Af[0], H0{}, P6{}, buf ^ 1, k2);
+                __syncthreads();                       // tile kt+1 is in LDS; every wave holds its last fragments of tile kt
+                ldW(Wf[0], buf ^ 1, 0);
+                ldA(Af[0], buf ^ 1, 0, 0);
+                phase(Wf[1], Af[1], H1{}, P0{}, buf, k3);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated fetches of the last tiles: their registers are reused below
+        } else {
         stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -613,6 +872,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             }
             mma(Wf[1], Af[1], H1{});
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
     }
 
@@ -739,7 +999,7 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + (PIPE == 2 ? 16384 : 0));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + (PIPE == 2 || PIPE == 4 ? 16384 : 0));
         if (e != hipSuccess) {
             vgpt_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return VGPT_ERR_HIP;
@@ -749,7 +1009,7 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     g.tiles_m = (int)cdiv(g.M, C::BM);
     g.tiles_n = (int)cdiv(n_out, MODE == MODE_GATED ? C::BN / 2 : C::BN);
     hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>), dim3(g.tiles_m * g.tiles_n), dim3(C::THREADS),
-                       C::LDS_BYTES + (PIPE == 2 ? 16384 : 0), s, g);
+                       C::LDS_BYTES + (PIPE == 2 || PIPE == 4 ? 16384 : 0), s, g);
     VGPT_CHECK_LAUNCH(name);
     return VGPT_OK;
 }
@@ -824,11 +1084,15 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     }
     auto big = [&](const GemmArgs& ga) {
         if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
-            if (use192) return launch_cfg<MODE, Cfg192, (VGPT_GEMM_PP ? 2 : 1), ATR, WTR>(ga, n_out, s, name);
+            if (use192) return launch_cfg<MODE, Cfg192, (VGPT_GEMM_RS ? 3 : VGPT_GEMM_PP ? 2 : 1), ATR, WTR>(ga, n_out, s, name);
         }
         if constexpr (!ATR && !WTR && VGPT_GEMM_PP) {
             if (ga.K >= 2 * BK) return launch_cfg<MODE, Cfg256, 2, ATR, WTR>(ga, n_out, s, name);
         }
+        if constexpr (!ATR && !WTR && VGPT_GEMM_RS == 2) {
+            if (ga.K >= 2 * BK) return launch_cfg<MODE, Cfg256, 4, ATR, WTR>(ga, n_out, s, name);
+        }
+        if constexpr (!ATR && !WTR && VGPT_GEMM_RS) return launch_cfg<MODE, Cfg256, 3, ATR, WTR>(ga, n_out, s, name);
         return launch_cfg<MODE, Cfg256, 1, ATR, WTR>(ga, n_out, s, name);
     };
     if (p.rows_big >= g.M) return big(g);
