@@ -1,0 +1,33 @@
+"""Developer probe (GPU): wall time of the once-per-clip passes of the cfg-2 engine (prefill, time-row pass, adaLN table),
+each synchronised, and the host time of merely enqueueing them."""
+import importlib, os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+importlib.import_module("video-gpt_amd")
+M = importlib.import_module("video-gpt_amd.model"); P = importlib.import_module("video-gpt_amd.processor")
+S = importlib.import_module("video-gpt_amd.scheduler"); E = importlib.import_module("video-gpt_amd.engine")
+dev = torch.device("cuda", 0); BF = torch.bfloat16
+C, G, hw = 4, 8, (32, 32)
+model = bench.build_model(M, bench.full_config(M, 32), dev, seed=0)
+proc = P.LVMProcessor(P.SpecialTokenizer(10, 11, 12), mask_format="layout")
+prompt = "".join(f"<img><|image_{i + 1}|></img>" if i < C else f"<|diffusion|><|image_{i + 1}|>" for i in range(C + G))
+prompt_ = "".join(f"<|diffusion|><|image_{i + 1}|>" for i in range(G))
+imgs = [torch.zeros(3, 256, 256) for _ in range(C)]
+batch = proc.prompt_condition_frame_block_inference([prompt, prompt_], [imgs, []], height=256, width=256, use_img_cfg=True,
+                                                    frame_blocks=[C, G])
+cond = [torch.randn(1, 4, *hw).to(dev, BF) for _ in range(C)]
+sched = S.LVMScheduler(num_steps=50, time_shifting_factor=1)
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    eng = E.StaticDenoiser(model, batch["input_ids"].to(dev), batch["position_ids"].to(dev), batch["attention_mask"], cond,
+                           batch["input_image_sizes"], batch["denoise_image_sizes"], batch["time_emb_inx"], 2 * G, hw, True, 1.6,
+                           "x1", sigma=sched.sigma, reuse_condition_prefix=True)
+    print("S", eng.S, "S0", eng.S0, "hoist", bool(eng.hoist), "ids", tuple(eng.input_ids.shape), eng.input_ids.device, flush=True)
+    def t(f, n=5):
+        f(); torch.cuda.synchronize()
+        w = []
+        for _ in range(n):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); f(); torch.cuda.synchronize(); w.append(time.perf_counter() - t0)
+        return 1e3 * min(w)
+    print(f"S0 {eng.S0} rows prefix, {eng.hoist['nf'] if eng.hoist else 0} frames; prefill {t(eng.prefill):.2f} ms | "
+          f"time pass {t(eng._time_pass):.2f} ms | mod pass {t(eng._mod_pass):.2f} ms | all {t(eng.per_clip_setup):.2f} ms")
