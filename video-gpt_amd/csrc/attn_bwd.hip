@@ -260,7 +260,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
                     for (int i = 0; i < 16; ++i) {
                         const int bit = (i & 3) + 8 * (i >> 2);
                         float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], a.scale_log2e, -lse_r));
-                        if (code == 2) p = ((w >> bit) & 1u) ? p : 0.f;
+                        // masked keys -> 0 without VCC: the bit spread to 0 / ~0 (v_bfe_i32) and one AND; an all-visible
+                        // tile carries all-ones words, so no branch and no select
+                        // (the empty asm keeps instcombine from turning the AND back into a select)
+                        uint32_t keep = (uint32_t)((int32_t)(w << (31 - bit)) >> 31);
+                        asm("" : "+v"(keep));
+                        p = __uint_as_float(__float_as_uint(p) & keep);
                         S[i] = p * (dP[i] - dlt_r) * a.scale;
                     }
                     bf16x8 dSf[2];
@@ -462,14 +467,19 @@ __global__ __launch_bounds__(256, (WANT_DK && WANT_DV) ? 1 : 2) void attn_bwd_dk
                     S[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], a.scale_log2e, -lse4[i >> 2][i & 3]));  // P
                 }
                 if (code == 2) {  // mixed tile: bit r of the word of (query row, this wave's 32 keys)
-                    const uint32_t mybit = 1u << r;
+                    // bit r spread to 0 / ~0 (v_bfe_i32) and one AND per probability, no VCC (as in the dQ kernel)
+                    auto keep = [&](float p, uint32_t w) {
+                        uint32_t m = (uint32_t)((int32_t)(w << (31 - r)) >> 31);
+                        asm("" : "+v"(m));
+                        return __uint_as_float(__float_as_uint(p) & m);
+                    };
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const uint4 w4 = *reinterpret_cast<const uint4*>(mw + wave * 64 + qh * 32 + 8 * g4 + 4 * h);
-                        S[4 * g4 + 0] = (w4.x & mybit) ? S[4 * g4 + 0] : 0.f;
-                        S[4 * g4 + 1] = (w4.y & mybit) ? S[4 * g4 + 1] : 0.f;
-                        S[4 * g4 + 2] = (w4.z & mybit) ? S[4 * g4 + 2] : 0.f;
-                        S[4 * g4 + 3] = (w4.w & mybit) ? S[4 * g4 + 3] : 0.f;
+                        S[4 * g4 + 0] = keep(S[4 * g4 + 0], w4.x);
+                        S[4 * g4 + 1] = keep(S[4 * g4 + 1], w4.y);
+                        S[4 * g4 + 2] = keep(S[4 * g4 + 2], w4.z);
+                        S[4 * g4 + 3] = keep(S[4 * g4 + 3], w4.w);
                     }
                 }
                 if (qt * 64 + 64 > a.L || kblk * 128 + 128 > a.L) {  // rows / keys past L (last tiles only)

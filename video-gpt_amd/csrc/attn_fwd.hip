@@ -357,6 +357,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             __builtin_amdgcn_sched_barrier(0);
             // ---- mask (mixed tiles only), row max on raw scores; scale folded into the exp2 FMA ----
             if (code == 2) {
+                // per score two integer instructions without VCC: the bit spread to 0 / ~0 (v_bfe_i32), then
+                // (s & m) | (-inf & ~m) (v_bitop3_b32) -- as a select it was and + cmp + nop + cndmask per score
                 const uint2 mw = *reinterpret_cast<const uint2*>(smem + MASK_OFF + buf * 1024 + wave * 256 + r * 8);
                 const uint32_t mw0 = mw.x, mw1 = (2 * (int)(e_cur >> 8) + 1 < a.W) ? mw.y : 0u;
 #pragma unroll
@@ -365,7 +367,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int bit = (i & 3) + 8 * (i >> 2);
-                        S[kb][i] = ((w >> bit) & 1u) ? S[kb][i] : -INFINITY;
+                        const uint32_t m = (uint32_t)((int32_t)(w << (31 - bit)) >> 31);
+                        S[kb][i] = __uint_as_float((__float_as_uint(S[kb][i]) & m) | (0xff800000u & ~m));
                     }
                 }
             }
