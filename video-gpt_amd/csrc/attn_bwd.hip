@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
                         S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[s], Qf[s], S, 0, 0, 0);
                         dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vf[s], dOf[s], dP, 0, 0, 0);
                     }
-                    // dS^T = P^T o (dP^T - delta) * scale, P^T = exp2(c S^T - LSE); masked keys -> 0
+                    // dS^T / scale = P^T o (dP^T - delta), P^T = exp2(c S^T - LSE); masked keys -> 0
                     const uint32_t w = (kb ? mw1 : mw0) >> (4 * h);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
                         uint32_t keep = (uint32_t)((int32_t)(w << (31 - bit)) >> 31);
                         asm("" : "+v"(keep));
                         p = __uint_as_float(__float_as_uint(p) & keep);
-                        S[i] = p * (dP[i] - dlt_r) * a.scale;
+                        S[i] = p * (dP[i] - dlt_r);   // the softmax scale multiplies dQ once, in the epilogue
                     }
                     bf16x8 dSf[2];
 #pragma unroll
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
             for (int g4 = 0; g4 < 4; ++g4) {
                 bf16x4 o;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = f2bf(dQ[dt][4 * g4 + t]);
+                for (int t = 0; t < 4; ++t) o[t] = f2bf(dQ[dt][4 * g4 + t] * a.scale);
                 *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g4 + 4 * h) = o;
             }
     }
@@ -489,10 +489,10 @@ __global__ __launch_bounds__(256, (WANT_DK && WANT_DV) ? 1 : 2) void attn_bwd_dk
                         if (key_row >= a.L || qt * 64 + qrow >= a.L) S[i] = 0.f;
                     }
                 }
-                // S now holds P; dP holds dP - delta.  dS = P (dP - delta) scale goes to dP, P stays in S.
+                // S now holds P; dP holds dP - delta.  dS / scale = P (dP - delta) goes to dP, P stays in S.
                 if constexpr (WANT_DK) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) dP[i] = S[i] * dP[i] * a.scale;
+                    for (int i = 0; i < 16; ++i) dP[i] = S[i] * dP[i];   // the softmax scale multiplies dK once, in the epilogue
                 }
                 if constexpr (WANT_DV) {
                     bf16x8 Pf[2];
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, (WANT_DK && WANT_DV) ? 1 : 2) void attn_bwd_dk
                 bf16x4 ok, ov;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    ok[t] = f2bf(dK[dt][4 * g4 + t]);
+                    ok[t] = f2bf(dK[dt][4 * g4 + t] * a.scale);
                     ov[t] = f2bf(dV[dt][4 * g4 + t]);
                 }
                 if constexpr (WANT_DK) *reinterpret_cast<bf16x4*>(kp_o + dt * 32 + 8 * g4 + 4 * h) = ok;
