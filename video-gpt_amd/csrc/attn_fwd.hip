@@ -367,8 +367,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int bit = (i & 3) + 8 * (i >> 2);
-                        const uint32_t m = (uint32_t)((int32_t)(w << (31 - bit)) >> 31);
-                        S[kb][i] = __uint_as_float((__float_as_uint(S[kb][i]) & m) | (0xff800000u & ~m));
+                        if constexpr (TR) {
+                            const uint32_t m = (uint32_t)((int32_t)(w << (31 - bit)) >> 31);
+                            S[kb][i] = __uint_as_float((__float_as_uint(S[kb][i]) & m) | (0xff800000u & ~m));
+                        } else {   // the register-staged variant is at its register limit: plain select
+                            S[kb][i] = ((w >> bit) & 1u) ? S[kb][i] : -INFINITY;
+                        }
                     }
                 }
             }
