@@ -74,7 +74,9 @@ def test_rope(ops, hd, nh, nkv):
 
 @pytest.mark.parametrize("M,K,hd,nh,nkv", [(77, 192, 96, 2, 2), (300, 128, 64, 3, 1), (515, 64, 128, 4, 2),
                                             # 128-tile kernel with m tail; 256x192 / 256x256 tiles (qkv of cfg-2: 4096 x 9216)
-                                            (4096, 192, 96, 32, 32), (4100, 64, 96, 32, 32), (5160, 128, 96, 32, 32)])
+                                            # (N = 9216 at 4096 / 2048 rows: the 256x288-tile kernel, two / one full rounds)
+                                            (4096, 192, 96, 32, 32), (4100, 64, 96, 32, 32), (5160, 128, 96, 32, 32),
+                                            (2048, 256, 96, 32, 32)])
 def test_qkv_gemm_with_fused_rope(ops, M, K, hd, nh, nkv):
     """vgpt_gemm_bf16_rope (qkv_proj + apply_rotary_pos_emb, sdpa_transform.py:39,52-53) vs the oracle's Linear (rounded
     to bf16) + apply_rope, and vs the two-kernel path (GEMM, then vgpt_rope_qk_inplace) it replaces."""
@@ -109,7 +111,8 @@ def test_qkv_gemm_with_fused_rope(ops, M, K, hd, nh, nkv):
                                    # large grids take the 256x256-tile kernel (m tail / n tail)
                                    (5160, 9216, 192), (4000, 2052, 64),
                                    # grids the launch plan gives to the 256x192-tile kernel (exact fit / m and n tails)
-                                   (4096, 3072, 192), (4000, 3000, 128), (4096, 9216, 64)])
+                                   # ... and to the 256x288-tile kernel (N = 9216 = 32 tiles: 4096 / 2048 rows are whole rounds)
+                                   (4096, 3072, 192), (4000, 3000, 128), (4096, 9216, 64), (2048, 9216, 320)])
 @pytest.mark.parametrize("epi", ["none", "resid", "bias"])
 def test_gemm(ops, M, N, K, epi):
     if epi != "none" and M > 1000 and N != 3000:

@@ -66,8 +66,13 @@ struct TileCfg {
     static constexpr int MI = BM / WM / 16, NI = BN / WN / 16;  // 16x16 sub-tiles per wave
     static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
     static constexpr int LDS_BYTES = 2 * (A_BYTES + W_BYTES);
-    static constexpr int A_SLABS = BM / 8 / NWAVES, W_SLABS = BN / 8 / NWAVES;  // 8-row slabs per wave
-    static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "slabs must divide over waves");
+    // 8-row slabs (1-KiB LDS-DMA pieces) per wave.  Where the W slabs do not divide over the waves (256 x 288) they are
+    // dealt round-robin and the last round is issued by the first waves only.
+    static constexpr int W_TOTAL = BN / 8;
+    static constexpr bool W_EVEN = W_TOTAL % NWAVES == 0;
+    static constexpr int A_SLABS = BM / 8 / NWAVES, W_SLABS = (W_TOTAL + NWAVES - 1) / NWAVES;
+    static_assert(BM % (8 * NWAVES) == 0 && BN % 8 == 0, "slabs must divide over waves");
+    static __device__ __host__ constexpr int w_slab(int wave, int i) { return W_EVEN ? wave * W_SLABS + i : i * NWAVES + wave; }
 };
 using Cfg128 = TileCfg<128, 128, 2, 2>;
 using Cfg256 = TileCfg<256, 256, 2, 4>;
@@ -75,6 +80,10 @@ using Cfg256 = TileCfg<256, 256, 2, 4>;
 // grid fills the last round badly: M = 4096 rows x N = 3072 is 192 tiles of 256 x 256 (a 75 % round) but exactly 256
 // tiles of 256 x 192; x N = 9216 it is 2.25 rounds against 3 full rounds of 0.75-size tiles.
 using Cfg192 = TileCfg<256, 192, 2, 4>;
+// 256 x 288, 4 x 2 waves of 64 x 144 (MI = 4, NI = 9), simple loop: N = 9216 (qkv_proj of the Phi-3-mini-class denoiser) is
+// 32 such tiles, so M = 4096 rows make exactly two rounds of 256 workgroups where 256-wide tiles make 2.25 and 192-wide
+// ones three (and a 192-wide tile's k-step takes as long as a 256-wide one's: the loop is not bound by its MFMAs)
+using Cfg288 = TileCfg<256, 288, 4, 2>;
 
 enum { MODE_PLAIN = 0, MODE_GATED = 1, MODE_ROPE = 2 };
 
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         if constexpr (WTR) {
             w_off[i] = tr_off(g.ldw, wave * C::W_SLABS + i, n0, g.N, BN);
         } else {
-            const int r = (wave * C::W_SLABS + i) * 8 + srow;
+            const int r = C::w_slab(wave, i) * 8 + srow;
             int wr;
             if constexpr (ROPE) wr = min(rope_col_of_slot(n0 + r, g.rope_cols, g.head_dim), n_rows_w - 1);
             else wr = min(w_row_of_slot<MODE>(n0, r, g.I), n_rows_w - 1) - (MODE == MODE_GATED ? 0 : n0);
@@ -260,7 +269,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             a_issue(i, kt, sA + buf * C::A_BYTES + (wave * C::A_SLABS + i) * 1024);
 #pragma unroll
         for (int i = 0; i < C::W_SLABS; ++i)
-            w_issue(i, kt, sW + buf * C::W_BYTES + (wave * C::W_SLABS + i) * 1024);
+            if (C::W_EVEN || C::w_slab(wave, i) < C::W_TOTAL)
+                w_issue(i, kt, sW + buf * C::W_BYTES + C::w_slab(wave, i) * 1024);
     };
 
     // ---- fragment read addresses ----
@@ -329,6 +339,76 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                     for (int j = 0; j < MI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
             }
+        }
+    } else if constexpr (PIPE == 5) {
+        // 4x2-wave tiles of 64 x 144 (256 x 288): six phases of 12 MFMAs per k-tile -- (ks, third of the wave's nine n
+        // sub-tiles) -- with the W fragments of phase p+1 (three reads) and the A fragments of the other k-step (four) in
+        // flight under phase p's MFMAs, the per-tile barrier in front of the LAST phase and the next tile's first fragments
+        // read behind it, the LDS-DMA in two halves as in the 4-phase loop.  200 accumulator + fragment registers.
+        static_assert(MI == 4 && NI == 9 && !ATR && !WTR, "six-phase loop: 4x2-wave tiles of 64 x 144, NT operands");
+        bf16x8 Wt[2][3], Af2[2][4];
+        auto ldW3 = [&](bf16x8(&dst)[3], int buf, int ks, int th) {
+            const char* b = sW + buf * C::W_BYTES + w_base + th * (3 * 2048) + ((ks * 4 + fk) ^ sw) * 16;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(b + i * 2048);
+        };
+        auto ldA4 = [&](bf16x8(&dst)[4], int buf, int ks) {
+            const char* b = sA + buf * C::A_BYTES + a_base + ((ks * 4 + fk) ^ sw) * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(b + j * 2048);
+        };
+        auto mma3 = [&](const bf16x8(&wf)[3], const bf16x8(&af)[4], auto th) {
+            constexpr int TH = decltype(th)::value;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[TH * 3 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[TH * 3 + i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto stage_half = [&](int buf, int kt, int half) {
+#pragma unroll
+            for (int i = 0; i < C::A_SLABS / 2; ++i) {
+                const int ii = half * (C::A_SLABS / 2) + i;
+                a_issue(ii, kt, sA + buf * C::A_BYTES + (wave * C::A_SLABS + ii) * 1024);
+            }
+#pragma unroll
+            for (int ii = 0; ii < C::W_SLABS; ++ii)
+                if ((ii >= C::W_SLABS / 2) == (half != 0) && (C::W_EVEN || C::w_slab(wave, ii) < C::W_TOTAL))
+                    w_issue(ii, kt, sW + buf * C::W_BYTES + C::w_slab(wave, ii) * 1024);
+        };
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, 1>;
+        using T2 = std::integral_constant<int, 2>;
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (nk > 1) stage(1, 1);
+        ldW3(Wt[0], 0, 0, 0);
+        ldA4(Af2[0], 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            ldW3(Wt[1], buf, 0, 1);
+            if (kt >= 1 && kt + 1 < nk) stage_half(buf ^ 1, kt + 1, 1);
+            mma3(Wt[0], Af2[0], T0{});
+            ldW3(Wt[0], buf, 0, 2);
+            ldA4(Af2[1], buf, 1);
+            mma3(Wt[1], Af2[0], T1{});
+            ldW3(Wt[1], buf, 1, 0);
+            mma3(Wt[0], Af2[0], T2{});
+            ldW3(Wt[0], buf, 1, 1);
+            mma3(Wt[1], Af2[1], T0{});
+            ldW3(Wt[1], buf, 1, 2);
+            mma3(Wt[0], Af2[1], T1{});
+            // every wave holds its last fragments of this tile and its share of tile kt+1 has landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 2 < nk) stage_half(buf, kt + 2, 0);
+            if (kt + 1 < nk) {
+                ldW3(Wt[0], buf ^ 1, 0, 0);
+                ldA4(Af2[0], buf ^ 1, 0);
+            }
+            mma3(Wt[1], Af2[1], T2{});
         }
     } else if constexpr (PIPE == 2 || PIPE == 4) {
         constexpr bool RS = PIPE == 4;   // register-staged operands (see PIPE == 3) in the ping-pong schedule
@@ -1097,9 +1177,13 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const int64_t tiles_n = cdiv(n_out, MODE == MODE_GATED ? 128 : 256);
     const int64_t tiles_m = cdiv(g.M, 256);
     const int64_t big_tiles = tiles_m * tiles_n;
-    const bool use256 = f == 256 || f == 257 || f == 192 || (f != 128 && big_tiles >= 128);
+    const bool use256 = f == 256 || f == 257 || f == 192 || f == 288 || f == 289 || (f != 128 && big_tiles >= 128);
     if (!use256) return launch_cfg<MODE, Cfg128, 0, ATR, WTR>(g, n_out, s, name);
     if (f == 257) return launch_cfg<MODE, Cfg256, 0, ATR, WTR>(g, n_out, s, name);
+    if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
+        if (f == 288) return launch_cfg<MODE, Cfg288, 5, ATR, WTR>(g, n_out, s, name);
+        if (f == 289) return launch_cfg<MODE, Cfg288, 0, ATR, WTR>(g, n_out, s, name);
+    }
     const int64_t nk = cdiv(g.K, BK);
     BigPlan p256 = plan_big(g.M, n_out, MODE == MODE_GATED ? 128 : 256, nk);
     if (f == 256) p256.rows_big = g.M;
@@ -1111,6 +1195,16 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
         if (f == 192) p192.rows_big = g.M;
         use192 = f == 192 || (f == 0 && p192.cost < 0.985 * p256.cost);
         if (use192) p = p192;
+    }
+    // 256 x 288 tiles (simple loop: a round costs ~1.35 of a 256 x 256 round at the same K, measured 100 vs 74 us at K = 3072)
+    // where they divide N and save enough rounds -- in practice qkv_proj (N = 9216) of a 4096-row sampler step: two rounds
+    // against three of 192-wide tiles, 200 vs 217 us with weights from HBM (scripts/gemm_epilogue_probe.py)
+    if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
+        if (f == 0 && n_out % 288 == 0 && p.rows_big >= g.M) {
+            const double r288 = (double)cdiv(tiles_m * (n_out / 288), 256) * 1.35;
+            const double rcur = (double)cdiv(tiles_m * cdiv(n_out, use192 ? 192 : 256), 256);
+            if (r288 < 0.95 * rcur) return launch_cfg<MODE, Cfg288, 5, ATR, WTR>(g, n_out, s, name);
+        }
     }
     auto big = [&](const GemmArgs& ga) {
         if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
