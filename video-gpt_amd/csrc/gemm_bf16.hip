@@ -80,9 +80,9 @@ using Cfg256 = TileCfg<256, 256, 2, 4>;
 // grid fills the last round badly: M = 4096 rows x N = 3072 is 192 tiles of 256 x 256 (a 75 % round) but exactly 256
 // tiles of 256 x 192; x N = 9216 it is 2.25 rounds against 3 full rounds of 0.75-size tiles.
 using Cfg192 = TileCfg<256, 192, 2, 4>;
-// 256 x 288, 4 x 2 waves of 64 x 144 (MI = 4, NI = 9), simple loop: N = 9216 (qkv_proj of the Phi-3-mini-class denoiser) is
-// 32 such tiles, so M = 4096 rows make exactly two rounds of 256 workgroups where 256-wide tiles make 2.25 and 192-wide
-// ones three (and a 192-wide tile's k-step takes as long as a 256-wide one's: the loop is not bound by its MFMAs)
+// 256 x 288, 4 x 2 waves of 64 x 144 (MI = 4, NI = 9), six-phase loop (PIPE == 5): N = 9216 (qkv_proj of the Phi-3-mini-class
+// denoiser) is 32 such tiles, so M = 4096 rows make exactly two rounds of 256 workgroups where 256-wide tiles make 2.25 and
+// 192-wide ones three (and a 192-wide tile's k-step takes as long as a 256-wide one's: the loop is not bound by its MFMAs)
 using Cfg288 = TileCfg<256, 288, 4, 2>;
 
 enum { MODE_PLAIN = 0, MODE_GATED = 1, MODE_ROPE = 2 };
@@ -1124,7 +1124,7 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     return VGPT_OK;
 }
 
-// 0 = heuristic, 128 / 256 = forced tile, 257 = 256-tile with the simple (non-pipelined) loop
+// 0 = heuristic, 128 / 256 / 192 / 288 = forced tile, 257 / 289 = the 256- / 288-wide tile with the simple (non-pipelined) loop
 // (VGPT_GEMM_TILE, read once; for A/B measurements)
 int forced_tile() {
     static int v = -1;
@@ -1196,9 +1196,10 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
         use192 = f == 192 || (f == 0 && p192.cost < 0.985 * p256.cost);
         if (use192) p = p192;
     }
-    // 256 x 288 tiles (simple loop: a round costs ~1.35 of a 256 x 256 round at the same K, measured 100 vs 74 us at K = 3072)
-    // where they divide N and save enough rounds -- in practice qkv_proj (N = 9216) of a 4096-row sampler step: two rounds
-    // against three of 192-wide tiles, 200 vs 217 us with weights from HBM (scripts/gemm_epilogue_probe.py)
+    // 256 x 288 tiles (a round costs ~1.3 of a 256 x 256 round at the same K -- 72 instead of 64 MFMAs per wave and k-tile;
+    // 1.35 is the simple loop's figure, VGPT_GEMM_TILE=289) where they divide N and save enough rounds -- in practice
+    // qkv_proj (N = 9216) of a 4096-row sampler step: two rounds against three of 192-wide tiles, 203 vs 225-230 us with
+    // weights from HBM (scripts/gemm_epilogue_probe.py, same box)
     if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
         if (f == 0 && n_out % 288 == 0 && p.rows_big >= g.M) {
             const double r288 = (double)cdiv(tiles_m * (n_out / 288), 256) * 1.35;
