@@ -60,6 +60,76 @@ def visible_pairs(mask, valid):
     return int(mask[valid].sum().item())
 
 
+def calibrate(device, stream, ops, tag):
+    """What THIS box sustains right now, measured in this process: the pure-MFMA loop on random
+    register operands (vgpt_calib_mfma), a 1-GiB streaming copy (vgpt_calib_copy) and an 8192^3 bf16 GEMM through the
+    product kernel (ops.linear), each warmed up once and timed with HIP events on `stream`.  Reported beside the
+    timed region, never inside it; a step time is read against these to tell a slow box from slow code."""
+    L = importlib.import_module("video-gpt_amd._lib")
+    lib = L.load()
+    res = {"when": tag}
+    with torch.cuda.stream(stream):
+        sp = stream.cuda_stream
+
+        def timed(fn, reps):
+            fn()
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record(stream)
+            for _ in range(reps):
+                fn()
+            e_.record(stream)
+            stream.synchronize()
+            return s_.elapsed_time(e_) * 1e-3 / reps
+        out = torch.zeros(4, dtype=torch.float32, device=device)
+        iters = 40000
+        t = timed(lambda: L.call("vgpt_calib_mfma", out.data_ptr(), iters, sp), 3)
+        res["mfma_loop_tflops"] = round(lib.vgpt_calib_mfma_flops(iters) / t / 1e12, 1)
+        nbytes = 1 << 30
+        src = torch.empty(nbytes, dtype=torch.uint8, device=device).fill_(1)
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        t = timed(lambda: L.call("vgpt_calib_copy", src.data_ptr(), dst.data_ptr(), nbytes, sp), 5)
+        res["hbm_copy_gbs"] = round(2 * nbytes / t / 1e9, 1)
+        del src, dst
+        g = torch.Generator(device=device).manual_seed(1234)
+        a = (torch.randn(8192, 8192, generator=g, device=device) * 0.5).to(BF)
+        w = (torch.randn(8192, 8192, generator=g, device=device) * 0.02).to(BF)
+        c = torch.empty(8192, 8192, dtype=BF, device=device)
+        t = timed(lambda: ops.linear(a, w, out=c), 10)
+        res["gemm_8192_tflops"] = round(2 * 8192.0 ** 3 / t / 1e12, 1)
+        del a, w, c
+    torch.cuda.empty_cache()
+    return res
+
+
+def pmc_records(kind):
+    """Counter evidence of one kernel kind from the committed rocprofv3 --pmc passes of THIS command (separate runs, as
+    MI355X_MICROARCH.md prescribes; scripts/pmc_traffic.py / pmc_mfma.py): beyond-L2 bytes per launch and matrix-pipe busy
+    fraction, each with the file it came from.  Not measured in this run -- `source` says so."""
+    pat = {"gate_up": ("gemm_bf16_kernel<1", "<256"), "qkv_rope": ("gemm_bf16_kernel<2", "<256"),
+           "o_proj": ("gemm_bf16_kernel<0", "<256"), "down_proj": ("gemm_bf16_kernel<0", "<256"),
+           "attn_fwd": ("attn_fwd_kernel<96", "")}[kind]
+    out = {}
+    for key, field, stems in (("traffic_bytes_per_launch", "traffic_bytes_per_launch", ("r03_pmc_traffic", "r02_pmc_traffic")),
+                              ("mfma_busy", "mfma_busy_frac", ("r03_pmc_mfma", "r02_pmc_mfma"))):
+        for stem in stems:
+            path = os.path.join(ROOT, "profiles", stem + ".json")
+            if not os.path.exists(path):
+                continue
+            try:
+                recs = [(rec["launches"], rec[field]) for name, rec in json.load(open(path))["kernels"].items()
+                        if pat[0] in name and pat[1] in name]
+            except Exception:
+                recs = []
+            if recs:
+                n = sum(a for a, _ in recs)
+                out[key] = round(sum(a * v for a, v in recs) / n, 4) if key == "mfma_busy" else int(sum(a * v for a, v in recs) / n)
+                out[key + "_source"] = f"profiles/{stem}.json (separate --pmc pass, not this run)"
+                break
+    if kind in ("o_proj", "down_proj") and out:
+        out["note"] = "o_proj and down_proj share one kernel instantiation: the counter figures are their launch-weighted mix"
+    return out
+
+
 def cpu_baseline(cfg_full, batch, layers_sample=2, with_vae=False):
     """CPU restatement of the reference path (oracle/restate.py) on a bounded sample: `layers_sample`
     of the 32 layers at full width over the full cfg-2 sequence; throughput scaled by layers."""
@@ -144,7 +214,7 @@ def bench_pipeline(args, rank, world, device, M, P, D):
     elapsed = D.timed_region(run, torch.cuda.synchronize, device)
     n_gen = 8 * args.rounds
     if rank == 0:
-        print(json.dumps({"metric": "end-to-end denoised clip-tokens/sec incl. VAE encode/decode (256^2, 8-frame next-clip, CFG, x1)",
+        print(json.dumps(tag_rehearsal({"metric": "end-to-end denoised clip-tokens/sec incl. VAE encode/decode (256^2, 8-frame next-clip, CFG, x1)",
                           "value": round(world * n_gen * 256 * args.steps / elapsed, 1), "unit": "clip-tokens/s", "n_gpus": world,
                           "steps": args.rounds, "warmup": 1, "ms_per_step": round(elapsed / args.rounds * 1e3, 1),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -153,7 +223,7 @@ def bench_pipeline(args, rank, world, device, M, P, D):
                                                  f"C=4 condition frames on round 0 then a 16-frame window, fp32 VAE ({args.vae_precision} convolutions), bf16 denoiser"
                                                  + (" with MX-fp8 attention in the sampler steps" if args.attn_precision == "fp8" else ""),
                                      "frames_returned": len(out[0]), "generated_frames_per_s": round(world * n_gen / elapsed, 2)},
-                          "roofline": None}), flush=True)
+                          "roofline": None}, args)), flush=True)
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()
@@ -198,7 +268,7 @@ def bench_vae(args, rank, world, device, D):
     if rank == 0:
         d = res["decode"]
         nfr = res["frames_per_step"]
-        print(json.dumps({"metric": f"VAE decode frames/sec (256^2, sdxl-vae, fp32 tensors, {args.vae_precision} convolutions)", "value": d["frames_per_s"], "unit": "frames/s",
+        print(json.dumps(tag_rehearsal({"metric": f"VAE decode frames/sec (256^2, sdxl-vae, fp32 tensors, {args.vae_precision} convolutions)", "value": d["frames_per_s"], "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(d["ms_per_frame"] * nfr, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32 (bf16x3 products)" if args.vae_precision == "bf16x3" else "f32", "data": "synthetic",
@@ -207,16 +277,26 @@ def bench_vae(args, rank, world, device, D):
                                        "peak": d["mfma"]["peak"], "unit": "TFLOP/s", "frac": d["mfma"]["frac"], "traffic": None,
                                        "note": "issued MFMA FLOPs (3x algorithmic for bf16x3) against the dense peak of the MFMA used; "
                                                "alg_frac in config.detail prices the algorithmic FLOPs",
-                                       "hbm_view": d["hbm_ideal_fusion"]}}), flush=True)
+                                       "hbm_view": d["hbm_ideal_fusion"]}}, args)), flush=True)
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()
 
 
+REHEARSAL_TAG = " [REHEARSAL: ranks share one GPU over gloo: INVALID]"
+
+
+def tag_rehearsal(line, args):
+    """--rehearse-on-one-gpu exercises the N > 1 code path with every rank on cuda:0: no such line is a measurement."""
+    if getattr(args, "rehearse_on_one_gpu", False):
+        line["config"]["workload"] += REHEARSAL_TAG
+        line["valid"] = False
+    return line
+
+
 def bench_stage1(args, rank, world, device, M, P, D, ops):
     line = measure_stage1(args.steps, args.warmup, args.layers, rank, world, device, M, P, D, grad_ckpt=args.grad_ckpt)
-    if args.rehearse_on_one_gpu:
-        line["config"]["workload"] += " [REHEARSAL: ranks share one GPU over gloo: INVALID]"
+    line = tag_rehearsal(line, args)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -332,6 +412,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-stage1", action="store_true",
                     help="skip the short stage-1 data-parallel training measurement appended to the default line")
+    ap.add_argument("--stage1-steps", type=int, default=10, help="timed steps of the stage-1 leg of the default line (2 warm-up)")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the box calibration launches around the timed region")
     ap.add_argument("--attn-precision", choices=["bf16", "fp8"], default="bf16",
                     help="infer / pipeline workloads: operands of the sampler steps' attention (fp8 = the cfg-5 option; "
                          "the headline metric is quoted on bf16)")
@@ -384,7 +466,7 @@ def main():
                               grad_ckpt=args.grad_ckpt)
         line["peak_memory_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            print(json.dumps(tag_rehearsal(line, args)), flush=True)
         return
 
     # ---- workload: cfg-2 ----
@@ -434,6 +516,9 @@ def main():
 
     stream = torch.cuda.Stream(device=device)
     use_graph = not args.no_graph
+    calibration = None
+    if rank == 0 and not args.no_calibration:
+        calibration = [calibrate(device, stream, ops, "before the timed region")]
     with torch.cuda.stream(stream):
         eng.set_latents(torch.cat(z, dim=0))
         if use_graph:
@@ -454,108 +539,76 @@ def main():
         eng.per_clip_setup()
         torch.cuda.synchronize()
         setup_s = time.perf_counter() - t0
+    if calibration is not None:
+        calibration.append(calibrate(device, stream, ops, "right after the timed region"))
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     value = world * G * N * args.steps / elapsed
     finite = bool(torch.isfinite(eng.z).all().item())
 
-    # ---- roofline of the dominant kernel: the plain NT GEMM (qkv_proj, o_proj, down_proj launches),
-    #      HIP events around every one of its launches during one extra eager denoise step ----
+    # ---- roofline: every hot kernel of the step timed live, back to back over the 32 layers on the step's own buffers and
+    #      weights (so weights stream from HBM as in the step), one HIP-event pair per kernel KIND on the stream the
+    #      launches go to; agrees with the rocprofv3 --stats averages of the graph run (profiles/).  The dominant kernel is
+    #      gemm_bf16_kernel (its four instantiations are 77 % of the step): `achieved` = the algorithmic FLOPs of all four
+    #      GEMMs of a layer over their summed launch time; `kernels` lists each instantiation and the attention forward. ----
     roof = None
     if rank == 0:
-        ev = []
-        orig_linear = ops.linear
-
-        def timed_linear(*a, **k):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record(stream)
-            out = orig_linear(*a, **k)
-            e.record(stream)
-            ev.append((s, e))
-            return out
-
-        orig_qkv = ops.linear_qkv_rope
-
-        def timed_qkv(*a, **k):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record(stream)
-            out = orig_qkv(*a, **k)
-            e.record(stream)
-            ev.append((s, e))
-            return out
-
+        nq_, nk_, hd_ = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        rows = eng.Ma if reuse else real_tokens_step
         with torch.cuda.stream(stream):
-            ops.linear = timed_linear
-            ops.linear_qkv_rope = timed_qkv
-            try:
-                eng.step.zero_()
-                ops.sampler_set_timesteps(eng.sigma, eng.step, eng.ts)
-                eng.forward_step(from_tables=True)
-            finally:
-                ops.linear = orig_linear
-                ops.linear_qkv_rope = orig_qkv
-            stream.synchronize()
-        t_bracketed = sum(s.elapsed_time(e) for s, e in ev) * 1e-3
-        n_launch = len(ev)
-        # A HIP-event pair around ONE launch also times the marker packets and the dispatch of the launch behind them
-        # (10-20 us here).  Second measurement, the one `achieved` uses: the same launches -- every layer's qkv (+RoPE),
-        # o_proj and down_proj on the step's own buffers and weights, so weights come from HBM as in the step -- back to
-        # back, one event pair per GEMM kind over the 32 layers; it agrees with the rocprofv3 average of the graph run.
-        t_gemm, b2b = t_bracketed, None
-        try:
-            with torch.cuda.stream(stream):
-                nq_, nk_, hd_ = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-                rope_ = eng.rope_a if eng.S else eng.rope
-                scratch = torch.empty_like(eng.hid)
-                kinds = (("qkv_rope", lambda l, li: orig_qkv(eng.nrm, l.self_attn.qkv_proj.weight, rope_[0], rope_[1], nq_, nk_, hd_,
-                                                             out=(eng.qkv_full[li][eng.S:] if eng.S else eng.qkv))),
-                         ("o_proj", lambda l, li: orig_linear(eng.ctx, l.self_attn.o_proj.weight, residual=eng.hid, out=scratch)),
-                         ("down_proj", lambda l, li: orig_linear(eng.act, l.mlp.down_proj.weight, residual=eng.hid, out=scratch)))
-                b2b, total = {}, 0.0
-                for name, fn in kinds:
-                    for li in (0, 1):
-                        fn(model.llm.layers[li], li)
-                    s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    s_.record(stream)
-                    for li, l in enumerate(model.llm.layers):
-                        fn(l, li)
-                    e_.record(stream)
-                    stream.synchronize()
-                    b2b[name] = round(s_.elapsed_time(e_) / nl * 1e3, 1)
-                    total += s_.elapsed_time(e_) * 1e-3
-                t_gemm = total
-        except Exception as ex:   # keep the bracketed number
-            b2b = {"error": repr(ex)[:200]}
-        # qkv (3H^2) + o (H^2) + down (HI) over the rows this forward_step ran (with special-row hoisting the 2 special
-        # tokens of every noisy frame are computed in the per-clip pass instead: n_frames x N rows per step)
-        alg = 2 * (4 * H * H + H * I) * (eng.Ma if reuse else real_tokens_step) * nl
+            rope_ = eng.rope_a if eng.S else eng.rope
+            scratch = torch.empty_like(eng.hid)
+            qkv_out = lambda li: (eng.qkv_full[li][eng.S:] if eng.S else eng.qkv)
+
+            def attn_call(l, li):
+                if eng.S:
+                    return ops.attention_qkv_range(eng.qkv_full[li].view(1, eng.L, -1), eng.pm, nq_, nk_, hd_, eng.S, eng.ctx,
+                                                   segments=eng.seg_live)
+                if eng.seg_all is not None:
+                    return ops.attention_qkv_range(eng.qkv, eng.pm, nq_, nk_, hd_, 0, eng.ctx, segments=eng.seg_all)
+                return ops.attention_qkv(eng.qkv, eng.pm, nq_, nk_, hd_, out=eng.ctx)
+            kinds = (("gate_up", "gemm_bf16_kernel<MODE_GATED> (gate_up_proj + act(gate) * up epilogue)", 2 * rows * H * 2 * I,
+                      lambda l, li: ops.gated_mlp_act(eng.nrm, l.mlp.gate_up_proj.weight, l.mlp.act, out=eng.act)),
+                     ("qkv_rope", "gemm_bf16_kernel<MODE_ROPE> (qkv_proj + RoPE epilogue)", 2 * rows * H * 3 * H,
+                      lambda l, li: ops.linear_qkv_rope(eng.nrm, l.self_attn.qkv_proj.weight, rope_[0], rope_[1], nq_, nk_, hd_,
+                                                        out=qkv_out(li))),
+                     ("down_proj", "gemm_bf16_kernel<MODE_PLAIN> (down_proj + residual)", 2 * rows * I * H,
+                      lambda l, li: ops.linear(eng.act, l.mlp.down_proj.weight, residual=eng.hid, out=scratch)),
+                     ("o_proj", "gemm_bf16_kernel<MODE_PLAIN> (o_proj + residual)", 2 * rows * H * H,
+                      lambda l, li: ops.linear(eng.ctx, l.self_attn.o_proj.weight, residual=eng.hid, out=scratch)),
+                     ("attn_fwd", "attn_fwd_kernel<96> (block-masked flash attention, planned launch)", flops_attn // nl, attn_call))
+            klist = []
+            for name, kname, alg, fn in kinds:
+                for li in (0, 1):
+                    fn(model.llm.layers[li], li)
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record(stream)
+                for li, l in enumerate(model.llm.layers):
+                    fn(l, li)
+                e_.record(stream)
+                stream.synchronize()
+                us = s_.elapsed_time(e_) / nl * 1e3
+                rec = {"name": name, "kernel": kname, "launches_per_step": nl, "avg_us": round(us, 1),
+                       "alg_gflop_per_launch": round(alg / 1e9, 1), "achieved_tflops": round(alg / us / 1e6, 1),
+                       "frac": round(alg / us / 1e6 / PEAK_BF16_TFLOPS, 4), "share_of_step": round(us * nl / (ms_per_step * 1e3), 3)}
+                rec.update(pmc_records(name))
+                klist.append(rec)
+        gem = [k for k in klist if k["name"] != "attn_fwd"]
+        t_gemm = sum(k["avg_us"] for k in gem) * 1e-6 * nl
+        alg = sum(k["alg_gflop_per_launch"] for k in gem) * 1e9 * nl
+        n_launch = len(gem) * nl
         achieved = alg / t_gemm / 1e12
-        traffic = None  # per-launch bytes beyond L2 of that kernel from the committed PMC passes (scripts/pmc_traffic.py)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-                recs = [(rec["launches"], rec["traffic_bytes_per_launch"]) for name, rec in json.load(f)["kernels"].items()
-                        if "gemm_bf16_kernel<0" in name and "TileCfg<256" in name]
-                if recs:
-                    traffic = int(sum(n * v for n, v in recs) / sum(n for n, _ in recs))
-        except Exception:
-            traffic = None
-        mfma_busy = None  # matrix-pipe busy fraction of that kernel from the committed SQ counter pass (scripts/pmc_mfma.py)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_mfma.json")) as f:
-                recs = [(rec["launches"], rec["mfma_busy_frac"]) for name, rec in json.load(f)["kernels"].items()
-                        if "gemm_bf16_kernel<0" in name and "TileCfg<256" in name]
-                if recs:
-                    mfma_busy = round(sum(n * v for n, v in recs) / sum(n for n, _ in recs), 4)
-        except Exception:
-            mfma_busy = None
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<MODE_PLAIN | MODE_ROPE> (qkv_proj with the RoPE epilogue, o_proj, down_proj)",
+        traf = [k.get("traffic_bytes_per_launch") for k in gem]
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all four instantiations of a decoder layer: gate_up, qkv_proj + RoPE, "
+                                           "down_proj, o_proj; 128 launches per step)",
                 "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "mfma_busy_pmc": mfma_busy,
-                "launches": n_launch, "avg_launch_us": round(t_gemm / max(n_launch, 1) * 1e6, 1),
-                "peak_note": "2500 = nominal dense bf16 peak (MI355X_MICROARCH.md); nothing-but-MFMA loops on random operands "
-                             "sustain 1840-1930 TFLOP/s on this part (scripts/probes/mfma_shape_rate.hip, DESIGN.md section 4)",
-                "avg_launch_us_by_kind_back_to_back": b2b,
-                "avg_launch_us_event_pair_per_launch": round(t_bracketed / max(n_launch, 1) * 1e6, 1),
-                "alg_flops_per_launch": alg / max(n_launch, 1),
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                "traffic": int(sum(traf) / len(traf)) if all(t is not None for t in traf) else None,
+                "traffic_source": gem[0].get("traffic_bytes_per_launch_source"),
+                "launches": n_launch, "avg_launch_us": round(t_gemm / n_launch * 1e6, 1),
+                "alg_flops_per_launch": alg / n_launch,
+                "peak_note": "2500 = nominal dense bf16 peak (MI355X_MICROARCH.md); calibration.mfma_loop_tflops is what "
+                             "nothing-but-MFMA loops on random operands sustain on THIS box in this run",
+                "kernels": klist,
                 "whole_step": {"alg_tflop": round(flops_step / 1e12, 2), "prefill_tflop_once": round(flops_prefill / 1e12, 2),
                                "achieved": round((flops_step * args.steps + flops_prefill) / elapsed / 1e12, 1),
                                "frac": round((flops_step * args.steps + flops_prefill) / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4)}}
@@ -592,14 +645,14 @@ def main():
         breakdown = {n: {"calls": len(v), "ms": round(sum(a.elapsed_time(b) for a, b in v), 3)} for n, v in evs.items() if v}
 
     # ---- second half of the BASELINE metric: stage-1 train samples/sec at this GPU count (data parallel over RCCL),
-    #      a short run (1 warm-up + 3 steps) on the same model; reported inside the same JSON line ----
+    #      2 warm-up + --stage1-steps (default 10) timed steps on the same model; reported inside the same JSON line ----
     hoisted, rows_per_step = bool(eng.hoist), int(eng.Ma) if reuse else real_tokens_step
     stage1 = None
     if not args.no_stage1 and args.layers == 32:
         del eng
         torch.cuda.empty_cache()
         try:
-            s1 = measure_stage1(3, 1, args.layers, rank, world, device, M, P, D, model=model)
+            s1 = measure_stage1(args.stage1_steps, 2, args.layers, rank, world, device, M, P, D, model=model)
             stage1 = {k: s1[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup")}
             stage1["config"] = s1["config"]
             stage1["roofline"] = s1["roofline"]
@@ -633,12 +686,12 @@ def main():
                            "per_clip_setup_ms": round(setup_s * 1e3, 2),
                            "ms_per_step_of_a_50_step_clip": round(((elapsed - setup_s) / max(args.steps, 1) * 50 + setup_s) / 50 * 1e3, 3),
                            "finite": finite},
-                "roofline": roof, "stage1_train": stage1, "vae": vae_obj}
+                "roofline": roof, "calibration": calibration, "stage1_train": stage1, "vae": vae_obj}
         if breakdown:
             line["breakdown_ms_per_step"] = breakdown
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, dict(batch, attention_mask=dense_mask), with_vae=args.cpu_baseline_vae)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(tag_rehearsal(line, args)), flush=True)
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()

@@ -46,6 +46,10 @@ extern "C" {
 #define VGPT_PRED_X1 1
 
 const char* vgpt_last_error(void);
+/* VGPT_ABI_VERSION of the library that was loaded.  Bumped with EVERY change of an exported signature; a binding written
+ * for another value must refuse to call (video-gpt_amd/_lib.py does): with shifted arguments a stale library would read a
+ * stream pointer as a scale and fault on the device instead of failing cleanly. */
+#define VGPT_ABI_VERSION 3
 int vgpt_abi_version(void);
 
 /* ---- transformer block -------------------------------------------------- */
@@ -401,6 +405,15 @@ int vgpt_graph_begin_capture(void* stream);
 int vgpt_graph_end_capture(void* stream, void** graph_exec_out);
 int vgpt_graph_launch(void* graph_exec, void* stream);
 int vgpt_graph_destroy(void* graph_exec);
+
+/* ---- box calibration (bench.py `calibration`; never on the product path) -- */
+/* 256 workgroups x 8 waves of nothing but mfma_f32_16x16x32_bf16 on random register operands: the rate the matrix pipes
+ * hold at the clock this device grants under load (scripts/probes/mfma_shape_rate.hip is the stand-alone form);
+ * vgpt_calib_mfma_flops(iters) = the FLOPs one such launch executes.  vgpt_calib_copy: 16-byte-per-lane streaming copy
+ * of n_bytes (n_bytes read + n_bytes written): the HBM rate.  The caller times the launches with events on `stream`. */
+int vgpt_calib_mfma(float* out, int iters, void* stream);
+double vgpt_calib_mfma_flops(int iters);
+int vgpt_calib_copy(const void* src, void* dst, int64_t n_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -4,11 +4,14 @@
     python tests/make_golden.py
 
 Vectors whose name starts with `ref_` come from the REFERENCE'S OWN classes executed through
-oracle/extract_reference.py (collator, prompt layout, LVMScheduler, TimestepEmbedder, FinalLayer,
-PatchEmbedMR, sincos tables) — they pin the oracle and the product's host logic.  `oracle_*`
-vectors come from the CPU restatement (oracle/restate.py) where the reference cannot run here
-(the Phi3 decoder stack and LVM.frame_block_forward: parity unpinned by the reference, see
-oracle/__init__.py); they freeze the oracle so that GPU parity tests have a committed target.
+oracle/extract_reference.py: collator, prompt layout, LVMScheduler, TimestepEmbedder, FinalLayer, PatchEmbedMR, sincos
+tables (`ref_collator_*`, `ref_scheduler`, `ref_leaf_modules`) and — since round 2 — the reference's LVM /
+LVMTraining / Phi3Transformer.forward / new_forward / training loss (`lvm_glue_vectors()`, `ref_lvm_glue_tiny`,
+`ref_loss_*_tiny`) and its LVMPipeline (`ref_pipeline_*`), run on CPU fp32 with the third-party imports stubbed as
+oracle/extract_reference.py describes (installed transformers 5.x Phi3 blocks adapted to the 4.47.1 call signatures).
+They pin the oracle and the product's host logic.  `oracle_tiny_e2e.npz` is the one file produced by the CPU restatement
+itself (oracle/restate.py): it freezes the oracle's end-to-end numbers so a later edit of the restatement is noticed; the
+restatement in turn equals the `ref_` vectors to <= 1e-5 (tests/test_oracle_pins.py).
 Only data is stored (inputs / expected outputs), never reference source text.
 """
 import os

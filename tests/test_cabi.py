@@ -44,12 +44,23 @@ def test_python_binding_covers_header(lib):
 
 def test_abi_version_and_error_string(lib):
     cdll = lib.load()
-    assert cdll.vgpt_abi_version() == 1
+    assert cdll.vgpt_abi_version() == lib.ABI_VERSION
+    hdr = open(os.path.join(ROOT, "include", "vgpt.h")).read()
+    assert int(re.search(r"#define VGPT_ABI_VERSION (\d+)", hdr).group(1)) == lib.ABI_VERSION
     # argument validation happens on the host before any launch: no GPU needed
     rc = cdll.vgpt_rmsnorm_fwd(None, None, None, 1, 64, 1e-5, None)
     assert rc == -1 and b"null pointer" in cdll.vgpt_last_error()
     rc = cdll.vgpt_attn_supported(96), cdll.vgpt_attn_supported(80)
     assert rc == (1, 0)
+
+
+def test_stale_library_is_refused(lib, monkeypatch):
+    """A library whose vgpt_abi_version() differs from the constant the binding was written for is never called."""
+    lib.load()
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "ABI_VERSION", lib.ABI_VERSION + 1)
+    with pytest.raises(lib.VgptError, match="ABI version"):
+        lib.load()
 
 
 def test_product_path_has_no_cpu_fallback(lib):

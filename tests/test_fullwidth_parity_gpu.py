@@ -49,7 +49,7 @@ def test_cfg2_decoder_layer_full_width(full_params):
     with torch.no_grad():
         ref = R.transformer(p, cfg, emb, batch["attention_mask"], batch["position_ids"])
     valid = batch["input_ids"] != cfg.pad_token_id
-    assert SC.rel_l2(out.cpu()[valid], ref[valid]) < 2e-2
+    assert SC.rel_l2(out.cpu()[valid], ref[valid]) < SC.tol("fullwidth_hidden")   # 2 x stock bf16 at full width: 1.3e-2
     # per-head check of the attention output columns is implied: every head's 96 columns feed o_proj; a wrong head
     # stride shows up as an O(1) error.  Worst rows (block seams) separately:
     err_rows = ((out.cpu().float() - ref) ** 2).sum(-1).sqrt() / (ref ** 2).sum(-1).sqrt()

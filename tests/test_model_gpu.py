@@ -1,8 +1,9 @@
 """GPU parity of the assembled model and sampler (product HIP path vs CPU fp32 oracle on identical
 bf16-representable weights, identical noise seeds).
 
-Tolerance: rel-L2 <= 3e-2 on predicted latents (bf16 activations through 2 layers + heads; SURVEY.md
-§8d states ~1e-2 per layer / ~3e-2 on 1-step latents for bf16 vs the fp32 oracle).
+Tolerances are measured, not guessed: 2 x the rel-L2 error torch's stock bf16 ops make on the same inputs against the
+fp32 oracle (scripts/calibrate_tolerances.py -> tests/golden/tolerance_calibration.json): 2.3e-2 on
+one-forward latents, 2.9e-2 on sampled latents, 1.1e-2 on hidden states, 1.6e-2 on the single-target forward.
 """
 import importlib
 
@@ -15,7 +16,9 @@ from tests import smoke_case as SC
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 BF = torch.bfloat16
-TOL = 3e-2
+# tolerances: 2 x the measured error of stock bf16 ops on the same inputs (tests/golden/tolerance_calibration.json,
+# scripts/calibrate_tolerances.py), per quantity
+TOL_FWD, TOL_SMP, TOL_HID, TOL_ONE = (SC.tol(q) for q in ("forward_latents", "sampler_latents", "llm_hidden", "single_forward_latents"))
 
 
 @pytest.fixture(scope="module")
@@ -36,8 +39,8 @@ def test_transformer_hidden_states(case):
                     position_ids=batch["position_ids"].to(DEV)).last_hidden_state
     ref = R.transformer(p, cfg, emb, batch["attention_mask"], batch["position_ids"])
     valid = batch["input_ids"] != cfg.pad_token_id  # pad rows are don't-care for the model outputs, but still match
-    assert SC.rel_l2(out, ref) < TOL
-    assert SC.rel_l2(out.cpu()[valid], ref[valid]) < TOL
+    assert SC.rel_l2(out, ref) < TOL_HID
+    assert SC.rel_l2(out.cpu()[valid], ref[valid]) < TOL_HID
 
 
 def test_transformer_rejects_2d_mask(case):
@@ -59,7 +62,7 @@ def test_frame_block_forward_with_cfg(case, prediction_type):
     okw = {k: batch[k] for k in ("input_ids", "input_image_sizes", "attention_mask", "position_ids",
                                  "denoise_image_sizes", "time_emb_inx")}
     ref = R.frame_block_forward_with_cfg(p, cfg, z, t, True, 1.6, prediction_type, input_img_latents=cond, **okw)
-    assert SC.rel_l2(torch.cat(out), torch.cat(ref)) < TOL
+    assert SC.rel_l2(torch.cat(out), torch.cat(ref)) < TOL_FWD
 
 
 def test_seam_replace_attention_matches_fused(case):
@@ -104,7 +107,7 @@ def test_sampler_fast_path(case, prediction_type, use_graph, pack):
                 prediction_type=prediction_type)
     assert sched.last_engine is not None and sched.last_engine.packed == pack
     ref = SC.oracle_sample(cfg, p, batch, z, cond, steps, prediction_type)
-    assert SC.rel_l2(torch.cat(out), torch.cat(ref)) < TOL
+    assert SC.rel_l2(torch.cat(out), torch.cat(ref)) < TOL_SMP
 
 
 def test_sampler_generic_path_matches_fast_path(case):
@@ -130,7 +133,7 @@ def test_shift_and_sigma_table():
 
 
 def test_smoke_entry():
-    assert SC.run_smoke(verbose=False) < TOL
+    assert SC.run_smoke(verbose=False) < TOL_SMP
 
 
 def test_single_target_forward(case):
@@ -151,17 +154,17 @@ def test_single_target_forward(case):
     ref = R.lvm_forward(p, cfg, x, t, ids, lat, sizes, mask, pos)
     out, cache = model.forward(x.to(DEV, BF), t.to(DEV), ids.to(DEV), [lat[0].to(DEV, BF)], sizes, mask.to(DEV), pos.to(DEV))
     assert cache is None and out.shape == x.shape
-    assert SC.rel_l2(out, ref) < TOL
+    assert SC.rel_l2(out, ref) < TOL_ONE
     # 'v' CFG on the batch halves
     o2, _ = model.forward_with_cfg(x.to(DEV, BF), t.to(DEV), ids.to(DEV), [lat[0].to(DEV, BF)], sizes, mask.to(DEV),
                                    pos.to(DEV), True, 1.6, None, False, False, prediction_type="v")
     c = ref[1:2] + 1.6 * (ref[0:1] - ref[1:2])
-    assert SC.rel_l2(o2, torch.cat([c, c])) < TOL
+    assert SC.rel_l2(o2, torch.cat([c, c])) < TOL_ONE
     # no condition tokens
     out3 = model.forward(x.to(DEV, BF), t.to(DEV), None, None, None, mask[:, Lc:, Lc:].contiguous().to(DEV),
                          pos[:, : N + 1].contiguous().to(DEV), return_past_key_values=False)
     ref3 = R.lvm_forward(p, cfg, x, t, None, None, None, mask[:, Lc:, Lc:], pos[:, : N + 1])
-    assert SC.rel_l2(out3, ref3) < TOL
+    assert SC.rel_l2(out3, ref3) < TOL_ONE
 
 
 def test_condition_prefix_reuse_matches_full_recompute():
@@ -182,7 +185,7 @@ def test_condition_prefix_reuse_matches_full_recompute():
             eng = sched.last_engine
             assert eng.S == 256 and eng.Ma == eng.L - 256      # 132-row prefix padded to 2 x 128
     ref = torch.cat(SC.oracle_sample(cfg, p, batch, z, cond, 3, "x1"))
-    assert SC.rel_l2(outs[True], ref) < TOL
+    assert SC.rel_l2(outs[True], ref) < TOL_SMP
     assert SC.rel_l2(outs[True], outs[False]) < 5e-3
 
 
@@ -222,7 +225,7 @@ def test_special_row_hoisting_matches_full_recompute(use_cfg, C, G, hw):
             assert eng.S0 == C * bl and eng.S == (C * bl + 2 * nf + 127) // 128 * 128 and eng.Ma == nf * N   # image rows only
             assert eng.time_qkv.shape[:3] == (steps, cfg.num_hidden_layers, nf)
     ref = torch.cat(SC.oracle_sample(cfg, p, batch, z, cond, steps, "x1", use_cfg=use_cfg))
-    assert SC.rel_l2(outs["hoist"], ref) < TOL
+    assert SC.rel_l2(outs["hoist"], ref) < TOL_SMP
     assert SC.rel_l2(outs["hoist"], outs["none"]) < 5e-3 and SC.rel_l2(outs["hoist"], outs["prefix"]) < 5e-3
 
 

@@ -96,3 +96,46 @@ def test_device_rope_table_with_longrope(long):
     qr, kr = R.apply_rope(q, k, cf.float(), sf.float())
     ref = torch.cat([qr.transpose(1, 2).reshape(B, L, -1), kr.transpose(1, 2).reshape(B, L, -1), qkv.float()[..., 4 * HD:]], -1)
     assert float((out - ref).norm() / ref.norm()) < 1e-2
+
+
+@pytest.mark.gpu
+def test_engine_hoisted_rows_use_the_whole_sequence_rope_factors():
+    """su / longrope picks short or long factors from the largest position of the WHOLE sequence (HF 4.47.1
+    Phi3LongRoPEScaledRotaryEmbedding.forward).  Layout where only the image rows cross original_max_position_embeddings
+    while the hoisted time rows (computed in a per-clip pass of their own) stay below it: the hoisted engine must rotate
+    them with the same (long) factors as the full recompute does."""
+    from tests import smoke_case as SC
+    S = importlib.import_module("video-gpt_amd.scheduler")
+    P = importlib.import_module("video-gpt_amd.processor")
+    LY = importlib.import_module("video-gpt_amd.layout")
+    cfg, C, G, hw, steps = R.TINY, 2, 2, (16, 16), 3
+    bl = (hw[0] // 2) * (hw[1] // 2) + 2
+    p, batch, z, cond = SC.build_case(cfg, C=C, G=G, hw=hw, use_cfg=True)
+    pos = batch["position_ids"]
+    t_rows = [t for b in batch["time_emb_inx"] for t in batch["time_emb_inx"][b]]
+    t_max = max(int(pos[b, t]) for b in batch["time_emb_inx"] for t in batch["time_emb_inx"][b])
+    orig = t_max + 2                      # time rows alone: short factors; the whole sequence: long factors
+    assert int(pos.max()) + 1 > orig > t_max + 1 and t_rows
+    half = cfg.head_dim // 2
+    scaling = {"type": "longrope", "short_factor": [1.0 + 0.01 * i for i in range(half)],
+               "long_factor": [1.5 + 0.25 * i for i in range(half)]}
+    pc = M.Phi3Config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                      num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                      num_key_value_heads=cfg.num_key_value_heads, hidden_act=cfg.hidden_act, rms_norm_eps=cfg.rms_norm_eps,
+                      rope_theta=cfg.rope_theta, pad_token_id=cfg.pad_token_id, max_position_embeddings=4 * orig,
+                      original_max_position_embeddings=orig, rope_scaling=scaling)
+    model = M.LVM(pc, pos_embed_max_size=cfg.pos_embed_max_size)
+    model.load_state_dict(p, strict=True)
+    model = model.to("cuda:0", torch.bfloat16).eval()
+    lay = LY.TokenLayout.from_plans([(P.plan_inference([C, G])[0], bl, 0), (P.plan_inference([0, G])[0], bl, C * bl)],
+                                    (C + G) * bl)
+    outs = {}
+    for mode in ("hoist", "none"):
+        sched = S.LVMScheduler(num_steps=steps)
+        sched.reuse_condition_prefix = sched.hoist_special_rows = mode == "hoist"
+        kw = SC.model_kwargs(batch, cond, "cuda:0", use_cfg=True)
+        kw["attention_mask"] = lay
+        outs[mode] = torch.cat(sched([x.to("cuda:0", torch.bfloat16) for x in z], model.frame_block_forward_with_cfg, kw,
+                                     prediction_type="x1"))
+        assert bool(sched.last_engine.hoist) == (mode == "hoist")
+    assert SC.rel_l2(outs["hoist"], outs["none"]) < 5e-3

@@ -68,4 +68,4 @@ def test_ulysses_two_ranks_match_single_rank_and_oracle():
                                 input_image_sizes=batch["input_image_sizes"], attention_mask=batch["attention_mask"],
                                 position_ids=batch["position_ids"], denoise_image_sizes=batch["denoise_image_sizes"],
                                 time_emb_inx=batch["time_emb_inx"])
-    assert SC.rel_l2(torch.from_numpy(o0), torch.cat(ref)) < 3e-2
+    assert SC.rel_l2(torch.from_numpy(o0), torch.cat(ref)) < SC.tol("forward_latents")

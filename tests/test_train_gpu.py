@@ -1,7 +1,9 @@
 """GPU parity of the stage-1 training step (HIP backward kernels, loss, AdamW) against torch autograd on the
 CPU fp32 oracle (oracle/restate.py::stage1_loss) with identical bf16-representable weights and noise.
 
-Tolerances: bf16 kernels vs fp32 autograd — rel-L2 <= 2e-2 for single backward ops, <= 6e-2 for parameter
+Tolerances: bf16 kernels vs fp32 autograd — rel-L2 <= 2e-2 for single backward ops; loss and parameter gradients of the
+assembled model: 2 x the measured error of stock bf16 autograd on the same inputs (4e-3 / 1.6e-2,
+tests/golden/tolerance_calibration.json, scripts/calibrate_tolerances.py); formerly hand-set: <= 6e-2 for parameter
 gradients through the 2-layer model (bf16 activations AND bf16 gradients at every layer boundary);
 loss <= 2e-2 relative; AdamW (fp32 master) <= 1e-5 vs torch.optim.AdamW."""
 import importlib
@@ -243,14 +245,14 @@ def test_loss_function_with_reference_signature():
     kw["input_img_latents"] = list(clean.split(1))
     torch.manual_seed(123)                       # CPU latents -> CPU draws, the reference's stream
     terms = LS.training_losses_x1_noise_input(model, list(x1.split(1)), dict(kw), device=DEV)
-    assert rel_l2(terms["loss"], torch.from_numpy(d["loss"])) < 2e-2
+    assert rel_l2(terms["loss"], torch.from_numpy(d["loss"])) < SC.tol("loss")
     # through a trainer the same call also back-propagates and (update=True) steps the optimizer
     tr = TR.Stage1Trainer(model, lr=1e-3)
     torch.manual_seed(123)
     t2 = LS.training_losses_x1_noise_input(tr, list(x1.split(1)), dict(kw), device=DEV, update=True)
     assert torch.equal(t2["loss"], terms["loss"]) and tr.step_count == 1
     key = "llm.layers.0.self_attn.o_proj.weight"
-    assert rel_l2(torch.from_numpy(GC.sampled_grad(tr.grads[key].float().cpu())), torch.from_numpy(d["grad." + key])) < 6e-2
+    assert rel_l2(torch.from_numpy(GC.sampled_grad(tr.grads[key].float().cpu())), torch.from_numpy(d["grad." + key])) < SC.tol("param_grads")
 
 
 def test_stage1_loss_and_gradients_match_autograd():
@@ -266,14 +268,17 @@ def test_stage1_loss_and_gradients_match_autograd():
     dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
     loss = tr.step(dbatch, x1, x0, t, clean, x0i, ti, update=False)
     assert rel_l2(tr.last["xt"], torch.cat(xt_ref)) < 4e-3
-    assert rel_l2(loss, loss_ref.detach()) < 2e-2
-    bad = {}
+    e_loss = rel_l2(loss, loss_ref.detach())
+    assert e_loss < SC.tol("loss"), e_loss
+    bad, worst = {}, 0.0
     for name, ref in pr.items():
         if name == "pos_embed":
             continue
         err = rel_l2(tr.grads[name], ref.grad)
-        if not err < 6e-2:
+        worst = max(worst, err)
+        if not err < SC.tol("param_grads"):
             bad[name] = err
+    print(f"stage-1 tiny: loss error {e_loss:.3e} (tol {SC.tol('loss'):.3e}), worst gradient error {worst:.3e} (tol {SC.tol('param_grads'):.3e})")
     assert not bad, bad
     # the full step: clip to 1.0 on the global norm, AdamW on fp32 master weights
     total = math.sqrt(sum(float(v.grad.double().pow(2).sum()) for k, v in pr.items() if k != "pos_embed"))
@@ -334,8 +339,8 @@ def test_stage2_frame_block_layout_gradients():
     tr = TR.Stage1Trainer(model)
     dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
     loss = tr.step(dbatch, x1, x0, t, clean, x0i, ti, update=False)
-    assert rel_l2(loss, loss_ref.detach()) < 2e-2
-    bad = {n_: rel_l2(tr.grads[n_], r.grad) for n_, r in pr.items() if n_ != "pos_embed" and not rel_l2(tr.grads[n_], r.grad) < 6e-2}
+    assert rel_l2(loss, loss_ref.detach()) < SC.tol("loss")
+    bad = {n_: rel_l2(tr.grads[n_], r.grad) for n_, r in pr.items() if n_ != "pos_embed" and not rel_l2(tr.grads[n_], r.grad) < SC.tol("param_grads")}
     assert not bad, bad
 
 
@@ -441,7 +446,7 @@ def test_data_parallel_two_ranks_stay_in_sync():
         p_.join(timeout=120)
         assert p_.exitcode == 0
     (_, w0, e0, n0, g0), (_, w1, e1, n1, g1) = res
-    assert g0 == g1 and all(v < 6e-2 for v in g0.values()), g0   # reduced gradient == mean of the per-rank oracle gradients
+    assert g0 == g1 and all(v < SC.tol("param_grads") for v in g0.values()), g0   # reduced gradient == mean of the per-rank oracle gradients
     assert n0 == n1 and n0 > 0, (n0, n1)                          # same all-reduced gradient norm on both ranks
     assert np.array_equal(w0, w1), float(np.abs(w0 - w1).max())   # replicas identical after all-reduced updates
     assert np.array_equal(e0, e1), float(np.abs(e0 - e1).max())

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VGPT_LIB selects another build of the same library (the `make stamps` diagnostic build); never a different backend
@@ -21,6 +21,8 @@ PRED_V, PRED_X1 = 0, 1
 
 _P = c_void_p
 _I64 = c_int64
+# VGPT_ABI_VERSION (include/vgpt.h) the SIGNATURES table below was written for; load() refuses any other library
+ABI_VERSION = 3
 
 # name -> (restype, argtypes); every symbol declared in include/vgpt.h
 SIGNATURES = {
@@ -106,6 +108,9 @@ SIGNATURES = {
     "vgpt_graph_end_capture": (c_int, [_P, POINTER(c_void_p)]),
     "vgpt_graph_launch": (c_int, [_P, _P]),
     "vgpt_graph_destroy": (c_int, [_P]),
+    "vgpt_calib_mfma": (c_int, [_P, c_int, _P]),
+    "vgpt_calib_mfma_flops": (c_double, [c_int]),
+    "vgpt_calib_copy": (c_int, [_P, _P, _I64, _P]),
 }
 
 
@@ -130,6 +135,15 @@ def load() -> ctypes.CDLL:
     # with ours (/opt/rocm) loaded first, torch's device state and our launches end up in different runtimes
     import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
+    ver = getattr(lib, "vgpt_abi_version", None)
+    got = None
+    if ver is not None:
+        ver.restype, ver.argtypes = c_int, []
+        got = ver()
+    if got != ABI_VERSION:
+        raise VgptError(f"{LIB_PATH} reports ABI version {got}, this binding was written for {ABI_VERSION}: the library is "
+                        "stale (rebuild it: `python -c 'import __graft_entry__ as g; g.build()'`); calling it with shifted "
+                        "arguments would fault on the device")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name, None)
         if fn is None:

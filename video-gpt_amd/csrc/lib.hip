@@ -14,7 +14,7 @@ void vgpt_set_error(const char* fmt, ...) {
 }
 
 VGPT_EXPORT const char* vgpt_last_error(void) { return g_err; }
-VGPT_EXPORT int vgpt_abi_version(void) { return 1; }
+VGPT_EXPORT int vgpt_abi_version(void) { return VGPT_ABI_VERSION; }
 
 VGPT_EXPORT int vgpt_graph_begin_capture(void* stream) {
     hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);

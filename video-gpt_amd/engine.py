@@ -406,11 +406,11 @@ class StaticDenoiser:
             ops.linear_small(sin[c:c + 32], tt[0].weight, tt[0].bias, post_act=ops.ACT_SILU, out=tt_h[c:c + 32])
             ops.linear_small(tt_h[c:c + 32], tt[2].weight, tt[2].bias, out=tt_o[c:c + 32])
         hid.view(T, nf, H)[:] = tt_o[:, None, :]
-        zpos = lambda n_: torch.zeros(n_, dtype=self.position_ids.dtype, device=dev)
-        pos = torch.cat([self.position_ids[0, :S0], zpos(P0 - S0), self.position_ids[0, S0:S0 + nf].repeat(T),
-                         zpos(P1 - P0 - T * nf), self.position_ids[0, S0 + nf:S0 + 2 * nf].repeat(T)]).view(1, Lp)
-        rope = m.llm.rope_tables(pos)
-        rope_s = (rope[0][P1:].contiguous(), rope[1][P1:].contiguous())
+        # the time rows' cos / sin are ROWS OF THE CLIP'S OWN TABLE (self.rope, built from the full position_ids): a su /
+        # longrope checkpoint picks short or long factors from the largest position of the WHOLE sequence (HF 4.47.1
+        # Phi3LongRoPEScaledRotaryEmbedding), which a table rebuilt from this pass's rows alone would get wrong whenever
+        # only the image rows cross original_max_position_embeddings
+        rope_s = tuple(t_[S0 + nf:S0 + 2 * nf].repeat(T, 1).contiguous() for t_ in self.rope)
         buf = torch.zeros(Lp, W3, dtype=BF16, device=dev)
         shape = (T, cfg.num_hidden_layers, nf, W3)
         if self.time_qkv is None or tuple(self.time_qkv.shape) != shape:

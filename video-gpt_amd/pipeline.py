@@ -99,6 +99,15 @@ class LVMPipeline:
         arr = u8.cpu().numpy()
         return [Image.fromarray(arr[i]) for i in range(arr.shape[0])]
 
+    def _rebuilt_processor(self, max_input_image_size: int):
+        """A processor for another max_input_image_size keeps the sequence-parallel padding of the one it replaces (the
+        reference passes hccl_info.world_size, LVM/pipeline.py:232) and its mask format."""
+        old = self.processor
+        new = LVMProcessor(old.text_tokenizer, max_image_size=max_input_image_size,
+                           sequence_parallel_size=getattr(old, "sequence_parallel_size", 1))
+        new.collator.mask_format = old.collator.mask_format
+        return new
+
     @torch.no_grad()
     def __call__(self, input_images=None, height: int = 1024, width: int = 1024, gen_num: int = 1,
                  num_inference_steps: int = 50, use_img_guidance: bool = True, img_guidance_scale: float = 1.6,
@@ -130,7 +139,7 @@ class LVMPipeline:
             use_img_guidance = False if ori_input_images is None else ori_use_img_guidance
             prompt = "".join(f"<img><|image_{i + 1}|></img>" for i in range(len(ori_input_images or [])))
             if max_input_image_size != self.processor.max_image_size:
-                self.processor = LVMProcessor(self.processor.text_tokenizer, max_image_size=max_input_image_size)
+                self.processor = self._rebuilt_processor(max_input_image_size)
             self.processor.collator.hidden_size = self.model.hidden_size
             self.model.to(self.device, dtype)
             input_data = self.processor([prompt], [list(ori_input_images)] if ori_input_images is not None else None,
@@ -176,8 +185,14 @@ class LVMPipeline:
             samples = samples.chunk(1 + num_cfg, dim=0)[0]
             self.last_samples.append(samples)
             if gen_idx == 0 and input_img_latents:
-                u8 = self.vae.decode_to_uint8(torch.cat(input_img_latents, dim=0))
-                output_images.extend(self._to_images(u8, output_type))
+                # the single-target path lets every condition image keep its own cropped resolution (process_image /
+                # crop_arr; the reference decodes them one by one, LVM/pipeline.py:307-318): one batched decode only when
+                # all latents share a shape
+                if len({tuple(t.shape) for t in input_img_latents}) == 1:
+                    output_images.extend(self._to_images(self.vae.decode_to_uint8(torch.cat(input_img_latents, dim=0)), output_type))
+                else:
+                    for lat in input_img_latents:
+                        output_images.extend(self._to_images(self.vae.decode_to_uint8(lat), output_type))
             u8 = self.vae.decode_to_uint8(samples)
             output_image = self._to_images(u8[:1], output_type)[0]
             output_images.append(output_image)
@@ -222,7 +237,7 @@ class LVMPipeline:
             else:
                 prompts, images = [prompt], [list(input_images)]
             if max_input_image_size != self.processor.max_image_size:
-                self.processor = LVMProcessor(self.processor.text_tokenizer, max_image_size=max_input_image_size)
+                self.processor = self._rebuilt_processor(max_input_image_size)
             # the sampler path never materialises the (B,L,L) mask: the collator hands over per-token attributes and
             # the device expands them into the packed rows the attention kernel reads (layout.TokenLayout)
             self.processor.collator.mask_format = self.mask_format

@@ -37,10 +37,18 @@ class Stage1Trainer:
     def __init__(self, model, lr: float = 1e-4, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: Optional[float] = 1.0, input_noise: float = 0.9, pack_padding: bool = True,
                  lr_scheduler: str = "constant", lr_warmup_steps: int = 0, gradient_checkpointing: Optional[bool] = None,
-                 forward_only: bool = False):
+                 forward_only: bool = False, lr_scheduler_steps_per_optimizer_step: int = 1):
         """lr_scheduler / lr_warmup_steps: diffusers' get_scheduler("constant" | "constant_with_warmup")
         (train_x1_stage1_noiseinput.py:279-283; the scripts use constant_with_warmup): the k-th optimizer step (k = 0, 1,
-        ...) runs at lr * min(1, k / warmup).  gradient_checkpointing (default: model.llm.gradient_checkpointing, set by
+        ...) runs at lr * min(1, k * lr_scheduler_steps_per_optimizer_step / warmup).
+        Stepping convention mirrored (default 1 = the reference's scripts: they pass --deepspeed_plugin
+        (pretrain_stage1_nv.sh:49), so `accelerator.prepare` wraps the scheduler in accelerate's DeepSpeedSchedulerWrapper
+        whose step() is a no-op and the DeepSpeed engine advances it ONCE per optimizer step whatever the world size;
+        num_warmup_steps there is lr_warmup_steps * gradient_accumulation_steps, :279-283, and the scripts use
+        accumulation 1).  Without the DeepSpeed plugin accelerate's AcceleratedScheduler advances the schedule
+        `num_processes` times per optimizer step (split_batches=False): pass lr_scheduler_steps_per_optimizer_step =
+        world size to mirror that launch instead.  No fixture pins the LR trajectory of the reference's loop (it needs
+        deepspeed, absent here): parity of the warm-up length is unpinned.  gradient_checkpointing (default: model.llm.gradient_checkpointing, set by
         `model.llm.gradient_checkpointing_enable()`, train...py:170-171): keep only each decoder layer's input and
         recompute the layer inside the backward (OmniGen/transformer.py:182-192).  forward_only: no gradient / optimizer
         state (loss evaluation through `loss.training_losses_x1_noise_input`)."""
@@ -51,6 +59,9 @@ class Stage1Trainer:
         if lr_scheduler not in ("constant", "constant_with_warmup"):
             raise VgptError(f"lr_scheduler {lr_scheduler!r}: only 'constant' and 'constant_with_warmup' are built")
         self.lr_scheduler, self.lr_warmup_steps = lr_scheduler, int(lr_warmup_steps)
+        if int(lr_scheduler_steps_per_optimizer_step) < 1:
+            raise VgptError("lr_scheduler_steps_per_optimizer_step must be >= 1")
+        self.lr_sched_stride = int(lr_scheduler_steps_per_optimizer_step)
         self.gradient_checkpointing = (bool(getattr(model.llm, "gradient_checkpointing", False))
                                        if gradient_checkpointing is None else bool(gradient_checkpointing))
         self.forward_only = forward_only
@@ -137,8 +148,9 @@ class Stage1Trainer:
     def current_lr(self) -> float:
         """Learning rate of the NEXT optimizer step (diffusers get_constant_schedule_with_warmup's lambda at
         current_step = optimizer steps taken so far)."""
-        if self.lr_scheduler == "constant_with_warmup" and self.step_count < self.lr_warmup_steps:
-            return self.lr * self.step_count / max(1.0, float(self.lr_warmup_steps))
+        k = self.step_count * self.lr_sched_stride
+        if self.lr_scheduler == "constant_with_warmup" and k < self.lr_warmup_steps:
+            return self.lr * k / max(1.0, float(self.lr_warmup_steps))
         return self.lr
 
     # ------------------------------------------------------------------------------------------------
