@@ -123,11 +123,14 @@ int vgpt_mask_pack_additive(const void* mask, int is_f32, uint32_t* bits, int64_
  * painters LVM/processor.py:575-616 (stage 1), :618-680 (frame-block training), :682-731 (next-clip inference) — all
  * three follow one rule over token attributes (video-gpt_amd/layout.py).
  * attr: (B, L, 2) int32, 8-byte aligned; per token t of row b
- *   word 0 = thr | seq << 24     thr: first query row that sees this CLEAN key (24 bits), seq: sequence id (8 bits)
+ *   word 0 = low | seq << 24     low (24 bits): thr of a CLEAN token = first query row that sees this key; sub of a NOISY
+ *                                token = sub-group inside its clip (0 everywhere in the collator's layouts; the engine
+ *                                numbers the time rows of denoise step s with s + 1 in its per-clip pass); seq: sequence
+ *                                id (8 bits)
  *   word 1 = kind | oc << 2 | grp << 4   kind 0 PAD, 1 CLEAN, 2 NOISY, 3 GAP; oc = min(offset in frame block, 2);
  *                                        grp = id of the (sequence, clip) a NOISY token belongs to
  * bit(q,k) = kind[q]==PAD  ||  (kind[k]==CLEAN && seq[q]==seq[k] && q >= thr[k])
- *         ||  (kind[k]==NOISY && kind[q]==NOISY && grp[q]==grp[k] && oc[q] >= oc[k]). */
+ *         ||  (kind[k]==NOISY && kind[q]==NOISY && grp[q]==grp[k] && oc[q] >= oc[k] && (sub[k]==0 || sub[k]==sub[q])). */
 int vgpt_mask_build_tokens(const int32_t* attr, uint32_t* bits, int64_t B, int64_t L, void* stream);
 /* Tile summary: one byte per (b, 128-row q block, 64-key tile): 2 bits per 32-row
  * q sub-block (0 = all masked, 1 = all visible, 2 = mixed).

@@ -1,5 +1,5 @@
-"""Developer probe (GPU): wall time of the once-per-clip passes of the cfg-2 engine (prefill, time-row pass, adaLN table),
-each synchronised, and the host time of merely enqueueing them."""
+"""Developer probe (GPU): wall time of the once-per-clip passes of the cfg-2 engine (the one-sequence clip pass = prefix +
+<|diffusion|> rows + time rows of every step; the prefix-only prefill for comparison; the adaLN table), each synchronised."""
 import importlib, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -29,5 +29,6 @@ with torch.cuda.stream(s):
         for _ in range(n):
             torch.cuda.synchronize(); t0 = time.perf_counter(); f(); torch.cuda.synchronize(); w.append(time.perf_counter() - t0)
         return 1e3 * min(w)
-    print(f"S0 {eng.S0} rows prefix, {eng.hoist['nf'] if eng.hoist else 0} frames; prefill {t(eng.prefill):.2f} ms | "
-          f"time pass {t(eng._time_pass):.2f} ms | mod pass {t(eng._mod_pass):.2f} ms | all {t(eng.per_clip_setup):.2f} ms")
+    print(f"S0 {eng.S0} rows prefix, {eng.hoist['nf'] if eng.hoist else 0} frames, {eng.num_steps} steps; prefix-only prefill "
+          f"{t(eng.prefill):.2f} ms | clip pass {t(eng._clip_pass):.2f} ms | mod pass {t(eng._mod_pass):.2f} ms | "
+          f"all {t(eng.per_clip_setup):.2f} ms")

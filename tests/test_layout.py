@@ -196,3 +196,51 @@ def test_left_pads_are_not_inferred_from_rows_that_merely_see_everything():
     ref[0, :2] = True
     ref[0, 2:, 2:] = torch.tril(torch.ones(4, 4, dtype=torch.bool))
     assert E.count_left_pads(ref) == [2]
+
+
+def _clip_pass_layout(C=2, G=3, N=16, T=4):
+    """The sequence engine.StaticDenoiser._clip_pass lays out: [prefix | <|diffusion|> rows | T x time rows]."""
+    bl = N + 2
+    batch = product_inference(C, G, N, 1, mask_format="layout")
+    lay, offs = batch["attention_mask"].pack()
+    pads = batch["attention_mask"].left_pads()
+    row_of = lambda b, s: offs[b] + s - pads[b]
+    S0 = C * bl
+    plan = E.StaticDenoiser._hoist_plan(lay, S0, lay.L, row_of, batch["denoise_image_sizes"], batch["time_emb_inx"])
+    hoisted = lay.permute(np.array(plan["perm"]))
+    nf = plan["nf"]
+    Sc = S0 + nf
+    idx = np.concatenate([np.arange(Sc), np.tile(np.arange(Sc, Sc + nf), T)])
+    lp = hoisted.permute(idx)
+    sub = lp.sub.copy()
+    sub[0, Sc:] = 1 + np.repeat(np.arange(T), nf)
+    return hoisted, lp.with_subgroups(sub), S0, nf, T
+
+
+def test_time_rows_of_all_steps_in_one_sequence():
+    """Sub-groups (layout.TokenLayout.sub): with the time rows of step s numbered s + 1, the one-sequence clip pass gives
+    every time row exactly the keys it has in the sampler's own sequence -- the prefix, its clip's <|diffusion|> columns,
+    the time columns of ITS step -- and nothing of any other step; prefix and <|diffusion|> rows are unchanged."""
+    hoisted, lp, S0, nf, T = _clip_pass_layout()
+    Sc = S0 + nf
+    ref = hoisted.to_bool()[0]                  # rows / columns [0, Sc + nf) = prefix, diffusion rows, time rows
+    got = lp.to_bool()[0]
+    assert np.array_equal(got[:Sc, :Sc], ref[:Sc, :Sc]) and not got[:Sc, Sc:].any()
+    for s in range(T):
+        rows = slice(Sc + s * nf, Sc + (s + 1) * nf)
+        assert np.array_equal(got[rows, :Sc], ref[Sc:Sc + nf, :Sc])            # prefix + diffusion columns
+        assert np.array_equal(got[rows, rows], ref[Sc:Sc + nf, Sc:Sc + nf])    # own step's time columns
+        other = np.ones(lp.L, dtype=bool)
+        other[:Sc] = False
+        other[rows] = False
+        assert not got[rows][:, other].any()                                   # no other step
+    with pytest.raises(ValueError):
+        LY.TokenLayout(lp.thr, lp.seq, lp.kind, lp.oc, lp.grp, np.ones_like(lp.sub))   # sub on a CLEAN token
+
+
+@pytest.mark.gpu
+def test_device_expansion_with_subgroups_is_bit_exact(ops):
+    _, lp, _, _, _ = _clip_pass_layout(C=2, G=3, N=16, T=5)
+    ref = ops.pack_mask(torch.from_numpy(lp.to_bool()).to("cuda:0"))
+    pm = lp.packed_mask("cuda:0")
+    assert torch.equal(pm.bits, ref.bits) and torch.equal(pm.summary, ref.summary)

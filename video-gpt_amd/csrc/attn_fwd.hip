@@ -22,6 +22,26 @@
 //     address (chunk ^= (key>>2)&3) so the ds_read_b128 16-lane groups are conflict-free without padding.
 #include "common.h"
 
+// Softmax arithmetic of the tile loop.  0 (product): the plain online softmax.  1: three arithmetic reductions, built to
+// parity and measured on the same box (`make attn-variant-VGPT_ATTN_LAZY`, round 3) -- an EXPERIMENT, not in the product:
+//   (a) scale * log2(e) folded into Q once per work item (Q' = bf16(Q * c)), so a score needs no multiply;
+//   (b) the running reference m_ref of a query row is LAZY: the score accumulators start at -m_ref (the C operand of the
+//       first QK^T MFMA is a register block holding -m_ref) so that P = exp2(S) directly -- no subtract, no per-tile
+//       alpha -- and the reference moves (and O, l are rescaled) only when a tile's largest score exceeds it by more than
+//       LAZY_THRESH (2^8: P <= 256, far inside fp32 / bf16 range) or when the row sees its first key;
+//   (c) the row sums l come from the matrix pipe: one more 32-row output tile of P V with an all-ones V block.
+// Per tile and wave it issues 16 v_max3 + 32 v_exp + 16 v_cvt_pk and 28 MFMAs where the plain form issues 16 v_max3 +
+// 16 v_pk_fma + 32 v_exp + 16 v_pk_add + 16 v_cvt_pk + the alpha bookkeeping and 24 MFMAs: a third fewer vector issue
+// cycles.  Measured (cfg-2 live rows, in the step's own launch order, same box): 148.7 / 151.3 us against 155.9 us -- 3-5 %,
+// 0.15 ms of a 31 ms step: the loop is not bound by what it issues.  And (a) costs accuracy exactly where logits are large:
+// Q' is a second rounding of Q, an error proportional to the score; tests/test_ops_gpu.py::test_attention_late_spike
+// (keys 30x the usual norm, scores ~ 400 in log2 units) keeps rel-L2 < 1e-2 but its max-abs bound reads 0.135 against
+// 0.06.  Without (a) the multiply stays and nothing is saved.  Not worth the accuracy: the product keeps the plain form.
+#ifndef VGPT_ATTN_LAZY
+#define VGPT_ATTN_LAZY 0
+#endif
+#define LAZY_THRESH 8.0f
+
 namespace {
 
 struct AttnArgs {
@@ -164,13 +184,30 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     bf16x8 Qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) Qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s + 8 * h);
+#if VGPT_ATTN_LAZY
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Qf[s][j] = f2bf(bf2f(Qf[s][j]) * a.scale_log2e);
+#endif
 
     f32x16 O[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
+#if VGPT_ATTN_LAZY
+    f32x16 Ol, Cm;      // row sums (every register of a lane: l of its query row); -m_ref, the C operand of S^T's first MFMA
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { Ol[i] = 0.f; Cm[i] = 0.f; }
+    float m_ref = 0.f;
+    bool need_ref = true;   // this row has not seen a key yet: the first finite tile maximum becomes its reference
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = f2bf(1.0f);
+#else
     float m_i = -INFINITY, l_i = 0.f;
+#endif
 
     // ---- staging helpers ----
     constexpr bool GLDS = TR && C::GLDS;
@@ -323,11 +360,18 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             f32x16 S[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
+#if VGPT_ATTN_LAZY
+                S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[kb][0], Qf[0], Cm, 0, 0, 0);   // S starts at -m_ref
+#pragma unroll
+                for (int s = 1; s < KS; ++s)
+                    S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[kb][s], Qf[s], S[kb], 0, 0, 0);
+#else
 #pragma unroll
                 for (int i = 0; i < 16; ++i) S[kb][i] = 0.f;
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
                     S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[kb][s], Qf[s], S[kb], 0, 0, 0);
+#endif
             }
             // ---- V^T fragments do not depend on the softmax: request them now so their LDS latency hides
             //      under the softmax VALU work ----
@@ -381,6 +425,35 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) mxp[kb] = fmaxf(mxp[kb], S[kb][i]);
+#if VGPT_ATTN_LAZY
+            // scores are in log2 units relative to the row's reference already: P = exp2(S) as it stands, unless a row
+            // outgrew its reference (or has none yet) -- then that row's reference moves to the tile maximum
+            const float mx = half_max(fmaxf(mxp[0], mxp[1]));
+            if (__any(need_ref || mx > LAZY_THRESH)) {
+                const bool fin = mx > -INFINITY;
+                const float delta = need_ref ? (fin ? mx : 0.f) : (mx > LAZY_THRESH ? mx : 0.f);
+                const float alpha = need_ref ? 1.f : __builtin_amdgcn_exp2f(-delta);   // a row without a key holds O = l = 0
+                need_ref = need_ref && !fin;
+                m_ref += delta;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) S[kb][i] -= delta;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    Ol[i] *= alpha;
+                    Cm[i] = -m_ref;
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S[kb][i] = __builtin_amdgcn_exp2f(S[kb][i]);
+#else
             const float mx = half_max(fmaxf(mxp[0], mxp[1])) * a.scale_log2e;  // scale > 0: max commutes with it
             const float m_new = fmaxf(m_i, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
@@ -412,6 +485,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
                     for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
             }
             m_i = m_new;
+#endif
             // ---- P^T fragments: accumulator registers 8*half..8*half+7 of S[kb] ----
             bf16x8 Pf[4];
 #pragma unroll
@@ -424,6 +498,10 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vf[dt][t], Pf[t], O[dt], 0, 0, 0);
+#if VGPT_ATTN_LAZY
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, Pf[t], Ol, 0, 0, 0);   // l += sum_k P
+#endif
         }
         e_cur = e_nxt;
         e_nxt = __builtin_amdgcn_readfirstlane(e_n2);
@@ -442,6 +520,9 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         t[3] = ((unsigned long long)(unsigned)wid << 32) | (unsigned)n_tiles_done;
     }
     // ---- epilogue: lane holds O^T[d = 32dt + (i&3) + 8(i>>2) + 4h][q = r] ----
+#if VGPT_ATTN_LAZY
+    const float l_i = Ol[0], m_i = m_ref;   // every register of Ol holds the lane's row sum (all 64 keys of a tile: no half-sum)
+#endif
     if (a.lse && q_valid && h == 0)
         a.lse[((int64_t)b * a.n_heads + head) * a.L + q_row] = l_i > 0.f ? m_i + __builtin_amdgcn_logf(l_i) : INFINITY;
     if (q_valid) {

@@ -51,7 +51,26 @@
 #define VGPT_GEMM_DEBUG_BUILD 0
 #endif
 
+// EXPERIMENT switch (make gemm-variant-VGPT_GEMM_STORE_WT): the epilogue's 8-byte output stores as write-through
+// (`sc0 sc1`: the line is not kept dirty in the XCD's L2), to see what the write-back of a GEMM's dirty output lines costs
+// at the kernel boundary behind it (MI355X_MICROARCH.md, price list row `boundary`: + B / 6 TB/s for B dirty bytes).
+// Measured in round 3: 35.3 ms per sampler step against 32.0 (o_proj 97 vs 72 us, qkv 242 vs 205): the consumer kernel
+// finds its input in neither L2 nor -- apparently -- as readily in the Infinity Cache; the plain stores stay.
+#ifndef VGPT_GEMM_STORE_WT
+#define VGPT_GEMM_STORE_WT 0
+#endif
+
 namespace {
+
+__device__ __forceinline__ void store_out4(bf16* p, bf16x4 v) {
+#if VGPT_GEMM_STORE_WT
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t d = __builtin_bit_cast(u32x2_t, v);
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+#else
+    *reinterpret_cast<bf16x4*>(p) = v;
+#endif
+}
 
 constexpr int BK = 64;
 constexpr int kDebug = VGPT_GEMM_DEBUG_BUILD;
@@ -179,23 +198,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- tile order: XCD-aware remap (bijective), then grouped along m ----
+    // ---- tile order: XCD-aware remap (bijective), then grouped along m.  A workgroup walks the virtual tile ids
+    //      blockIdx.x, blockIdx.x + gridDim.x, ... (persistent launch: gridDim.x = one round of the chip; a plain launch
+    //      has gridDim.x = number of tiles and the walk ends after one).  gridDim.x % 8 == 0 or a single round, so a
+    //      workgroup's tiles keep `vt & 7`, the XCD the remap assumes. ----
     const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    constexpr int GROUP = 8;
-    const int in_group = GROUP * g.tiles_n;
-    const int group_id = bid / in_group;
-    const int first_m = group_id * GROUP;
-    const int gsz = min(g.tiles_m - first_m, GROUP);
-    const int tm = first_m + (bid % in_group) % gsz;
-    const int tn = (bid % in_group) / gsz;
-    const int m0 = tm * BM;
-    const int n0 = tn * (MODE == MODE_GATED ? BN / 2 : BN);
-
     // ---- staging addresses: wave w stages its share of 8-row slabs of both tiles ----
     const int srow = lane >> 3;            // row inside the 8-row slab
     const int schunk = (lane & 7) ^ srow;  // source 16-B chunk (XOR swizzle)
@@ -213,40 +220,60 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         const int col = min(col0 + lchunk * 8, width - 8) - col0;
         return (uint32_t)(row * (int)ld + col) * 2u;
     };
-    const char* a_org = reinterpret_cast<const char*>(ATR ? g.A + m0 : g.A + (int64_t)m0 * g.lda);
-    const char* w_org;
-    if constexpr (WTR) w_org = reinterpret_cast<const char*>(g.W + n0);
-    else if constexpr (MODE == MODE_GATED || ROPE) w_org = reinterpret_cast<const char*>(g.W);
-    else w_org = reinterpret_cast<const char*>(g.W + (int64_t)n0 * g.ldw);
-#pragma unroll
-    for (int i = 0; i < C::A_SLABS; ++i) {
-        if constexpr (ATR) {
-            a_off[i] = tr_off(g.lda, wave * C::A_SLABS + i, m0, g.M, BM);
-        } else {
-            const int r = min((wave * C::A_SLABS + i) * 8 + srow, g.M - 1 - m0);
-            a_off[i] = (uint32_t)(r * (int)g.lda + schunk * 8) * 2u;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < C::W_SLABS; ++i) {
-        if constexpr (WTR) {
-            w_off[i] = tr_off(g.ldw, wave * C::W_SLABS + i, n0, g.N, BN);
-        } else {
-            const int r = C::w_slab(wave, i) * 8 + srow;
-            int wr;
-            if constexpr (ROPE) wr = min(rope_col_of_slot(n0 + r, g.rope_cols, g.head_dim), n_rows_w - 1);
-            else wr = min(w_row_of_slot<MODE>(n0, r, g.I), n_rows_w - 1) - (MODE == MODE_GATED ? 0 : n0);
-            w_off[i] = (uint32_t)(wr * (int)g.ldw + schunk * 8) * 2u;
-        }
-    }
-    const int64_t a_step = (ATR ? (int64_t)BK * g.lda : BK) * 2, w_step = (WTR ? (int64_t)BK * g.ldw : BK) * 2;
     // A transposed operand is fetched with buffer_load ... lds through a descriptor that ends after reduction row
     // K-1: the rows of a partial last k-tile are out of range and the hardware returns zeros for them.
+    v4i32 a_rs = {0, 0, 0, 0}, w_rs = {0, 0, 0, 0};
+    int m0 = 0, n0 = 0;
+    const char* a_org = nullptr;
+    const char* w_org = nullptr;
+    auto set_tile = [&](int vt) {
+        int bid = vt;
+        {
+            const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        }
+        constexpr int GROUP = 8;
+        const int in_group = GROUP * g.tiles_n;
+        const int group_id = bid / in_group;
+        const int first_m = group_id * GROUP;
+        const int gsz = min(g.tiles_m - first_m, GROUP);
+        const int tm = first_m + (bid % in_group) % gsz;
+        const int tn = (bid % in_group) / gsz;
+        m0 = tm * BM;
+        n0 = tn * (MODE == MODE_GATED ? BN / 2 : BN);
+        a_org = reinterpret_cast<const char*>(ATR ? g.A + m0 : g.A + (int64_t)m0 * g.lda);
+        if constexpr (WTR) w_org = reinterpret_cast<const char*>(g.W + n0);
+        else if constexpr (MODE == MODE_GATED || ROPE) w_org = reinterpret_cast<const char*>(g.W);
+        else w_org = reinterpret_cast<const char*>(g.W + (int64_t)n0 * g.ldw);
+#pragma unroll
+        for (int i = 0; i < C::A_SLABS; ++i) {
+            if constexpr (ATR) {
+                a_off[i] = tr_off(g.lda, wave * C::A_SLABS + i, m0, g.M, BM);
+            } else {
+                const int r = min((wave * C::A_SLABS + i) * 8 + srow, g.M - 1 - m0);
+                a_off[i] = (uint32_t)(r * (int)g.lda + schunk * 8) * 2u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::W_SLABS; ++i) {
+            if constexpr (WTR) {
+                w_off[i] = tr_off(g.ldw, wave * C::W_SLABS + i, n0, g.N, BN);
+            } else {
+                const int r = C::w_slab(wave, i) * 8 + srow;
+                int wr;
+                if constexpr (ROPE) wr = min(rope_col_of_slot(n0 + r, g.rope_cols, g.head_dim), n_rows_w - 1);
+                else wr = min(w_row_of_slot<MODE>(n0, r, g.I), n_rows_w - 1) - (MODE == MODE_GATED ? 0 : n0);
+                w_off[i] = (uint32_t)(wr * (int)g.ldw + schunk * 8) * 2u;
+            }
+        }
+        if constexpr (ATR) a_rs = make_rsrc(a_org, (int)(((int64_t)g.K * g.lda - m0) * 2));
+        if constexpr (WTR) w_rs = make_rsrc(w_org, (int)(((int64_t)g.K * g.ldw - n0) * 2));
+    };
+    int vt_cur = blockIdx.x;
+    set_tile(vt_cur);
+    const int64_t a_step = (ATR ? (int64_t)BK * g.lda : BK) * 2, w_step = (WTR ? (int64_t)BK * g.ldw : BK) * 2;
     const uint32_t lds_base =
         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-    v4i32 a_rs = {0, 0, 0, 0}, w_rs = {0, 0, 0, 0};
-    if constexpr (ATR) a_rs = make_rsrc(a_org, (int)(((int64_t)g.K * g.lda - m0) * 2));
-    if constexpr (WTR) w_rs = make_rsrc(w_org, (int)(((int64_t)g.K * g.ldw - n0) * 2));
     auto a_issue = [&](int i, int kt, char* dst) {
         if constexpr (ATR)
             buf_glds16_asm(a_rs, a_off[i], (int)(kt * a_step), lds_base + (uint32_t)(dst - smem));
@@ -283,10 +310,6 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     const int sw = frow & 7;
 
     f32x4 acc[NI][MI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x16 acc2[2][4];   // diagnostics flag 32 only
     if constexpr ((kDebug & 32) != 0) {
 #pragma unroll
@@ -309,9 +332,21 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     };
 
     const int nk = (g.K + BK - 1) / BK;  // a partial last k-tile exists only with transposed operands (zero rows)
+    // Persistent walk (PERSIST): when this workgroup has another tile, that tile's first k-tile is requested (LDS-DMA into
+    // staging buffer 0, free once every wave is past the last barrier of the k-loop) BEFORE the epilogue of the current one,
+    // so the fetch latency of a tile's prologue and the HBM write time of its predecessor's epilogue overlap instead of
+    // adding up (one workgroup per CU: nothing else overlaps them).  Not for MODE_ROPE, whose epilogue stages the cos / sin
+    // rows through the same LDS, nor for the experimental loops.
+    constexpr bool PERSIST = (PIPE == 0 || PIPE == 1) && !ROPE;
+    bool prefetched = false;
+    for (;;) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (PIPE == 0) {
         // one barrier per k-tile: wait for tile kt, issue tile kt+1's DMA, compute tile kt
-        stage(0, 0);
+        if (!prefetched) stage(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -941,7 +976,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated fetches of the last tiles: their registers are reused below
         } else {
-        stage(0, 0);
+        if (!prefetched) stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (nk > 1) stage(1, 1);
@@ -978,6 +1013,20 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         }
     }
 
+    // ---- the tile whose accumulators are stored now; then (persistent walk) the next tile's first k-tile is requested ----
+    const int m0e = m0, n0e = n0;
+    bool more = false;
+    if constexpr (PERSIST) {
+        const int vt_next = vt_cur + (int)gridDim.x;
+        more = vt_next < nwg;
+        if (more) {
+            __syncthreads();          // every wave has read its last fragments: both staging buffers are free
+            vt_cur = vt_next;
+            set_tile(vt_next);
+            stage(0, 0);
+            prefetched = true;
+        }
+    }
     if constexpr ((kDebug & 4) != 0) {   // diagnostics: no epilogue (one store keeps the accumulators alive)
         float sum = 0.f;
         if constexpr ((kDebug & 32) != 0 && PIPE == 1) {
@@ -1009,7 +1058,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         const bool staged = 2 * tab_bytes <= C::LDS_BYTES;
         if (staged) {
             __syncthreads();                                           // every wave has read its last fragments
-            const int64_t row0_bytes = (int64_t)m0 * half * 4;
+            const int64_t row0_bytes = (int64_t)m0e * half * 4;
             // last readable 16 bytes of the table, relative to this tile's first row (rows past M are never used)
             const uint32_t last = (uint32_t)min((int64_t)g.M * half * 4 - row0_bytes - 16, (int64_t)tab_bytes);
             const char* cbase = reinterpret_cast<const char*>(g.rope_cos) + row0_bytes;
@@ -1026,11 +1075,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
             const int ml = wm * (MI * 16) + j * 16 + em;
-            const int m = m0 + ml;
+            const int m = m0e + ml;
             if (m >= g.M) continue;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int gs = n0 + wn * (NI * 16) + i * 16 + en;
+                const int gs = n0e + wn * (NI * 16) + i * 16 + en;
                 if (gs >= g.N) continue;
                 const int n = rope_col_of_slot(gs, g.rope_cols, g.head_dim);
                 f32x4 v = acc[i][j];
@@ -1057,17 +1106,17 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) o[t] = f2bf(v[t]);
                 }
-                *reinterpret_cast<bf16x4*>(g.C + (int64_t)m * g.ldc + n) = o;
+                store_out4(g.C + (int64_t)m * g.ldc + n, o);
             }
         }
     } else if (MODE == MODE_PLAIN) {
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
-            const int m = m0 + wm * (MI * 16) + j * 16 + em;
+            const int m = m0e + wm * (MI * 16) + j * 16 + em;
             if (m >= g.M) continue;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int n = n0 + wn * (NI * 16) + i * 16 + en;
+                const int n = n0e + wn * (NI * 16) + i * 16 + en;
                 if (n >= g.N) continue;
                 f32x4 v = acc[i][j];
                 if (g.epi == VGPT_EPI_RESID) {
@@ -1082,26 +1131,54 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                 bf16x4 o;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[t] = f2bf(v[t]);
-                *reinterpret_cast<bf16x4*>(g.C + (int64_t)m * g.ldc + n) = o;
+                store_out4(g.C + (int64_t)m * g.ldc + n, o);
             }
         }
     } else {
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
-            const int m = m0 + wm * (MI * 16) + j * 16 + em;
+            const int m = m0e + wm * (MI * 16) + j * 16 + em;
             if (m >= g.M) continue;
 #pragma unroll
             for (int p = 0; p < NI / 2; ++p) {
-                const int n = n0 + (wn * (NI / 2) + p) * 16 + en;  // output column
+                const int n = n0e + (wn * (NI / 2) + p) * 16 + en;  // output column
                 if (n >= g.I) continue;
                 const f32x4 gate = acc[2 * p][j], up = acc[2 * p + 1][j];
                 bf16x4 o;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[t] = f2bf(act_apply(gate[t], g.act) * up[t]);
-                *reinterpret_cast<bf16x4*>(g.C + (int64_t)m * g.ldc + n) = o;
+                store_out4(g.C + (int64_t)m * g.ldc + n, o);
             }
         }
     }
+    if (!more) break;
+    }   // persistent walk
+}
+
+// Persistent walk: OFF unless VGPT_GEMM_PERSIST=1.  Measured in round 3 on one box (bench.py, same process order): sampler
+// step 31.996 ms with it against 32.03 without (gate_up 318 vs 322 us), stage-1 step 216.0 ms WITH it against 213.5 without --
+// hardware dispatch already starts the next workgroup's prologue while other CUs store, and it balances the ragged last
+// m-tile rows of the training shapes dynamically, which a static walk cannot.  Kept as a switch for later A/B runs.
+bool persist_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VGPT_GEMM_PERSIST");
+        v = e ? (atoi(e) != 0) : 0;
+    }
+    return v != 0;
+}
+
+int cu_count() {
+    static int v = 0;
+    if (v == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            v = n;
+        else
+            v = 256;
+    }
+    return v;
 }
 
 template <int MODE, typename C, int PIPE, bool ATR = false, bool WTR = false>
@@ -1118,7 +1195,14 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     }
     g.tiles_m = (int)cdiv(g.M, C::BM);
     g.tiles_n = (int)cdiv(n_out, MODE == MODE_GATED ? C::BN / 2 : C::BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>), dim3(g.tiles_m * g.tiles_n), dim3(C::THREADS),
+    // persistent walk (kernel: PERSIST): one round of the chip's workgroup slots, each workgroup taking tiles
+    // blockIdx.x, + gridDim.x, ...; the slot count is a multiple of 8 (XCD remap).  Off by default (persist_enabled()).
+    int grid = g.tiles_m * g.tiles_n;
+    if ((PIPE == 0 || PIPE == 1) && MODE != MODE_ROPE && persist_enabled()) {
+        const int slots = cu_count() * (C::LDS_BYTES > 80 * 1024 ? 1 : 2);
+        if (slots % 8 == 0 && grid > slots) grid = slots;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>), dim3(grid), dim3(C::THREADS),
                        C::LDS_BYTES + (PIPE == 2 || PIPE == 4 ? 16384 : 0), s, g);
     VGPT_CHECK_LAUNCH(name);
     return VGPT_OK;

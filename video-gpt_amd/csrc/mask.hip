@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const T* __restrict__ ma
 }
 
 // Mask rows straight from per-token attributes (video-gpt_amd/layout.py; the rule of LVM/processor.py:575-731 in closed
-// form).  attr[t] = { thr | seq << 24, kind | oc << 2 | grp << 4 }.  Block = 256 consecutive query rows x 4 words
+// form).  attr[t] = { (thr of a CLEAN token | sub of a NOISY one) | seq << 24, kind | oc << 2 | grp << 4 }.  Block = 256 consecutive query rows x 4 words
 // (128 keys): the key attributes are the same for every lane (scalar loads), each lane keeps its own row's attributes
 // in registers and writes its 4 words.
 enum { TK_PAD = 0, TK_CLEAN = 1, TK_NOISY = 2, TK_GAP = 3 };
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void mask_tokens_kernel(const uint2* __restric
     const int q = (int)(blockIdx.x / (unsigned)wgroups) * 256 + threadIdx.x;
     const int w0 = (int)(blockIdx.x % (unsigned)wgroups) * 4;
     const uint2 aq = attr[(int64_t)b * L + min(q, L - 1)];
-    const uint32_t kq = aq.y & 3u, ocq = (aq.y >> 2) & 3u, gq = aq.y >> 4, sq = aq.x >> 24;
+    const uint32_t kq = aq.y & 3u, ocq = (aq.y >> 2) & 3u, gq = aq.y >> 4, sq = aq.x >> 24, subq = aq.x & 0xffffffu;
     const uint2* ak = attr + (int64_t)b * L;
     uint32_t word[4];
 #pragma unroll
@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void mask_tokens_kernel(const uint2* __restric
             const uint2 a = ak[k0 + j];  // wave-uniform address
             const uint32_t kk = a.y & 3u;
             const bool clean = kk == TK_CLEAN && (a.x >> 24) == sq && (uint32_t)q >= (a.x & 0xffffffu);
-            const bool noisy = kk == TK_NOISY && kq == TK_NOISY && (a.y >> 4) == gq && ocq >= ((a.y >> 2) & 3u);
+            const uint32_t subk = a.x & 0xffffffu;   // sub-group of a NOISY key: 0 = seen by every sub-group of its clip
+            const bool noisy = kk == TK_NOISY && kq == TK_NOISY && (a.y >> 4) == gq && ocq >= ((a.y >> 2) & 3u) &&
+                               (subk == 0u || subk == subq);
             wd |= (uint32_t)(clean || noisy) << j;
         }
         if (kq == TK_PAD) wd = nk >= 32 ? 0xffffffffu : (nk > 0 ? (1u << nk) - 1u : 0u);  // pad rows see the whole row

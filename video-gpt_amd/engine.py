@@ -125,7 +125,7 @@ class StaticDenoiser:
                 #      index alone.  Both leave the per-step row set: the sequence is re-ordered to
                 #      [prefix | diffusion rows | time rows | gap | image rows], the image rows (n_frames x N: whole
                 #      GEMM / attention tiles) are all a step computes, and the time rows' q/k/v of EVERY step come
-                #      from one batched pass (_time_pass) and are dropped in by vgpt_sampler_copy_step_rows. ----
+                #      from the per-clip pass (_clip_pass) and are dropped in by vgpt_sampler_copy_step_rows. ----
                 perm, S, inv = plan["perm"], plan["S"], plan["inv"]
                 pt = torch.tensor([p_ if p_ >= 0 else 0 for p_ in perm], dtype=torch.int64, device=input_ids.device)
                 gapm = torch.tensor([p_ < 0 for p_ in perm], dtype=torch.bool, device=input_ids.device)
@@ -259,9 +259,10 @@ class StaticDenoiser:
         if self.sigma is not None:
             self._mod_pass()
         if S:
-            self.prefill()
             if self.hoist and self.sigma is not None:
-                self._time_pass()
+                self._clip_pass()
+            else:
+                self.prefill()
 
     def prefill(self):
         """One forward over the static prefix rows [0, S) ONLY -- they never see a later row (that is what makes them
@@ -296,12 +297,14 @@ class StaticDenoiser:
         torch.cuda.current_stream().synchronize()
 
     def per_clip_setup(self):
-        """Everything a clip computes once instead of once per step: condition-prefix prefill, the special rows of every
-        step, the final layer's adaLN modulation of every step."""
+        """Everything a clip computes once instead of once per step: the condition prefix and the special rows of every step
+        (one pass, _clip_pass; prefill() alone when the layout cannot be hoisted), the final layer's adaLN modulation of
+        every step."""
         if self.S:
-            self.prefill()
             if self.hoist:
-                self._time_pass()
+                self._clip_pass()
+            else:
+                self.prefill()
         self._mod_pass()
 
     def set_sigma(self, sigma: torch.Tensor):
@@ -310,7 +313,7 @@ class StaticDenoiser:
         if getattr(self, "mod", None) is not None:
             self._mod_pass()
         if getattr(self, "hoist", None) and getattr(self, "qkv_full", None) is not None:
-            self._time_pass()
+            self._clip_pass()
 
     def _mod_pass(self):
         """t_embedder MLP + adaLN modulation of the final layer for EVERY step in one pass per clip: they depend on
@@ -366,36 +369,36 @@ class StaticDenoiser:
                 f0 = f
         return dict(perm=perm, inv=inv, S=S, nf=nf, ntok=ntok, segments=tuple(segs))
 
-    def _time_pass(self):
-        """q/k/v rows of the time tokens for EVERY denoise step in one batched forward.  A time row sees the condition
-        prefix, the `<|diffusion|>` columns of its clip (both step-invariant: K/V from the prefill) and the time columns
-        of its own step.  Sequence of the pass: [prefix | gap | per step a COPY of the diffusion rows' K/V (keys only,
-        never queries) | gap | per step the n_frames time rows (the only rows computed)], every step's copies and time
-        rows forming their own clip group so that steps do not see each other.  Leaves time_qkv[step]."""
+    def _clip_pass(self):
+        """Everything of a hoisted clip that does not depend on the latents, in ONE forward per clip: the condition prefix
+        and the `<|diffusion|>` rows (step-invariant; what prefill() computes) and the time rows of EVERY denoise step (a
+        function of the step index alone).  The reference recomputes all of them inside every model call
+        (LVM/model.py:435-454, LVM/scheduler.py:174).  Sequence of the pass:
+            [prefix 0..S0) | nf `<|diffusion|>` rows | step 0's nf time rows | step 1's | ... | step T-1's]
+        with the clip's own token attributes, the time rows of step s carrying sub-group s + 1 (layout.TokenLayout): they
+        see the prefix, their clip's `<|diffusion|>` columns (sub-group 0) and the time columns of their own step only.
+        One sequence means every layer's weights stream once per clip and the GEMMs run S0 + nf + T nf rows (1.9 k at
+        cfg-2 with 53 steps) instead of two passes of about half that.  Leaves qkv_full[l][:S0 + nf] (post-RoPE q/k/v of
+        the cached rows) and time_qkv[step, l]."""
         import numpy as np
         m, cfg, H, dev = self.model, self.cfg, self.H, self.dev
         nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         W3 = (nq + 2 * nk) * hd
         S0, nf, T = self.S0, self.hoist["nf"], self.num_steps
-        lay = self.layout
-        P0 = (S0 + 127) // 128 * 128                     # first diffusion-key copy
-        P1 = (P0 + T * nf + 127) // 128 * 128            # first time row
-        Lp = P1 + T * nf
-        idx = np.concatenate([np.arange(S0), np.full(P0 - S0, -1), np.tile(np.arange(S0, S0 + nf), T),
-                              np.full(P1 - P0 - T * nf, -1), np.tile(np.arange(S0 + nf, S0 + 2 * nf), T)])
-        lp = lay.permute(idx)
-        grp = lp.grp.copy()
-        base = int(lay.grp.max()) + 1
-        step_of = np.repeat(np.arange(T), nf)
-        for lo in (P0, P1):                               # one clip group per (clip, step), shared by copies and time rows
-            old = grp[0, lo:lo + T * nf]
-            uniq = {g: i for i, g in enumerate(sorted(set(lay.grp[0, S0:S0 + 2 * nf].tolist())))}
-            grp[0, lo:lo + T * nf] = base + step_of * len(uniq) + np.array([uniq[g] for g in old.tolist()])
-        lp = lp.with_groups(grp)
-        pm = lp.packed_mask(dev)
+        Sc = S0 + nf                                       # rows the sampler steps read from the cache
+        Lp = Sc + T * nf
+        idx = np.concatenate([np.arange(Sc), np.tile(np.arange(Sc, Sc + nf), T)])
+        lp = self.layout.permute(idx)
+        sub = lp.sub.copy()
+        sub[0, Sc:] = 1 + np.repeat(np.arange(T), nf)
+        pm = lp.with_subgroups(sub).packed_mask(dev)
         e = lambda *s_, dt=BF16: torch.empty(*s_, dtype=dt, device=dev)
-        Ms = T * nf
-        hid, nrm, ctx, act = e(1, Ms, H), e(1, Ms, H), e(1, Ms, nq * hd), e(1, Ms, cfg.intermediate_size)
+        hid, nrm, ctx, act = e(1, Lp, H), e(1, Lp, H), e(1, Lp, nq * hd), e(1, Lp, cfg.intermediate_size)
+        # rows [0, Sc): token embeddings + the condition frames' patch embeddings, as prefill()
+        ops.embed_gather(self.input_ids[:, :Sc].contiguous(), m.llm.embed_tokens.weight, out=hid[:, :Sc])
+        if self.cond is not None:
+            ops.patch_embed(self.cond, m.input_x_embedder.proj.weight, m.input_x_embedder.proj.bias, m.pos_embed[0],
+                            self.cond_rows, hid.view(-1, H), m.pos_embed_max_size)
         # time_token(sigma_s): one value per step (every frame of a step carries the same t, LVM/scheduler.py:169),
         # through the same small-M kernels as the per-step path (at most 32 rows per call), then broadcast to the rows
         ts = self.sigma[:T].contiguous()
@@ -405,32 +408,33 @@ class StaticDenoiser:
         for c in range(0, T, 32):
             ops.linear_small(sin[c:c + 32], tt[0].weight, tt[0].bias, post_act=ops.ACT_SILU, out=tt_h[c:c + 32])
             ops.linear_small(tt_h[c:c + 32], tt[2].weight, tt[2].bias, out=tt_o[c:c + 32])
-        hid.view(T, nf, H)[:] = tt_o[:, None, :]
-        # the time rows' cos / sin are ROWS OF THE CLIP'S OWN TABLE (self.rope, built from the full position_ids): a su /
-        # longrope checkpoint picks short or long factors from the largest position of the WHOLE sequence (HF 4.47.1
+        hid[0, Sc:].view(T, nf, H)[:] = tt_o[:, None, :]
+        # cos / sin are ROWS OF THE CLIP'S OWN TABLE (self.rope, built from the full position_ids): a su / longrope
+        # checkpoint picks short or long factors from the largest position of the WHOLE sequence (HF 4.47.1
         # Phi3LongRoPEScaledRotaryEmbedding), which a table rebuilt from this pass's rows alone would get wrong whenever
         # only the image rows cross original_max_position_embeddings
-        rope_s = tuple(t_[S0 + nf:S0 + 2 * nf].repeat(T, 1).contiguous() for t_ in self.rope)
-        buf = torch.zeros(Lp, W3, dtype=BF16, device=dev)
+        rope = tuple(torch.cat([t_[:Sc], t_[Sc:Sc + nf].repeat(T, 1)]).contiguous() for t_ in self.rope)
+        buf = e(1, Lp, W3)
         shape = (T, cfg.num_hidden_layers, nf, W3)
         if self.time_qkv is None or tuple(self.time_qkv.shape) != shape:
             self.time_qkv = e(*shape)      # a captured graph reads this buffer: re-allocating invalidates it
             self.graph = None
-        seg = ((0, P1, Lp),)
+        seg = ((0, 0, Lp),)
         for li, layer in enumerate(m.llm.layers):
             at, mlp = layer.self_attn, layer.mlp
             full = self.qkv_full[li]
-            buf[:S0].copy_(full[:S0])
-            buf[P0:P0 + T * nf].view(T, nf, W3).copy_(full[S0:S0 + nf].unsqueeze(0).expand(T, nf, W3))
             ops.rmsnorm(hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=nrm)
-            ops.linear_qkv_rope(nrm, at.qkv_proj.weight, rope_s[0], rope_s[1], nq, nk, hd, out=buf[P1:])
-            ops.attention_qkv_range(buf.view(1, Lp, -1), pm, nq, nk, hd, P1, ctx, segments=seg)
+            ops.linear_qkv_rope(nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=buf)
+            full[:Sc].copy_(buf[0, :Sc])
+            self.time_qkv[:, li].copy_(buf[0, Sc:].view(T, nf, W3))
+            if self.attn_fp8:   # the sampler steps read the cached rows' K / V from the fp8 workspace of this layer
+                ops.attention_fp8_quantize(full.view(1, self.L, -1), self.fp8_ws[li], nq, nk, hd)
+            ops.attention_qkv_range(buf, pm, nq, nk, hd, 0, ctx, segments=seg)
             ops.linear(ctx, at.o_proj.weight, residual=hid, out=hid)
             ops.rmsnorm(hid, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon, out=nrm)
             ops.gated_mlp_act(nrm, mlp.gate_up_proj.weight, mlp.act, out=act)
             ops.linear(act, mlp.down_proj.weight, residual=hid, out=hid)
-            self.time_qkv[:, li].copy_(buf[P1:].view(T, nf, W3))
-        self.time_dst = self.qkv_full[:, S0 + nf:S0 + 2 * nf]    # (layers, nf, 3H) view the step copy writes
+        self.time_dst = self.qkv_full[:, Sc:Sc + nf]    # (layers, nf, 3H) view the step copy writes
         torch.cuda.current_stream().synchronize()
 
     def set_latents(self, z: torch.Tensor):

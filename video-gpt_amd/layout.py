@@ -14,10 +14,13 @@ Rule (q = query row, k = key column, both indices into the row's L tokens):
     kind[q] == PAD                                   -> visible            (pad rows see everything, :726-727)
     kind[k] == CLEAN and seq[q] == seq[k]            -> visible iff q >= thr[k]
     kind[k] == NOISY and kind[q] == NOISY
-                     and grp[q] == grp[k]            -> visible iff oc[q] >= oc[k]
+                     and grp[q] == grp[k]            -> visible iff oc[q] >= oc[k] and (sub[k] == 0 or sub[k] == sub[q])
     otherwise (PAD / GAP key, other sequence, ...)   -> masked
 with thr[k] = k for `<img>` / `</img>`, block_start + 1 for image slots; oc = min(in-block offset, 2); grp unique per
-(sequence, clip); GAP tokens (alignment filler the engine inserts) see nothing and are seen by nothing.
+(sequence, clip); GAP tokens (alignment filler the engine inserts) see nothing and are seen by nothing.  `sub` is 0 on
+every token the collator lays out; the engine's per-clip pass (engine.StaticDenoiser._clip_pass) numbers the time rows of
+denoise step s with sub = s + 1 so that ONE sequence holds the time tokens of every step: they all see their clip's
+`<|diffusion|>` columns (sub 0) and only the time columns of their own step.
 """
 from __future__ import annotations
 
@@ -32,11 +35,15 @@ MAX_CLIPS = 4096        # clips per sequence (grp = seq * MAX_CLIPS + clip)
 
 
 class TokenLayout:
-    def __init__(self, thr, seq, kind, oc, grp):
+    def __init__(self, thr, seq, kind, oc, grp, sub=None):
         self.thr, self.seq, self.kind, self.oc, self.grp = (np.ascontiguousarray(a, dtype=np.int64)
                                                             for a in (thr, seq, kind, oc, grp))
-        if not (self.thr.ndim == 2 and self.thr.shape == self.seq.shape == self.kind.shape == self.oc.shape == self.grp.shape):
+        self.sub = np.zeros_like(self.thr) if sub is None else np.ascontiguousarray(sub, dtype=np.int64)
+        if not (self.thr.ndim == 2 and self.thr.shape == self.seq.shape == self.kind.shape == self.oc.shape == self.grp.shape
+                == self.sub.shape):
             raise ValueError("TokenLayout: attribute arrays must all be (B, L)")
+        if self.sub.min(initial=0) < 0 or self.sub.max(initial=0) >= 1 << 24 or bool((self.sub[self.kind != NOISY] != 0).any()):
+            raise ValueError("TokenLayout: sub must be in [0, 2^24) and 0 on every token that is not NOISY")
         if self.thr.shape[1] >= 1 << 24:
             raise ValueError("TokenLayout: L must be below 2^24")
         self._pm = {}
@@ -103,7 +110,8 @@ class TokenLayout:
             kq, kk = self.kind[b][:, None], self.kind[b][None, :]
             vis = (kk == CLEAN) & (self.seq[b][:, None] == self.seq[b][None, :]) & (q >= self.thr[b][None, :])
             vis |= (kk == NOISY) & (kq == NOISY) & (self.grp[b][:, None] == self.grp[b][None, :]) & \
-                   (self.oc[b][:, None] >= self.oc[b][None, :])
+                   (self.oc[b][:, None] >= self.oc[b][None, :]) & \
+                   ((self.sub[b][None, :] == 0) | (self.sub[b][None, :] == self.sub[b][:, None]))
             vis |= (kq == PAD)
             out[b] = vis
         return out
@@ -124,15 +132,15 @@ class TokenLayout:
         Returns (layout with B == 1, offsets of the rows in the packed sequence)."""
         pads = self.left_pads() if pads is None else pads
         offsets, o = [], 0
-        cols = {n: [] for n in ("thr", "seq", "kind", "oc", "grp")}
+        cols = {n: [] for n in ("thr", "seq", "kind", "oc", "grp", "sub")}
         for b in range(self.B):
             p = pads[b]
             offsets.append(o)
             cols["thr"].append(self.thr[b, p:] - p + o)
-            for n in ("seq", "kind", "oc", "grp"):
+            for n in ("seq", "kind", "oc", "grp", "sub"):
                 cols[n].append(getattr(self, n)[b, p:])
             o += self.L - p
-        return TokenLayout(*(np.concatenate(cols[n])[None, :] for n in ("thr", "seq", "kind", "oc", "grp"))), offsets
+        return TokenLayout(*(np.concatenate(cols[n])[None, :] for n in ("thr", "seq", "kind", "oc", "grp", "sub"))), offsets
 
     def insert_gap(self, at: int, n: int) -> "TokenLayout":
         """n GAP tokens in front of position `at` of every row (the engine aligns the static condition prefix to the
@@ -144,7 +152,8 @@ class TokenLayout:
         def ins(a, fill):
             return np.concatenate([a[:, :at], np.full((B, n), fill, dtype=np.int64), a[:, at:]], axis=1)
         thr = np.where(self.thr >= at, self.thr + n, self.thr)
-        return TokenLayout(ins(thr, 0), ins(self.seq, GAP_SEQ), ins(self.kind, GAP), ins(self.oc, 0), ins(self.grp, 0))
+        return TokenLayout(ins(thr, 0), ins(self.seq, GAP_SEQ), ins(self.kind, GAP), ins(self.oc, 0), ins(self.grp, 0),
+                           ins(self.sub, 0))
 
     def permute(self, perm) -> "TokenLayout":
         """Tokens re-ordered: new position i holds old token perm[i]; perm[i] == -1 inserts a GAP token.  Only valid
@@ -162,11 +171,15 @@ class TokenLayout:
         def take(a, fill):
             return np.where(keep[None, :], a[:, src], fill)
         return TokenLayout(take(self.thr, 0), take(self.seq, GAP_SEQ), take(self.kind, GAP), take(self.oc, 0),
-                           take(self.grp, 0))
+                           take(self.grp, 0), take(self.sub, 0))
 
     def with_groups(self, grp) -> "TokenLayout":
-        """Same tokens with other clip-group ids for the NOISY ones (engine: one group per denoise step)."""
-        return TokenLayout(self.thr, self.seq, self.kind, self.oc, grp)
+        """Same tokens with other clip-group ids for the NOISY ones."""
+        return TokenLayout(self.thr, self.seq, self.kind, self.oc, grp, self.sub)
+
+    def with_subgroups(self, sub) -> "TokenLayout":
+        """Same tokens with other sub-group numbers for the NOISY ones (engine: time rows of step s carry s + 1)."""
+        return TokenLayout(self.thr, self.seq, self.kind, self.oc, self.grp, sub)
 
     def prefix_is_static(self, t_first: int, row: int = 0) -> bool:
         """True when no row before t_first can see a column at or behind it — the rows of the condition prefix are
@@ -185,8 +198,10 @@ class TokenLayout:
 
     # ---- device form ------------------------------------------------------------------------------------------------
     def attr(self) -> np.ndarray:
-        """(B, L, 2) int32: word 0 = thr | seq << 24, word 1 = kind | oc << 2 | grp << 4 (include/vgpt.h)."""
-        w0 = (self.thr | (self.seq << 24)).astype(np.uint32)
+        """(B, L, 2) int32: word 0 = (thr of a CLEAN token, sub of a NOISY one, else 0) | seq << 24,
+        word 1 = kind | oc << 2 | grp << 4 (include/vgpt.h)."""
+        low = np.where(self.kind == CLEAN, self.thr, np.where(self.kind == NOISY, self.sub, 0)) & 0xFFFFFF
+        w0 = (low | (self.seq << 24)).astype(np.uint32)
         w1 = (self.kind | (self.oc << 2) | (self.grp << 4)).astype(np.uint32)
         return np.stack([w0, w1], axis=-1).view(np.int32)
 
