@@ -20,6 +20,8 @@
 //   - V^T fragments come from ds_read_b64_tr_b16 (hardware transposed read) on a [key][d] image whose row stride
 //     keeps the four 64-byte windows of a half-wave on disjoint banks; the K image is XOR-swizzled on the DMA source
 //     address (chunk ^= (key>>2)&3) so the ds_read_b128 16-lane groups are conflict-free without padding.
+#include <type_traits>
+
 #include "common.h"
 
 // Softmax arithmetic of the tile loop.  0 (product): the plain online softmax.  1: three arithmetic reductions, built to
@@ -41,6 +43,12 @@
 #define VGPT_ATTN_LAZY 0
 #endif
 #define LAZY_THRESH 8.0f
+// Round 3 also built a software-pipelined form of the tile loop (the QK^T MFMAs of tile t+1 issued inside the softmax of
+// tile t through sched_group_barrier, K one tile ahead of V in the same two staging buffers; 252 registers, parity-green on
+// the whole suite) and measured it SLOWER on the same box: 162.8 / 163.5 us against 151.3 us per layer at the cfg-2 live
+// rows (31.75 vs 31.51 ms per step).  Overlapping a wave's own matrix and vector work does not help a loop whose two
+// waves per SIMD already fill the issue port between them (active_inst_any 0.39 per wave, profiles/r02_pmc_mfma.json);
+// removed from the source (git history: "attention: software-pipelined loop").
 
 namespace {
 
