@@ -108,6 +108,12 @@ int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const void* extra, 
  * K % 64 == 0, I % 64 == 0. */
 int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, void* out, int64_t M, int64_t I,
                            int64_t K, int64_t lda, int64_t ldw, int64_t ldo, int act, void* stream);
+/* The same product for the TRAINING forward (LVMTraining.forward through Phi3MLP, LVM/model.py:752-845): additionally stores
+ * gate_up_out (M, ld_gu >= 2I) = [A Wg^T | A Wu^T] rounded to bf16 -- gate_up_proj's own output, which the backward reads --
+ * and computes out = act(gate) * up FROM those rounded values: bit for bit vgpt_gemm_bf16 followed by vgpt_silu_mul_fwd,
+ * without writing and re-reading the (M, 2I) tensor in between. */
+int vgpt_gated_mlp_act_fwd_keep(const void* A, const void* W_gate_up, void* out, void* gate_up_out, int64_t M, int64_t I,
+                                int64_t K, int64_t lda, int64_t ldw, int64_t ldo, int64_t ld_gu, int act, void* stream);
 
 /* ---- block-masked attention ---------------------------------------------- */
 

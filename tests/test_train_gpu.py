@@ -72,6 +72,22 @@ def test_transposed_operand_gemms(ops, T, M, N, K):
         assert torch.equal(dw2, dw)
 
 
+@pytest.mark.parametrize("M,I,K", [(300, 256, 192), (37, 64, 64), (4096, 2048, 512), (2080, 1024, 256)])
+def test_gated_forward_that_keeps_gate_up_is_the_unfused_pair_bit_for_bit(ops, T, M, I, K):
+    """The training forward's gate_up_proj + activation in one kernel (vgpt_gated_mlp_act_fwd_keep) against what it
+    replaces, ops.linear followed by silu_mul_fwd: the stored [gate | up] and the activation are identical bits (small grids
+    on the 128-tile kernel, big ones on the 256-tile kernel and its row remainder)."""
+    x = bf(torch.randn(M, K, generator=g(61))).to(DEV, BF)
+    w = bf(torch.randn(2 * I, K, generator=g(62)) * 0.1).to(DEV, BF)
+    gu_ref = ops.linear(x, w)
+    act_ref = T.silu_mul_fwd(gu_ref, torch.empty(M, I, dtype=BF, device=DEV), ops.ACT_SILU)
+    gu = torch.full((M, 2 * I), 7.0, dtype=BF, device=DEV)
+    act = ops.gated_mlp_act(x, w, ops.ACT_SILU, out=torch.empty(M, I, dtype=BF, device=DEV), gate_up_out=gu)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+    with pytest.raises(Exception, match="2I"):
+        ops.gated_mlp_act(x, w, ops.ACT_SILU, gate_up_out=torch.empty(M, I, dtype=BF, device=DEV))
+
+
 def test_elementwise_backward(ops, T):
     M, I, H = 37, 64, 192
     gu = bf(torch.randn(M, 2 * I, generator=g(5))).requires_grad_()

@@ -48,7 +48,7 @@
 // the whole suite) and measured it SLOWER on the same box: 162.8 / 163.5 us against 151.3 us per layer at the cfg-2 live
 // rows (31.75 vs 31.51 ms per step).  Overlapping a wave's own matrix and vector work does not help a loop whose two
 // waves per SIMD already fill the issue port between them (active_inst_any 0.39 per wave, profiles/r02_pmc_mfma.json);
-// removed from the source (git history: "attention: software-pipelined loop").
+// kept out of the product as csrc/experiments/attn_fwd_pipelined_loop.inc.
 
 namespace {
 

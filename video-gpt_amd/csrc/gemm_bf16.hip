@@ -122,6 +122,11 @@ struct GemmArgs {
     const float* rope_cos;
     const float* rope_sin;
     int rope_cols, head_dim;
+    // MODE_GATED, training forward (vgpt_gated_mlp_act_fwd_keep): also store [gate | up] (M, 2I) rounded to bf16 -- what
+    // gate_up_proj returns and the backward reads -- and compute act(gate) * up FROM the rounded values, bit for bit what
+    // the plain GEMM followed by vgpt_silu_mul_fwd produces; null: inference (activation from the fp32 accumulators)
+    bf16* gu_out = nullptr;
+    int64_t ld_gu = 0;
 };
 
 __device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
@@ -1145,8 +1150,20 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                 if (n >= g.I) continue;
                 const f32x4 gate = acc[2 * p][j], up = acc[2 * p + 1][j];
                 bf16x4 o;
+                if (g.gu_out) {
+                    bf16x4 gb, ub;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = f2bf(act_apply(gate[t], g.act) * up[t]);
+                    for (int t = 0; t < 4; ++t) {
+                        gb[t] = f2bf(gate[t]);
+                        ub[t] = f2bf(up[t]);
+                        o[t] = f2bf(act_apply(bf2f(gb[t]), g.act) * bf2f(ub[t]));
+                    }
+                    store_out4(g.gu_out + (int64_t)m * g.ld_gu + n, gb);
+                    store_out4(g.gu_out + (int64_t)m * g.ld_gu + g.I + n, ub);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = f2bf(act_apply(gate[t], g.act) * up[t]);
+                }
                 store_out4(g.C + (int64_t)m * g.ldc + n, o);
             }
         }
@@ -1389,9 +1406,25 @@ VGPT_EXPORT int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const v
     return launch<MODE_PLAIN, false, true>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_tr");
 }
 
+static int gated_mlp_impl(const void* A, const void* W_gate_up, void* out, void* gate_up_out, int64_t M, int64_t I, int64_t K,
+                          int64_t lda, int64_t ldw, int64_t ldo, int64_t ld_gu, int act, void* stream);
+
 VGPT_EXPORT int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, void* out, int64_t M,
                                        int64_t I, int64_t K, int64_t lda, int64_t ldw, int64_t ldo,
                                        int act, void* stream) {
+    return gated_mlp_impl(A, W_gate_up, out, nullptr, M, I, K, lda, ldw, ldo, 0, act, stream);
+}
+
+VGPT_EXPORT int vgpt_gated_mlp_act_fwd_keep(const void* A, const void* W_gate_up, void* out, void* gate_up_out, int64_t M,
+                                            int64_t I, int64_t K, int64_t lda, int64_t ldw, int64_t ldo, int64_t ld_gu,
+                                            int act, void* stream) {
+    VGPT_REQUIRE(gate_up_out && ld_gu >= 2 * I && ld_gu % 4 == 0 && ((uintptr_t)gate_up_out & 7) == 0, VGPT_ERR_INVALID,
+                 "vgpt_gated_mlp_act_fwd_keep: gate_up_out must be an 8-byte aligned (M, >= 2I) buffer, ld_gu a multiple of 4");
+    return gated_mlp_impl(A, W_gate_up, out, gate_up_out, M, I, K, lda, ldw, ldo, ld_gu, act, stream);
+}
+
+static int gated_mlp_impl(const void* A, const void* W_gate_up, void* out, void* gate_up_out, int64_t M, int64_t I, int64_t K,
+                          int64_t lda, int64_t ldw, int64_t ldo, int64_t ld_gu, int act, void* stream) {
     VGPT_REQUIRE(A && W_gate_up && out, VGPT_ERR_INVALID, "vgpt_gated_mlp_act_fwd: null pointer");
     VGPT_REQUIRE(M >= 0 && I > 0 && K > 0, VGPT_ERR_INVALID, "vgpt_gated_mlp_act_fwd: bad shape");
     VGPT_REQUIRE(act >= VGPT_ACT_SILU && act <= VGPT_ACT_GELU_TANH, VGPT_ERR_INVALID,
@@ -1413,6 +1446,7 @@ VGPT_EXPORT int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, voi
     g.epi = VGPT_EPI_NONE; g.act = act; g.I = (int)I;
     g.tiles_m = g.tiles_n = 0;
     g.rope_cos = g.rope_sin = nullptr; g.rope_cols = g.head_dim = 0;
+    g.gu_out = (bf16*)gate_up_out; g.ld_gu = ld_gu;
     return launch<MODE_GATED>(g, I, (hipStream_t)stream, "vgpt_gated_mlp_act_fwd");
 }
 

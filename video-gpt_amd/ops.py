@@ -155,8 +155,9 @@ def linear_qkv_rope(x: torch.Tensor, weight: torch.Tensor, cos: torch.Tensor, si
 
 
 def gated_mlp_act(x: torch.Tensor, w_gate_up: torch.Tensor, act: int = ACT_SILU,
-                  out: Optional[torch.Tensor] = None):
-    """act(x Wg^T) * (x Wu^T) with W_gate_up = [Wg ; Wu] (2I, K)."""
+                  out: Optional[torch.Tensor] = None, gate_up_out: Optional[torch.Tensor] = None):
+    """act(x Wg^T) * (x Wu^T) with W_gate_up = [Wg ; Wu] (2I, K).  gate_up_out (M, 2I): the training forward's form --
+    also stores the bf16 [gate | up] the backward needs and computes the activation from those rounded values."""
     _chk(x, BF16, "gated_mlp.x"); _chk(w_gate_up, BF16, "gated_mlp.w")
     K = x.shape[-1]
     I = w_gate_up.shape[0] // 2
@@ -167,6 +168,13 @@ def gated_mlp_act(x: torch.Tensor, w_gate_up: torch.Tensor, act: int = ACT_SILU,
         out = torch.empty(*x.shape[:-1], I, dtype=BF16, device=x.device)
     else:
         _chk(out, BF16, "gated_mlp.out")
+    if gate_up_out is not None:
+        _chk(gate_up_out, BF16, "gated_mlp.gate_up_out")
+        if gate_up_out.numel() != M * 2 * I:
+            raise VgptError("gated_mlp: gate_up_out must hold (M, 2I) values")
+        call("vgpt_gated_mlp_act_fwd_keep", x.data_ptr(), w_gate_up.data_ptr(), out.data_ptr(), gate_up_out.data_ptr(), M, I, K,
+             K, K, I, 2 * I, act, _stream())
+        return out
     call("vgpt_gated_mlp_act_fwd", x.data_ptr(), w_gate_up.data_ptr(), out.data_ptr(), M, I, K, K, K, I,
          act, _stream())
     return out

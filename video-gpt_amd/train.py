@@ -238,8 +238,9 @@ class Stage1Trainer:
             ops.linear(ctx[k], at.o_proj.weight, residual=hbuf[li], out=h2[k])
             ops.rmsnorm(h2[k], layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon,
                         out=n2[k])
-            ops.linear(n2[k], mlp.gate_up_proj.weight, out=gu[k])
-            T.silu_mul_fwd(gu[k], act[k], mlp.act)
+            # gate_up_proj + act(gate) * up in one kernel that also keeps the bf16 [gate | up] for the backward: bit for bit
+            # ops.linear(n2, W) followed by T.silu_mul_fwd (tests/test_train_gpu.py), without the (M, 2I) round trip
+            ops.gated_mlp_act(n2[k], mlp.gate_up_proj.weight, mlp.act, out=act[k], gate_up_out=gu[k])
             if with_output:
                 ops.linear(act[k], mlp.down_proj.weight, residual=h2[k], out=hbuf[li + 1])
 
