@@ -43,6 +43,13 @@
 #define VGPT_ATTN_LAZY 0
 #endif
 #define LAZY_THRESH 8.0f
+// Diagnostics build (make attn-variant-VGPT_ATTN_STAMPS, scripts/attn_stamps.py; results unchanged, timing perturbed by
+// ~4 x 50 cycles per tile): wave 0 of every workgroup sums, over its tiles, the shader cycles (s_memtime) of four stretches
+// of the loop -- top of the iteration -> behind the barrier | -> QK^T MFMAs issued | -> softmax done | -> P V issued -- into
+// rows [cap, 2 cap) of the vgpt_attn_trace buffer, and its first / last s_memtime and tile count into rows [2 cap, 3 cap).
+#ifndef VGPT_ATTN_STAMPS
+#define VGPT_ATTN_STAMPS 0
+#endif
 // Round 3 also built a software-pipelined form of the tile loop (the QK^T MFMAs of tile t+1 issued inside the softmax of
 // tile t through sched_group_barrier, K one tile ahead of V in the same two staging buffers; 252 registers, parity-green on
 // the whole suite) and measured it SLOWER on the same box: 162.8 / 163.5 us against 151.3 us per layer at the cfg-2 live
@@ -74,6 +81,7 @@ struct AttnArgs {
     int64_t q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss;
     float scale_log2e;
     unsigned long long* trace;  // diagnostics (vgpt_attn_trace): 4 x u64 per workgroup, or null
+    long long trace_cap;        // rows of one region of the trace buffer (the stamps build writes three regions)
 };
 
 // One 1-KiB LDS-DMA piece: lane i's 16 bytes at base + off land at lds_dst + 16 i.  Issued from inline asm so
@@ -97,6 +105,17 @@ __device__ __forceinline__ void glds4(const uint32_t* src, uint32_t lds_dst) {
                  : "v"(src), "s"(lds_dst)
                  : "memory");
 }
+
+#if VGPT_ATTN_STAMPS
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define STAMP(var) const unsigned long long var = stamp_now()
+#else
+#define STAMP(var)
+#endif
 
 template <int D>
 struct Cfg {
@@ -133,6 +152,10 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     const int r = lane & 31, h = lane >> 5;
     const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int n_tiles_done = 0;
+#if VGPT_ATTN_STAMPS
+    unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull};
+    const unsigned long long c_start = stamp_now();
+#endif
 
     // ---- work item ----
     int wid = blockIdx.x, head, b, row0, row_last;
@@ -333,6 +356,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     mask_dma(0, e_cur);
     stage(0, (int)(e_cur >> 8));
     for (int it = 0; it < n_act; ++it) {
+        STAMP(sA);
         if constexpr (GLDS) {
             // this wave's share of the current tile has landed; the raw barrier then (a) publishes every wave's
             // share and (b) guarantees every wave is done reading the other buffer before it is refilled
@@ -343,6 +367,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             lds_store(buf);
             __syncthreads();
         }
+        STAMP(sB);
         const uint32_t e_n2 = it + 2 < n_act ? alist[3 + it] : 0u;  // consumed at the end of the iteration
         if (it + 1 < n_act) {
             mask_dma(buf ^ 1, e_nxt);
@@ -381,6 +406,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
                     S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[kb][s], Qf[s], S[kb], 0, 0, 0);
 #endif
             }
+            STAMP(sC);
             // ---- V^T fragments do not depend on the softmax: request them now so their LDS latency hides
             //      under the softmax VALU work ----
             bf16x8 Vf[DT][4];
@@ -494,6 +520,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             }
             m_i = m_new;
 #endif
+            STAMP(sD);
             // ---- P^T fragments: accumulator registers 8*half..8*half+7 of S[kb] ----
             bf16x8 Pf[4];
 #pragma unroll
@@ -509,6 +536,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
 #if VGPT_ATTN_LAZY
 #pragma unroll
             for (int t = 0; t < 4; ++t) Ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, Pf[t], Ol, 0, 0, 0);   // l += sum_k P
+#endif
+#if VGPT_ATTN_STAMPS
+            {
+                STAMP(sE);
+                ph[0] += sB - sA; ph[1] += sC - sB; ph[2] += sD - sC; ph[3] += sE - sD;
+            }
 #endif
         }
         e_cur = e_nxt;
@@ -526,6 +559,13 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         t[1] = __builtin_amdgcn_s_memrealtime();
         t[2] = ((unsigned long long)xcc_id << 32) | hw_id;
         t[3] = ((unsigned long long)(unsigned)wid << 32) | (unsigned)n_tiles_done;
+#if VGPT_ATTN_STAMPS
+        const unsigned long long c_end = stamp_now();
+        unsigned long long* p1 = a.trace + 4ull * (a.trace_cap + blockIdx.x);
+        unsigned long long* p2 = a.trace + 4ull * (2ull * a.trace_cap + blockIdx.x);
+        p1[0] = ph[0]; p1[1] = ph[1]; p1[2] = ph[2]; p1[3] = ph[3];
+        p2[0] = c_start; p2[1] = c_end; p2[2] = (unsigned long long)n_tiles_done; p2[3] = 0ull;
+#endif
     }
     // ---- epilogue: lane holds O^T[d = 32dt + (i&3) + 8(i>>2) + 4h][q = r] ----
 #if VGPT_ATTN_LAZY
@@ -638,6 +678,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
     a.n_items = plan ? (int)plan->n_items : 0;
     const int64_t n_wg = plan ? plan->n_items * n_heads : (int64_t)(a.nqb - a.qb0) * n_heads * B;
     a.trace = n_wg <= g_trace_cap ? g_trace : nullptr;
+    a.trace_cap = g_trace_cap;
     hipStream_t s = (hipStream_t)stream;
     int rc = VGPT_ERR_UNSUPPORTED;
 #define ATTN_CASE(DD)                                                                     \

@@ -56,6 +56,11 @@
 // at the kernel boundary behind it (MI355X_MICROARCH.md, price list row `boundary`: + B / 6 TB/s for B dirty bytes).
 // Measured in round 3: 35.3 ms per sampler step against 32.0 (o_proj 97 vs 72 us, qkv 242 vs 205): the consumer kernel
 // finds its input in neither L2 nor -- apparently -- as readily in the Infinity Cache; the plain stores stay.
+// Also measured and removed (round 3): software prefetch into the XCD's L2 -- wave 0 / 1 of every workgroup touching one dword
+// per 128-byte line of a 1/4 (A) / 1/8 (W) slice of the k-pieces three k-tiles ahead, so that the first of the 4 / 8
+// workgroups of an XCD that want a piece no longer misses L2 (12 of 64 piece fetches per k-tile do: the 16-19 % beyond-L2
+// fills of the counters).  Same box: 34.0 ms per sampler step against 33.35 / 33.43, 8192^3 1254 vs 1306 TFLOP/s: the extra
+// vector-memory instructions cost the loop more than the Infinity-Cache-served fills do.
 #ifndef VGPT_GEMM_STORE_WT
 #define VGPT_GEMM_STORE_WT 0
 #endif
@@ -1329,6 +1334,7 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     g2.A = ATR ? g.A + m1 : g.A + m1 * g.lda;  // a transposed A keeps m along its columns
     g2.C = g.C + m1 * g.ldc;
     if (g.epi == VGPT_EPI_RESID) g2.extra = g.extra + m1 * g.ldr;
+    if (g.gu_out) g2.gu_out = g.gu_out + m1 * g.ld_gu;
     if (MODE == MODE_ROPE) {
         g2.rope_cos = g.rope_cos + m1 * (g.head_dim / 2);
         g2.rope_sin = g.rope_sin + m1 * (g.head_dim / 2);
