@@ -562,9 +562,10 @@ def main():
             def attn_call(l, li):
                 if eng.S:
                     return ops.attention_qkv_range(eng.qkv_full[li].view(1, eng.L, -1), eng.pm, nq_, nk_, hd_, eng.S, eng.ctx,
-                                                   segments=eng.seg_live)
+                                                   segments=eng.seg_live, item_rows=eng.attn_item_rows)
                 if eng.seg_all is not None:
-                    return ops.attention_qkv_range(eng.qkv, eng.pm, nq_, nk_, hd_, 0, eng.ctx, segments=eng.seg_all)
+                    return ops.attention_qkv_range(eng.qkv, eng.pm, nq_, nk_, hd_, 0, eng.ctx, segments=eng.seg_all,
+                                                   item_rows=eng.attn_item_rows)
                 return ops.attention_qkv(eng.qkv, eng.pm, nq_, nk_, hd_, out=eng.ctx)
             kinds = (("gate_up", "gemm_bf16_kernel<MODE_GATED> (gate_up_proj + act(gate) * up epilogue)", 2 * rows * H * 2 * I,
                       lambda l, li: ops.gated_mlp_act(eng.nrm, l.mlp.gate_up_proj.weight, l.mlp.act, out=eng.act)),

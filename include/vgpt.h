@@ -175,7 +175,7 @@ int vgpt_attn_blockmask_fwd_qrange(const void* q, const void* k, const void* v, 
                                    int64_t o_sh, int64_t o_ss, float scale, void* stream);
 
 /* ---- planned forward.  A PLAN describes the query side of one mask:
- *   items         (n_items, 4) int32: {batch, row0, nrows (1..128), 0}; disjoint row ranges, cut wherever the
+ *   items         (n_items, 4) int32: {batch, row0, nrows (1..item_rows), 0}; disjoint row ranges, cut wherever the
  *                 caller likes -- at the boundaries of packed sequences, so that no item mixes rows with different key
  *                 sets (an aligned block straddling two sequences would walk the key tiles of both);
  *   item_summary  (n_items, ceil(L/64)) uint16: 2 bits per 32-row slab of the item (0 none / 1 all / 2 mixed);
@@ -183,7 +183,9 @@ int vgpt_attn_blockmask_fwd_qrange(const void* q, const void* k, const void* v, 
  * vgpt_attn_plan_build fills item_summary and order from bits and items; both live in ONE caller-allocated workspace of
  * vgpt_attn_plan_workspace_bytes(L, n_items) bytes: item_summary at its start, order at the next multiple of 256 bytes
  * behind n_items * ceil(L/64) * 2.  vgpt_attn_fwd_plan computes exactly the rows the items cover (same result as
- * vgpt_attn_blockmask_fwd up to the rounding of the online softmax); lse may be NULL. */
+ * vgpt_attn_blockmask_fwd up to the rounding of the online softmax); lse may be NULL.  item_rows = the upper bound of the
+ * items' row counts, 128 or 256: 256 (head_dim 96 only) runs workgroups of 8 waves on 256 query rows, so one K / V tile
+ * staged in LDS serves twice the rows (half the LDS-DMA instructions per wave and half the L2 -> LDS bytes per FLOP). */
 int64_t vgpt_attn_plan_workspace_bytes(int64_t L, int64_t n_items);
 int vgpt_attn_plan_build(const uint32_t* bits, int64_t B, int64_t L, const int32_t* items, int64_t n_items,
                          uint16_t* item_summary, int32_t* order, void* stream);
@@ -191,7 +193,7 @@ int vgpt_attn_fwd_plan(const void* q, const void* k, const void* v, void* o, flo
                        const int32_t* items, const uint16_t* item_summary, const int32_t* order, int64_t n_items,
                        int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim, int64_t q_sb,
                        int64_t q_sh, int64_t q_ss, int64_t k_sb, int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh,
-                       int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss, float scale, void* stream);
+                       int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss, float scale, int item_rows, void* stream);
 
 /* ---- MX-fp8 attention (inference option of the cfg-5 rollout; head_dim 96).  Same operator as
  * vgpt_attn_fwd_plan with Q, K, V and the probabilities rounded to OCP e4m3 in blocks of 32 sharing a power-of-two (E8M0)

@@ -376,6 +376,13 @@ def test_attention_planned_kernel(ops, B, L, nh, nkv, segs, hd):
         assert rel_l2(out[b, r0:r1], ref[b, r0:r1]) < 1e-2
         assert torch.equal(out[b, r0:r1], legacy[b, r0:r1])   # same kernel, same per-row operation sequence
     assert bool((out.cpu()[~seen].float() == 7.0).all())   # rows outside the segments are not touched
+    if segs is not None and B == 1:
+        # 256-row items = the eight-wave kernel (head dim 96; other head dims fall back to 128-row items): one K / V tile
+        # staged per 256 query rows, every row still walks the same tiles in the same order -> the same bits
+        out8 = torch.full((B, L, nh * hd), 7.0, dtype=BF, device=DEV)
+        ops.attention_qkv_range(dq, pm, nh, nkv, hd, 0, out8, segments=segs, item_rows=256)
+        assert torch.equal(out8, out)
+        assert (pm.plan(segs, 256).item_rows == 256) and pm.plan(segs, 256).n_items < pm.plan(segs).n_items
 
 
 @pytest.mark.parametrize("spike_at,boost", [(200, 8.0), (40, 30.0), (700, 3.0)])

@@ -53,7 +53,7 @@ SIGNATURES = {
     "vgpt_attn_plan_build": (c_int, [_P, _I64, _I64, _P, _I64, _P, _P, _P]),
     "vgpt_attn_plan_workspace_bytes": (_I64, [_I64, _I64]),
     "vgpt_attn_fwd_plan": (
-        c_int, [_P] * 9 + [_I64, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
+        c_int, [_P] * 9 + [_I64, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, c_int, _P]),
     "vgpt_attn_fp8_workspace_bytes": (_I64, [_I64, _I64, c_int, c_int, c_int]),
     "vgpt_attn_fp8_quantize": (c_int, [_P] * 4 + [_I64, _I64, _I64, c_int, c_int, c_int] + [_I64] * 9 + [c_float, _P]),
     "vgpt_attn_fwd_plan_fp8": (c_int, [_P] * 6 + [_I64, _I64, _I64, c_int, c_int, c_int] + [_I64] * 3 + [_P]),

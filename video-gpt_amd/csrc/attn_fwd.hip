@@ -137,8 +137,14 @@ struct Cfg {
 template <int D, bool TR>
 constexpr int vbytes() { return TR ? 64 * Cfg<D>::VROW_TR : D * Cfg<D>::VROW_T; }
 
-template <int D, bool TR>
-__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnArgs a) {
+// NW = waves per workgroup: 4 (128 query rows, two workgroups per CU) or 8 (256 rows, one workgroup per CU, planned launches
+// with 256-row items, head dim 96 on the LDS-DMA path): the same K / V tile then serves twice the query rows, so every wave
+// issues half the LDS-DMA pieces per tile (3 instead of 6) and the CU takes in half the bytes per FLOP.
+template <int D, bool TR, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void attn_fwd_kernel(AttnArgs a) {
+    static_assert(NW == 4 || (NW == 8 && D == 96 && TR), "8 waves: head dim 96, LDS-DMA path");
+    constexpr int CODE_BITS = 2 * NW;                       // summary bits of one tile in an active-list entry
+    constexpr uint32_t CODE_MASK = (1u << CODE_BITS) - 1u;
     using C = Cfg<D>;
     constexpr int KS = D / 16;  // k-steps of the QK^T product
     constexpr int DT = D / 32;  // 32-wide d tiles of the output
@@ -242,7 +248,10 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
 
     // ---- staging helpers ----
     constexpr bool GLDS = TR && C::GLDS;
-    constexpr int PIECES = (64 * D * 2) / 1024 / 4;  // 1-KiB LDS-DMA pieces per wave per operand
+    constexpr int PIECES = (64 * D * 2) / 1024 / 4;  // 1-KiB LDS-DMA pieces per wave per operand (4 waves share one operand)
+    // 8 waves: waves 0-3 stage the K image, waves 4-7 the V image (3 pieces each); 4 waves: every wave stages both
+    const int swave = NW == 8 ? (wave & 3) : wave;
+    const bool do_k = NW == 4 || wave < 4, do_v = NW == 4 || wave >= 4;
     // per-lane (key, source chunk) of each DMA piece this wave issues
     // per-lane byte offset (inside a tile) of each 16-byte unit this wave moves; the tile base is wave-uniform
     int g_key[GLDS ? PIECES : 1];
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     if constexpr (GLDS) {
 #pragma unroll
         for (int j = 0; j < PIECES; ++j) {
-            const int unit = (wave * PIECES + j) * 64 + lane;  // 16-byte unit inside the tile image
+            const int unit = (swave * PIECES + j) * 64 + lane;  // 16-byte unit inside the tile image
             g_key[j] = unit / C::CHUNKS;
             g_vc[j] = (unit % C::CHUNKS) * 16;
             g_kc[j] = ((unit % C::CHUNKS) ^ ((g_key[j] >> 2) & 3)) * 16;
@@ -273,9 +282,9 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
                     ko = key * (uint32_t)a.k_ss * 2u + g_kc[j];
                     vo = key * (uint32_t)a.v_ss * 2u + g_vc[j];
                 }
-                const uint32_t dst = lds_base + (uint32_t)(buf * STAGE + (wave * PIECES + j) * 1024);
-                glds16(kt_base, ko, dst);
-                glds16(vt_base, vo, dst + C::KBYTES);
+                const uint32_t dst = lds_base + (uint32_t)(buf * STAGE + (swave * PIECES + j) * 1024);
+                if (do_k) glds16(kt_base, ko, dst);
+                if (do_v) glds16(vt_base, vo, dst + C::KBYTES);
             }
         }
     };
@@ -319,8 +328,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         a.bits + ((int64_t)b * a.L + min(row0 + wave * 32 + (lane >> 1), row_last)) * a.W;
     auto mask_dma = [&](int buf_, uint32_t e) {
         if (((e >> (2 * wave)) & 3) == 2) {
-            const int t = (int)(e >> 8);
-            glds4(mrow_src + min(2 * t + (lane & 1), a.W - 1), lds_base + (uint32_t)(MASK_OFF + buf_ * 1024 + wave * 256));
+            const int t = (int)(e >> CODE_BITS);
+            glds4(mrow_src + min(2 * t + (lane & 1), a.W - 1), lds_base + (uint32_t)(MASK_OFF + buf_ * (NW * 256) + wave * 256));
         }
     };
     auto stage = [&](int buf_, int kt_) {
@@ -334,14 +343,14 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     __syncthreads();  // every wave is done with the previous list and the staging buffers
     if (wave == 0) {
         const int lim = min(chunk0 + ACT_MAX, a.nkt);
-        auto code_of_tile = [&](int t) { return t < lim ? (sum16 ? (uint32_t)sum16[t] & 0xffu : (uint32_t)sum8[t]) : 0u; };
+        auto code_of_tile = [&](int t) { return t < lim ? (sum16 ? (uint32_t)sum16[t] & CODE_MASK : (uint32_t)sum8[t]) : 0u; };
         int n = 0;
         for (int base = chunk0; base < lim; base += 64) {
             const int t = base + lane;
             const uint32_t c = code_of_tile(t);
             const uint64_t bal = __ballot(c != 0);
             const int idx = n + __popcll(bal & ((1ull << lane) - 1));
-            if (c) alist[1 + idx] = ((uint32_t)t << 8) | c;
+            if (c) alist[1 + idx] = ((uint32_t)t << CODE_BITS) | c;
             n += __popcll(bal);
         }
         if (lane == 0) alist[0] = (uint32_t)n;
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     uint32_t e_nxt = __builtin_amdgcn_readfirstlane(n_act > 1 ? alist[2] : 0u);
     int buf = 0;
     mask_dma(0, e_cur);
-    stage(0, (int)(e_cur >> 8));
+    stage(0, (int)(e_cur >> CODE_BITS));
     for (int it = 0; it < n_act; ++it) {
         STAMP(sA);
         if constexpr (GLDS) {
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         const uint32_t e_n2 = it + 2 < n_act ? alist[3 + it] : 0u;  // consumed at the end of the iteration
         if (it + 1 < n_act) {
             mask_dma(buf ^ 1, e_nxt);
-            stage(buf ^ 1, (int)(e_nxt >> 8));
+            stage(buf ^ 1, (int)(e_nxt >> CODE_BITS));
         }
         const int code = (e_cur >> (2 * wave)) & 3;
         if (code) {
@@ -437,8 +446,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             if (code == 2) {
                 // per score two integer instructions without VCC: the bit spread to 0 / ~0 (v_bfe_i32), then
                 // (s & m) | (-inf & ~m) (v_bitop3_b32) -- as a select it was and + cmp + nop + cndmask per score
-                const uint2 mw = *reinterpret_cast<const uint2*>(smem + MASK_OFF + buf * 1024 + wave * 256 + r * 8);
-                const uint32_t mw0 = mw.x, mw1 = (2 * (int)(e_cur >> 8) + 1 < a.W) ? mw.y : 0u;
+                const uint2 mw = *reinterpret_cast<const uint2*>(smem + MASK_OFF + buf * (NW * 256) + wave * 256 + r * 8);
+                const uint32_t mw0 = mw.x, mw1 = (2 * (int)(e_cur >> CODE_BITS) + 1 < a.W) ? mw.y : 0u;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     const uint32_t w = (kb ? mw1 : mw0) >> (4 * h);
@@ -588,12 +597,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     }
 }
 
-template <int D, bool TR>
+template <int D, bool TR, int NW = 4>
 int launch(const AttnArgs& a, hipStream_t s) {
-    constexpr int lds = 2 * (Cfg<D>::KBYTES + vbytes<D, TR>()) + 4096 + 2048;
+    constexpr int lds = 2 * (Cfg<D>::KBYTES + vbytes<D, TR>()) + 4096 + 2 * NW * 256;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, TR>,
+        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, TR, NW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             vgpt_set_error("vgpt_attn_blockmask_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -602,7 +611,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int total = a.items ? a.n_items * a.n_heads : (a.nqb - a.qb0) * a.n_heads * a.B;
-    hipLaunchKernelGGL((attn_fwd_kernel<D, TR>), dim3(total), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, TR, NW>), dim3(total), dim3(64 * NW), lds, s, a);
     VGPT_CHECK_LAUNCH("vgpt_attn_blockmask_fwd");
     return VGPT_OK;
 }
@@ -627,6 +636,7 @@ struct ItemPlan {
     const uint16_t* isum;
     const int32_t* order;
     int64_t n_items;
+    int item_rows;   // upper bound of the items' row counts: 128 (4-wave kernel) or 256 (8-wave kernel, head dim 96)
 };
 
 static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, int64_t q_start,
@@ -685,6 +695,11 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
     case DD:                                                                              \
         rc = variant == 0 ? launch<DD, true>(a, s) : launch<DD, false>(a, s);             \
         break;
+    if (plan && plan->item_rows == 256) {
+        VGPT_REQUIRE(head_dim == 96 && variant == 0, VGPT_ERR_UNSUPPORTED,
+                     "vgpt_attn_fwd_plan: 256-row items need head_dim 96 (got %d)", head_dim);
+        return launch<96, true, 8>(a, s);
+    }
     switch (head_dim) {
         ATTN_CASE(64) ATTN_CASE(96) ATTN_CASE(128)
     }
@@ -732,7 +747,7 @@ VGPT_EXPORT int vgpt_attn_blockmask_fwd_qrange(const void* q, const void* k, con
 
 namespace {
 // ---- plan: per (item, key tile) summary and the longest-first order ----
-// block = 256 threads, one per row of an item (items hold at most 128 rows here); 2 bits per 32-row slab
+// block = 256 threads, one per row of an item (items hold at most 256 rows); 2 bits per 32-row slab
 __global__ __launch_bounds__(256) void item_summary_kernel(const uint32_t* __restrict__ bits,
                                                            const int32_t* __restrict__ items,
                                                            uint16_t* __restrict__ isum, int L, int W, int nkt) {
@@ -816,9 +831,10 @@ VGPT_EXPORT int vgpt_attn_fwd_plan(const void* q, const void* k, const void* v, 
                                    int64_t n_items, int64_t B, int64_t L, int n_heads, int n_kv_heads, int head_dim,
                                    int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                                    int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb, int64_t o_sh, int64_t o_ss,
-                                   float scale, void* stream) {
+                                   float scale, int item_rows, void* stream) {
     VGPT_REQUIRE(items && item_summary && order, VGPT_ERR_INVALID, "vgpt_attn_fwd_plan: null pointer");
-    const ItemPlan plan = {items, item_summary, order, n_items};
+    VGPT_REQUIRE(item_rows == 128 || item_rows == 256, VGPT_ERR_INVALID, "vgpt_attn_fwd_plan: item_rows must be 128 or 256");
+    const ItemPlan plan = {items, item_summary, order, n_items, item_rows};
     return attn_fwd_impl(q, k, v, o, lse, 0, bits, nullptr, nullptr, &plan, B, L, n_heads, n_kv_heads, head_dim, q_sb, q_sh, q_ss,
                          k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, scale, 0, stream);
 }

@@ -85,6 +85,13 @@ class StaticDenoiser:
         # "fp8": the per-step attention of the sampler runs on MX-fp8 operands (csrc/attn_fp8.hip; the cfg-5 option of
         # SURVEY.md §8d).  The per-clip passes (prefill, time rows) stay bf16.
         self.attn_fp8 = attention_precision == "fp8"
+        # query rows per work item of the per-step bf16 attention: 128 = the four-wave kernel, two workgroups per CU (product).
+        # 256 = the eight-wave kernel (one K / V tile staged per 256 rows: half the LDS-DMA instructions per wave and half the
+        # L2 -> LDS bytes per FLOP; head dim 96): bit-identical results, measured SLOWER in round 3 -- 159.5 / 160.4 us per
+        # layer against 148.3 us at the cfg-2 live rows, same box (a barrier across eight waves per tile costs more than the
+        # staging it saves) -- and kept behind VGPT_ATTN_ITEM_ROWS=256 for A/B runs.
+        import os
+        self.attn_item_rows = int(os.environ.get("VGPT_ATTN_ITEM_ROWS", "128"))
         self.model = model
         cfg = model.llm.config
         self.cfg = cfg
@@ -484,13 +491,15 @@ class StaticDenoiser:
                     ops.attention_qkv_fp8(full.view(1, self.L, -1), self.pm, nq, nk, hd, out=self.ctx, q_start=S,
                                           segments=self.seg_live, workspace=self.fp8_ws[li_], quant_from=self.fp8_from)
                 else:
-                    ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, S, self.ctx, segments=self.seg_live)
+                    ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, S, self.ctx, segments=self.seg_live,
+                                            item_rows=self.attn_item_rows)
             else:
                 ops.linear_qkv_rope(self.nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=self.qkv)
                 if self.attn_fp8:
                     ops.attention_qkv_fp8(self.qkv, self.pm, nq, nk, hd, out=self.ctx, segments=self.seg_all)
                 elif self.seg_all is not None:
-                    ops.attention_qkv_range(self.qkv, self.pm, nq, nk, hd, 0, self.ctx, segments=self.seg_all)
+                    ops.attention_qkv_range(self.qkv, self.pm, nq, nk, hd, 0, self.ctx, segments=self.seg_all,
+                                            item_rows=self.attn_item_rows)
                 else:
                     ops.attention_qkv(self.qkv, self.pm, nq, nk, hd, out=self.ctx)
             ops.linear(self.ctx, at.o_proj.weight, residual=self.hid, out=self.hid)

@@ -186,11 +186,11 @@ class AttnPlan:
     """Work items of a planned attention launch: items (n,4) int32, and one workspace sized by
     vgpt_attn_plan_workspace_bytes holding the per-(item, key tile) summary and the longest-first order."""
 
-    def __init__(self, items, summary, order, n_items):
-        self.items, self.summary, self.order, self.n_items = items, summary, order, n_items
+    def __init__(self, items, summary, order, n_items, item_rows=128):
+        self.items, self.summary, self.order, self.n_items, self.item_rows = items, summary, order, n_items, item_rows
 
 
-ITEM_ROWS = 128   # rows per work item of the planned forward kernel (four waves x 32 rows)
+ITEM_ROWS = 128   # rows per work item of the planned forward kernel (four waves x 32 rows); 256 = the eight-wave kernel
 
 
 class PackedMask:
@@ -201,13 +201,15 @@ class PackedMask:
         self._order = {}
         self._plans = {}
 
-    def plan(self, segments=None) -> "AttnPlan":
+    def plan(self, segments=None, item_rows: int = ITEM_ROWS) -> "AttnPlan":
         """Work plan of the planned forward kernel (include/vgpt.h, vgpt_attn_plan_build) for the query rows of
         `segments` = ((batch, row_begin, row_end), ...); default: every row, one segment per batch item.  Each
-        segment is cut into items of ITEM_ROWS rows; cut segments where packed sequences meet so that no item straddles
-        two key sets."""
+        segment is cut into items of `item_rows` rows (128, or 256 for the eight-wave kernel: head dim 96); cut segments
+        where packed sequences meet so that no item straddles two key sets."""
+        if item_rows not in (128, 256):
+            raise VgptError("attention plan: item_rows must be 128 or 256")
         skey = tuple(tuple(int(v) for v in s_) for s_ in segments) if segments is not None else None
-        key = skey
+        key = (skey, item_rows)
         p = self._plans.get(key)
         if p is None:
             segs = skey if skey is not None else tuple((b, 0, self.L) for b in range(self.B))
@@ -215,7 +217,7 @@ class PackedMask:
             for b, r0, r1 in segs:
                 if not (0 <= b < self.B and 0 <= r0 <= r1 <= self.L):
                     raise VgptError(f"attention plan: bad segment {(b, r0, r1)}")
-                items += [(b, r, min(ITEM_ROWS, r1 - r), 0) for r in range(r0, r1, ITEM_ROWS)]
+                items += [(b, r, min(item_rows, r1 - r), 0) for r in range(r0, r1, item_rows)]
             dev = self.bits.device
             n_ = len(items)
             it = torch.tensor(items, dtype=torch.int32).reshape(n_, 4).to(dev)
@@ -230,7 +232,7 @@ class PackedMask:
             if n_:
                 call("vgpt_attn_plan_build", self.bits.data_ptr(), self.B, self.L, it.data_ptr(), n_,
                      summ.data_ptr(), order.data_ptr(), _stream())
-            p = self._plans[key] = AttnPlan(it, summ, order, n_)
+            p = self._plans[key] = AttnPlan(it, summ, order, n_, item_rows)
             p.workspace = ws
         return p
 
@@ -352,11 +354,12 @@ def _attn_plan_call(q, k, v, o, lse, pm, plan, B, L, n_heads, n_kv_heads, head_d
     if plan.n_items:
         call("vgpt_attn_fwd_plan", q, k, v, o, lse, pm.bits.data_ptr(), plan.items.data_ptr(), plan.summary.data_ptr(),
              plan.order.data_ptr(), plan.n_items, B, L, n_heads, n_kv_heads, head_dim,
-             *strides, float(scale), _stream())
+             *strides, float(scale), int(plan.item_rows), _stream())
 
 
 def attention_qkv_range(qkv_full: torch.Tensor, pm: PackedMask, n_heads: int, n_kv_heads: int, head_dim: int,
-                        q_start: int, out_active: torch.Tensor, scale: Optional[float] = None, segments=None):
+                        q_start: int, out_active: torch.Tensor, scale: Optional[float] = None, segments=None,
+                        item_rows: int = ITEM_ROWS):
     """Attention of query rows [q_start, L) against all L rows of the fused (1, L, 3H-like) buffer; `out_active`
     holds the L - q_start computed rows (condition-prefix reuse, see include/vgpt.h).  segments: optional
     ((0, row_begin, row_end), ...) covering [q_start, L), cut where packed sequences meet."""
@@ -370,7 +373,9 @@ def attention_qkv_range(qkv_full: torch.Tensor, pm: PackedMask, n_heads: int, n_
     kq = qkv_full.data_ptr() + hq * 2
     vq = kq + n_kv_heads * head_dim * 2
     o_base = out_active.data_ptr() - q_start * hq * 2   # absolute-row addressing of the active output buffer
-    plan = pm.plan(segments if segments is not None else ((0, q_start, L),))
+    if item_rows == 256 and head_dim != 96:
+        item_rows = ITEM_ROWS        # the eight-wave kernel exists for head dim 96 only
+    plan = pm.plan(segments if segments is not None else ((0, q_start, L),), item_rows)
     _attn_plan_call(qkv_full.data_ptr(), kq, vq, o_base, None, pm, plan, 1, L, n_heads, n_kv_heads, head_dim,
                     (L * width, head_dim, width) * 3 + (L * hq, head_dim, hq), scale)
     return out_active
