@@ -245,3 +245,49 @@ def test_scheduler_noise_level_premix():
     b = torch.cat(S.LVMScheduler(num_steps=2)(mixed, model.frame_block_forward_with_cfg, SC.model_kwargs(batch, cond, DEV),
                                               prediction_type="x1"))
     assert SC.rel_l2(a, b) < 1e-2
+
+
+def test_engine_is_reused_for_the_next_clip_of_the_same_sequence():
+    """Rounds of a rollout whose window is full present the same sequence with new condition latents: the scheduler re-binds
+    the engine cached on the model (buffers, attention plan, captured graph kept; per-clip pass redone) instead of building
+    a new one.  Same bits as a fresh engine on the same inputs; another layout, other parameter storage or
+    cache_engines = False build a new engine."""
+    cfg = R.TINY
+    P = importlib.import_module("video-gpt_amd.processor")
+    LY = importlib.import_module("video-gpt_amd.layout")
+    S = importlib.import_module("video-gpt_amd.scheduler")
+    C, G, hw, steps = 2, 2, (16, 16), 3
+    bl = (hw[0] // 2) * (hw[1] // 2) + 2
+    p, batch, z, cond = SC.build_case(cfg, C=C, G=G, hw=hw)
+    lay = lambda: LY.TokenLayout.from_plans([(P.plan_inference([C, G])[0], bl, 0), (P.plan_inference([0, G])[0], bl, C * bl)],
+                                            (C + G) * bl)
+    model = SC.build_product_model(cfg, p, DEV)
+    cond2 = [torch.randn(1, 4, *hw, generator=torch.Generator("cpu").manual_seed(2000 + i)).to(BF).float() for i in range(C)]
+    z2 = [torch.randn(1, 4, *hw, generator=torch.Generator("cpu").manual_seed(3000 + i)).to(BF).float() for i in range(G)] * 2
+
+    def sample(zz, cc, cache=True, prec="bf16"):
+        sched = S.LVMScheduler(num_steps=steps)
+        sched.cache_engines = cache
+        sched.attention_precision = prec
+        kw = SC.model_kwargs(batch, cc, DEV)
+        kw["attention_mask"] = lay()                    # a NEW layout object with the same attributes, as the collator makes
+        out = torch.cat(sched([x.to(DEV, BF) for x in zz], model.frame_block_forward_with_cfg, kw, prediction_type="x1"))
+        return out, sched
+    for prec in ("bf16", "fp8"):
+        model.__dict__.pop("_vgpt_engine_cache", None)
+        a1, s1 = sample(z, cond, prec=prec)
+        a2, s2 = sample(z2, cond2, prec=prec)           # same sequence, new latents: the cached engine
+        assert not s1.last_engine_reused and s2.last_engine_reused and s2.last_engine is s1.last_engine
+        assert s2.last_engine.hoist and s2.last_engine.graph is not None
+        b2, f2 = sample(z2, cond2, cache=False, prec=prec)
+        assert not f2.last_engine_reused and f2.last_engine is not s1.last_engine
+        assert torch.equal(a2, b2)
+        a3, s3 = sample(z, cond, prec=prec)             # and back: nothing of clip 2 survives in the cached engine
+        assert s3.last_engine_reused and torch.equal(a3, a1)
+    ref = torch.cat(SC.oracle_sample(cfg, p, batch, z2, cond2, steps, "x1"))
+    assert SC.rel_l2(b2, ref) < 6e-2
+    # another sequence (one more generated frame) -> another engine; two layouts are kept
+    p3, batch3, z3, cond3 = SC.build_case(cfg, C=C, G=3, hw=hw)
+    sched = S.LVMScheduler(num_steps=steps)
+    sched([x.to(DEV, BF) for x in z3], model.frame_block_forward_with_cfg, SC.model_kwargs(batch3, cond3, DEV), prediction_type="x1")
+    assert not sched.last_engine_reused

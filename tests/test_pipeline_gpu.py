@@ -154,9 +154,10 @@ def test_cfg5_chained_rounds_with_fp8_attention(pipe_case, monkeypatch):
         bf16 engine within the calibrated latent tolerance, fp8 within 6e-2 (the fp8 option's own bound,
         tests/test_attn_fp8_gpu.py: measured ~2e-2 against bf16 attention on the same operands);
       * fp8 rollout against the bf16 rollout on the returned uint8 frames;
-      * the last round re-run ALONE on its recorded inputs by a fresh scheduler / engine, after poisoning the allocator's
-        free blocks, equals the chained run bit for bit: no per-layer fp8 workspace (prefix quantised once per clip in
-        prefill(), live rows from `fp8_from` per step), prefix cache or captured graph survives from an earlier round."""
+      * round 2 presents the same sequence as round 1 (full window), so the scheduler RE-BINDS round 1's engine (buffers,
+        per-layer fp8 workspaces, attention plan, captured graph kept; per-clip pass redone): the last round re-run ALONE on
+        its recorded inputs by a fresh engine, after poisoning the allocator's free blocks, equals the chained run bit for
+        bit -- nothing of an earlier round (quantised prefix, live rows, sampler state) survives in the re-used engine."""
     cfg, vcfg, p, vp, pipe, frames = pipe_case
     PL = importlib.import_module("video-gpt_amd.pipeline")
     S = importlib.import_module("video-gpt_amd.scheduler")
@@ -190,6 +191,7 @@ def test_cfg5_chained_rounds_with_fp8_attention(pipe_case, monkeypatch):
     for prec in ("bf16", "fp8"):
         assert len(outs[prec]) == 2 + sum(gen_nums)
         assert [len(r[1]["input_img_latents"]) for r in rec[prec]] == [2, 4, 4]          # grows, then slides
+        assert rec[prec][2][3] is rec[prec][1][3] and rec[prec][1][3] is not rec[prec][0][3]   # the slid window re-binds the engine
         for k, (z, kw, out, eng) in enumerate(rec[prec]):
             assert eng is not None and eng.attn_fp8 == (prec == "fp8") and eng.hoist        # the fast path, hoisted layout
             C = len(kw["input_img_latents"])
@@ -209,6 +211,7 @@ def test_cfg5_chained_rounds_with_fp8_attention(pipe_case, monkeypatch):
     _poison_free_device_memory()
     alone = S.LVMScheduler(num_steps=steps)
     alone.attention_precision = "fp8"
+    alone.cache_engines = False            # round 2 of the chained run re-bound round 1's engine (same sequence): this one is new
     got = alone(z, pipe.model.frame_block_forward_with_cfg, kw, prediction_type="x1")
     assert alone.last_engine.attn_fp8
     assert torch.equal(torch.cat(got), torch.cat(out))

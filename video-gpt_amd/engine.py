@@ -303,6 +303,24 @@ class StaticDenoiser:
             ops.linear(act, mlp.down_proj.weight, residual=hid, out=hid)
         torch.cuda.current_stream().synchronize()
 
+    def rebind(self, input_img_latents):
+        """The NEXT clip on an engine built for an identical sequence (same ids, positions, mask, frame geometry, sigma table:
+        the rounds of a rollout once the frame window is full): new condition latents in, everything that depends on them
+        recomputed (the per-clip pass), every buffer, the attention plan and the captured graph kept.  Nothing else of the
+        previous clip survives: the live rows of qkv_full and of the fp8 workspaces are rewritten by every step before they
+        are read, the sampler state by set_latents()."""
+        n_new = 0 if input_img_latents is None else len(input_img_latents)
+        if (self.cond is None) != (n_new == 0):
+            raise VgptError("StaticDenoiser.rebind: the clip has a different number of condition frames")
+        if self.cond is not None:
+            new = torch.cat([t.to(BF16) for t in input_img_latents], dim=0)
+            if tuple(new.shape) != tuple(self.cond.shape):
+                raise VgptError("StaticDenoiser.rebind: condition latents of another shape")
+            self.cond.copy_(new)
+        self.per_clip_setup()
+        self.steps_taken = 0
+        return self
+
     def per_clip_setup(self):
         """Everything a clip computes once instead of once per step: the condition prefix and the special rows of every step
         (one pass, _clip_pass; prefill() alone when the layout cannot be hoisted), the final layer's adaLN modulation of

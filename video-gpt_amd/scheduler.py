@@ -16,6 +16,7 @@ path).  KV caching is not used, exactly as the reference passes `past_key_values
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -35,7 +36,12 @@ class LVMScheduler:
         self.reuse_condition_prefix = True   # compute the step-invariant condition rows once per clip (engine.py)
         self.hoist_special_rows = True       # ... and the <|diffusion|> / time rows of all steps in one pass (needs a TokenLayout mask)
         self.attention_precision = "bf16"    # "fp8": MX-fp8 attention in the sampler steps of the fast path (cfg-5 option)
+        # keep the engine of a clip on the model and re-use it for the next clip of an identical sequence (the rounds of a
+        # rollout once the window is full: LVM/pipeline.py:418-422 re-creates the same prompt every round): buffers, attention
+        # plan and the captured graph survive, the per-clip pass is redone on the new condition latents
+        self.cache_engines = os.environ.get("VGPT_ENGINE_CACHE", "1") != "0"
         self.last_engine = None
+        self.last_engine_reused = False
 
     # ---- fast path ----
     def _fast_path_engine(self, z, func, model_kwargs, prediction_type):
@@ -53,6 +59,42 @@ class LVMScheduler:
                 "time_emb_inx", "use_img_cfg", "img_cfg_scale")
         if any(k not in model_kwargs for k in need) or model_kwargs.get("offload_model"):
             return None
+        self.last_engine_reused = False
+        self._owner_params = list(owner.parameters())
+        key = self._engine_key(z, model_kwargs, prediction_type) if self.cache_engines else None
+        cache = owner.__dict__.setdefault("_vgpt_engine_cache", {}) if key is not None else None
+        if cache is not None and key in cache:
+            eng = cache.pop(key)
+            cache[key] = eng                     # most recently used last
+            self.last_engine_reused = True
+            return eng.rebind(lat)
+        eng = self._build_engine(StaticDenoiser, owner, z, lat, model_kwargs, prediction_type)
+        if cache is not None:
+            cache[key] = eng
+            while len(cache) > 2:                # a clip's buffers are a few GB at cfg-2: the last two layouts are kept
+                cache.pop(next(iter(cache)))
+        return eng
+
+    def _engine_key(self, z, model_kwargs, prediction_type):
+        """Everything a StaticDenoiser is built from except the condition latents' VALUES; None when the mask is not a
+        TokenLayout (a dense mask would have to be compared element by element)."""
+        from .layout import TokenLayout
+        mask = model_kwargs["attention_mask"]
+        if not isinstance(mask, TokenLayout):
+            return None
+        lat = model_kwargs.get("input_img_latents")
+        tb = lambda t: t.detach().cpu().numpy().tobytes()
+        return (tb(model_kwargs["input_ids"]), tb(model_kwargs["position_ids"]), mask.attr().tobytes(),
+                repr(model_kwargs["input_image_sizes"]), repr(model_kwargs["denoise_image_sizes"]), repr(model_kwargs["time_emb_inx"]),
+                len(z), tuple(z[0].shape), None if not lat else (len(lat), tuple(lat[0].shape)),
+                bool(model_kwargs["use_img_cfg"]), float(model_kwargs["img_cfg_scale"]), prediction_type, tb(self.sigma),
+                self.pack_padding, self.reuse_condition_prefix, self.hoist_special_rows, self.attention_precision,
+                str(z[0].device),
+                # the captured graph holds the parameters' device addresses: parameters moved or re-allocated since
+                # (model.to(...), a new state dict assigned tensor by tensor) must not meet a cached graph
+                tuple(p_.data_ptr() for p_ in self._owner_params))
+
+    def _build_engine(self, StaticDenoiser, owner, z, lat, model_kwargs, prediction_type):
         return StaticDenoiser(owner, model_kwargs["input_ids"], model_kwargs["position_ids"],
                               model_kwargs["attention_mask"], lat, model_kwargs["input_image_sizes"],
                               model_kwargs["denoise_image_sizes"], model_kwargs["time_emb_inx"], len(z),
