@@ -20,7 +20,11 @@ def wrap(obj, name, label):
         torch.cuda.synchronize(); acc[label] = acc.get(label, 0.0) + time.perf_counter() - t0
         return r
     setattr(obj, name, g)
-wrap(pipe, "vae_encode", "vae_encode")
+wrap(pipe, "vae_encode", "vae_encode(sample)")
+wrap(pipe, "vae_posteriors", "vae_posteriors(encoder)")
+wrap(E.StaticDenoiser, "rebind", "engine_rebind(incl clip pass)")
+wrap(E.StaticDenoiser, "_clip_pass", "clip_pass")
+wrap(E.StaticDenoiser, "set_latents", "set_latents")
 wrap(pipe.vae, "decode_to_uint8", "vae_decode")
 wrap(pipe.processor, "prompt_condition_frame_block_inference", "processor")
 wrap(E.StaticDenoiser, "__init__", "engine_init(incl prefill)")
@@ -32,7 +36,7 @@ frames = [torch.rand(3, 256, 256) * 2 - 1 for _ in range(4)]
 kw = dict(input_images=frames, height=256, width=256, num_inference_steps=50, use_img_guidance=True, img_guidance_scale=1.6,
           seed=42, output_type="pt", prediction_type="x1", clean_image_noise_level=0.05, max_frame_window=16)
 pipe.prompt_condition_frame_block_autoregressive_inference(gen_nums=[8], **dict(kw, num_inference_steps=2))
-for rounds in (1, 3):
+for rounds in (1, 4):
     acc.clear()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     pipe.prompt_condition_frame_block_autoregressive_inference(gen_nums=[8] * rounds, **kw)
