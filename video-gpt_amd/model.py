@@ -475,6 +475,11 @@ class LVM(nn.Module):
         pe = self.pos_embed.reshape(1, self.pos_embed_max_size, self.pos_embed_max_size, -1)
         return pe[:, top:top + height, left:left + width, :].reshape(1, -1, pe.shape[-1])
 
+    def release_engines(self):
+        """Drop the sampler engines LVMScheduler keeps on this model between clips of the same sequence (a few GB of
+        per-clip buffers each at 256^2 / 12 frames; scheduler.LVMScheduler.cache_engines)."""
+        self.__dict__.pop("_vgpt_engine_cache", None)
+
     def _check_ready(self):
         w = self.llm.norm.weight
         if not w.is_cuda or w.dtype != BF16:

@@ -53,6 +53,8 @@ class Stage1Trainer:
         recompute the layer inside the backward (OmniGen/transformer.py:182-192).  forward_only: no gradient / optimizer
         state (loss evaluation through `loss.training_losses_x1_noise_input`)."""
         model._check_ready()
+        if hasattr(model, "release_engines"):
+            model.release_engines()          # a sampler engine cached on the model holds GBs the trainer's buffers want
         self.model = model
         self.cfg = model.llm.config
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
