@@ -108,6 +108,10 @@ using Cfg192 = TileCfg<256, 192, 2, 4>;
 // denoiser) is 32 such tiles, so M = 4096 rows make exactly two rounds of 256 workgroups where 256-wide tiles make 2.25 and
 // 192-wide ones three (and a 192-wide tile's k-step takes as long as a 256-wide one's: the loop is not bound by its MFMAs)
 using Cfg288 = TileCfg<256, 288, 4, 2>;
+// 256 x 256 with FOUR waves of 128 x 128 (MI = NI = 8: 256 accumulator registers, one wave per SIMD, 512-register budget)
+// and the register-staged, fragment-streaming loop PIPE == 6: every fragment feeds 8 MFMAs (a third fewer LDS bytes per
+// FLOP than the 128 x 64 wave tile) and no instruction of the loop is an LDS-DMA.  EXPERIMENT: VGPT_GEMM_TILE=512.
+using Cfg256w4 = TileCfg<256, 256, 2, 2>;
 
 enum { MODE_PLAIN = 0, MODE_GATED = 1, MODE_ROPE = 2 };
 
@@ -199,7 +203,7 @@ constexpr bool getenv_prio = VGPT_GEMM_SETPRIO;
 // 32-byte units of a row are XOR-swizzled with ((row>>3)&1)<<2 | (row&3) (on the DMA source address and on the
 // read) so that the 8 rows x 32 B a half-wave reads transposed hit 64 different banks.
 template <int MODE, typename C, int PIPE, bool ATR = false, bool WTR = false>
-__global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
+__global__ __launch_bounds__(C::THREADS, (PIPE == 6 ? 1 : 2)) void gemm_bf16_kernel(GemmArgs g) {
     static_assert(!(ATR || WTR) || MODE == MODE_PLAIN, "transposed operands: plain kernel only");
     constexpr bool ROPE = MODE == MODE_ROPE;
     constexpr int BM = C::BM, BN = C::BN, MI = C::MI, NI = C::NI;
@@ -385,6 +389,124 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
             }
         }
+    } else if constexpr (PIPE == 6) {
+        // One wave per SIMD, wave tile 128 x 128: a k-tile is 16 STEPS of 8 MFMAs (step s: W sub-tile s & 7 of k-step s >> 3
+        // against the eight A sub-tiles).  Operands go global -> registers -> LDS (same swizzled images as the LDS-DMA
+        // loops); every step carries, between its MFMAs, one piece of the staging pipeline and its share of the fragment
+        // stream:
+        //   steps 0..12 : piece p of tile kt+1 (fetched one whole iteration ago: counted vmcnt) -> LDS buffer buf^1, then
+        //                 the same piece of tile kt+2 fetched into the same registers (16 pieces over 13 steps);
+        //   every step  : the W fragment of step s+3 into a ring of four; k-step 0's steps also the A fragment s of
+        //                 k-step 1;
+        //   behind step 12: lgkmcnt(0) + s_barrier -- tile kt+1 complete in buf^1, nobody reads buf any more except through
+        //                 fragments already requested;
+        //   steps 13..15: the eight A fragments of tile kt+1's k-step 0 (and, through the ring, its first W fragments).
+        static_assert(MI == 8 && NI == 8 && !ATR && !WTR, "fragment-streaming loop: 2x2 waves of 128 x 128, NT operands");
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int NP = C::A_SLABS + C::W_SLABS;   // 16 pieces of 1 KiB per wave and k-tile
+        static_assert(NP == 16, "16 staging pieces per wave");
+        u32x4 R[NP];
+        bf16x8 A0[MI], A1[MI], Wr[4];
+        const int lane16 = lane * 16;
+        const int last = nk - 1;
+        auto gl = [&](u32x4& dst, const char* base, uint32_t voff) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base));
+        };
+        auto gload1 = [&](auto pc, int kt) {
+            constexpr int p = decltype(pc)::value;
+            if constexpr (p < C::A_SLABS) gl(R[p], a_org + (int64_t)kt * a_step, a_off[p]);
+            else gl(R[p], w_org + (int64_t)kt * w_step, w_off[p - C::A_SLABS]);
+        };
+        auto lwrite1 = [&](auto pc, int buf) {
+            constexpr int p = decltype(pc)::value;
+            if constexpr (p < C::A_SLABS)
+                *reinterpret_cast<u32x4*>(sA + buf * C::A_BYTES + (wave * C::A_SLABS + p) * 1024 + lane16) = R[p];
+            else
+                *reinterpret_cast<u32x4*>(sW + buf * C::W_BYTES + C::w_slab(wave, p - C::A_SLABS) * 1024 + lane16) = R[p];
+        };
+        auto ldWf = [&](bf16x8& dst, int buf, int ks, int i) {
+            dst = *reinterpret_cast<const bf16x8*>(sW + buf * C::W_BYTES + w_base + ((ks * 4 + fk) ^ sw) * 16 + i * 2048);
+        };
+        auto ldAf = [&](bf16x8& dst, int buf, int ks, int j) {
+            dst = *reinterpret_cast<const bf16x8*>(sA + buf * C::A_BYTES + a_base + ((ks * 4 + fk) ^ sw) * 16 + j * 2048);
+        };
+        auto mm2 = [&](const bf16x8& wf, const bf16x8(&af)[MI], auto ic, auto j0) {
+            constexpr int i = decltype(ic)::value, j = decltype(j0)::value;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[j], acc[i][j], 0, 0, 0);
+            acc[i][j + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[j + 1], acc[i][j + 1], 0, 0, 0);
+        };
+        // one step; `kt` is the tile being multiplied (buffer buf = kt & 1)
+        auto step = [&](auto sc, int buf, int kt) {
+            constexpr int S = decltype(sc)::value, KS = S >> 3, I = S & 7, SLOT = S & 3;
+            using IC = std::integral_constant<int, I>;
+            const bf16x8(&af)[MI] = KS == 0 ? A0 : A1;
+            // pieces of the staging pipeline carried by this step: steps 0..2 two each, steps 3..12 one each
+            constexpr int P0 = S < 3 ? 2 * S : (S < 13 ? S + 3 : -1);
+            constexpr int PN = S < 3 ? 2 : (S < 13 ? 1 : 0);
+            mm2(Wr[SLOT], af, IC{}, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PN > 0) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP - PN) : "memory");   // the PN oldest of the 16 fetches in flight
+                lwrite1(std::integral_constant<int, P0>{}, buf ^ 1);
+                if constexpr (PN > 1) lwrite1(std::integral_constant<int, P0 + 1>{}, buf ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm2(Wr[SLOT], af, IC{}, std::integral_constant<int, 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PN > 0) {
+                gload1(std::integral_constant<int, P0>{}, min(kt + 2, last));
+                if constexpr (PN > 1) gload1(std::integral_constant<int, P0 + 1>{}, min(kt + 2, last));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm2(Wr[SLOT], af, IC{}, std::integral_constant<int, 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+            // W fragment of step S + 3 (this tile, or the next one's first steps: behind the barrier of step 12)
+            if constexpr (S + 3 < 16) ldWf(Wr[(S + 3) & 3], buf, (S + 3) >> 3, (S + 3) & 7);
+            else ldWf(Wr[(S + 3) & 3], buf ^ 1, 0, (S + 3) & 7);
+            // A fragments: k-step 1 of this tile during k-step 0; the next tile's k-step 0 during steps 13..15
+            if constexpr (KS == 0) ldAf(A1[I], buf, 1, I);
+            if constexpr (S == 13) { ldAf(A0[0], buf ^ 1, 0, 0); ldAf(A0[1], buf ^ 1, 0, 1); ldAf(A0[2], buf ^ 1, 0, 2); }
+            if constexpr (S == 14) { ldAf(A0[3], buf ^ 1, 0, 3); ldAf(A0[4], buf ^ 1, 0, 4); ldAf(A0[5], buf ^ 1, 0, 5); }
+            if constexpr (S == 15) { ldAf(A0[6], buf ^ 1, 0, 6); ldAf(A0[7], buf ^ 1, 0, 7); }
+            __builtin_amdgcn_sched_barrier(0);
+            mm2(Wr[SLOT], af, IC{}, std::integral_constant<int, 6>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (S == 12) {   // tile kt+1 is in buf^1 (every wave's 16 pieces) and buf is read no more
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        };
+        // prologue: tile 0 through the registers into buffer 0, tile 1 fetched, first fragments
+        {
+#define VGPT_P16(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+#define VGPT_GL0(p) gload1(std::integral_constant<int, p>{}, 0);
+#define VGPT_LW0(p) lwrite1(std::integral_constant<int, p>{}, 0);
+#define VGPT_GL1(p) gload1(std::integral_constant<int, p>{}, min(1, last));
+            VGPT_P16(VGPT_GL0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            VGPT_P16(VGPT_LW0)
+            VGPT_P16(VGPT_GL1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < MI; ++j) ldAf(A0[j], 0, 0, j);
+            ldWf(Wr[0], 0, 0, 0);
+            ldWf(Wr[1], 0, 0, 1);
+            ldWf(Wr[2], 0, 0, 2);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+#define VGPT_STEP(sidx) step(std::integral_constant<int, sidx>{}, buf, kt);
+            VGPT_P16(VGPT_STEP)
+#undef VGPT_STEP
+        }
+#undef VGPT_GL0
+#undef VGPT_LW0
+#undef VGPT_GL1
+#undef VGPT_P16
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated fetches behind the last tile
     } else if constexpr (PIPE == 5) {
         // 4x2-wave tiles of 64 x 144 (256 x 288): six phases of 12 MFMAs per k-tile -- (ks, third of the wave's nine n
         // sub-tiles) -- with the W fragments of phase p+1 (three reads) and the A fragments of the other k-step (four) in
@@ -1145,32 +1267,79 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             }
         }
     } else {
+        // the activation is resolved OUTSIDE the unrolled loops (one instantiation per kind): with the switch inside, the
+        // 8 x 4 iterations of the 128 x 128 wave tile exceed the unroller's budget and the accumulators fall into scratch
+        auto gated_store = [&](auto actc, auto keepc) {
+            constexpr int ACT = decltype(actc)::value;
+            constexpr bool KEEP = decltype(keepc)::value;
 #pragma unroll
-        for (int j = 0; j < MI; ++j) {
-            const int m = m0e + wm * (MI * 16) + j * 16 + em;
-            if (m >= g.M) continue;
+            for (int j = 0; j < MI; ++j) {
+                const int m = m0e + wm * (MI * 16) + j * 16 + em;
+                if (m >= g.M) continue;
 #pragma unroll
-            for (int p = 0; p < NI / 2; ++p) {
-                const int n = n0e + (wn * (NI / 2) + p) * 16 + en;  // output column
-                if (n >= g.I) continue;
-                const f32x4 gate = acc[2 * p][j], up = acc[2 * p + 1][j];
-                bf16x4 o;
-                if (g.gu_out) {
-                    bf16x4 gb, ub;
+                for (int p = 0; p < NI / 2; ++p) {
+                    const int n = n0e + (wn * (NI / 2) + p) * 16 + en;  // output column
+                    if (n >= g.I) continue;
+                    const f32x4 gate = acc[2 * p][j], up = acc[2 * p + 1][j];
+                    bf16x4 o;
+                    if constexpr (KEEP) {
+                        bf16x4 gb, ub;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        gb[t] = f2bf(gate[t]);
-                        ub[t] = f2bf(up[t]);
-                        o[t] = f2bf(act_apply(bf2f(gb[t]), g.act) * bf2f(ub[t]));
+                        for (int t = 0; t < 4; ++t) {
+                            gb[t] = f2bf(gate[t]);
+                            ub[t] = f2bf(up[t]);
+                            o[t] = f2bf(act_apply(bf2f(gb[t]), ACT) * bf2f(ub[t]));
+                        }
+                        store_out4(g.gu_out + (int64_t)m * g.ld_gu + n, gb);
+                        store_out4(g.gu_out + (int64_t)m * g.ld_gu + g.I + n, ub);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o[t] = f2bf(act_apply(gate[t], ACT) * up[t]);
                     }
-                    store_out4(g.gu_out + (int64_t)m * g.ld_gu + n, gb);
-                    store_out4(g.gu_out + (int64_t)m * g.ld_gu + g.I + n, ub);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) o[t] = f2bf(act_apply(gate[t], g.act) * up[t]);
+                    store_out4(g.C + (int64_t)m * g.ldc + n, o);
                 }
-                store_out4(g.C + (int64_t)m * g.ldc + n, o);
             }
+        };
+        using KT = std::true_type;
+        using KF = std::false_type;
+        if constexpr (PIPE != 6) {
+            // the 8-wave kernels (16 iterations) stay as they were measured: activation selected inside the loops
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const int m = m0e + wm * (MI * 16) + j * 16 + em;
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int p = 0; p < NI / 2; ++p) {
+                    const int n = n0e + (wn * (NI / 2) + p) * 16 + en;  // output column
+                    if (n >= g.I) continue;
+                    const f32x4 gate = acc[2 * p][j], up = acc[2 * p + 1][j];
+                    bf16x4 o;
+                    if (g.gu_out) {
+                        bf16x4 gb, ub;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            gb[t] = f2bf(gate[t]);
+                            ub[t] = f2bf(up[t]);
+                            o[t] = f2bf(act_apply(bf2f(gb[t]), g.act) * bf2f(ub[t]));
+                        }
+                        store_out4(g.gu_out + (int64_t)m * g.ld_gu + n, gb);
+                        store_out4(g.gu_out + (int64_t)m * g.ld_gu + g.I + n, ub);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o[t] = f2bf(act_apply(gate[t], g.act) * up[t]);
+                    }
+                    store_out4(g.C + (int64_t)m * g.ldc + n, o);
+                }
+            }
+        } else if (g.act == VGPT_ACT_SILU) {
+            if (g.gu_out) gated_store(std::integral_constant<int, VGPT_ACT_SILU>{}, KT{});
+            else gated_store(std::integral_constant<int, VGPT_ACT_SILU>{}, KF{});
+        } else if (g.act == VGPT_ACT_GELU) {
+            if (g.gu_out) gated_store(std::integral_constant<int, VGPT_ACT_GELU>{}, KT{});
+            else gated_store(std::integral_constant<int, VGPT_ACT_GELU>{}, KF{});
+        } else {
+            if (g.gu_out) gated_store(std::integral_constant<int, VGPT_ACT_GELU_TANH>{}, KT{});
+            else gated_store(std::integral_constant<int, VGPT_ACT_GELU_TANH>{}, KF{});
         }
     }
     if (!more) break;
@@ -1283,9 +1452,12 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const int64_t tiles_n = cdiv(n_out, MODE == MODE_GATED ? 128 : 256);
     const int64_t tiles_m = cdiv(g.M, 256);
     const int64_t big_tiles = tiles_m * tiles_n;
-    const bool use256 = f == 256 || f == 257 || f == 192 || f == 288 || f == 289 || (f != 128 && big_tiles >= 128);
+    const bool use256 = f == 256 || f == 257 || f == 192 || f == 288 || f == 289 || f == 512 || (f != 128 && big_tiles >= 128);
     if (!use256) return launch_cfg<MODE, Cfg128, 0, ATR, WTR>(g, n_out, s, name);
     if (f == 257) return launch_cfg<MODE, Cfg256, 0, ATR, WTR>(g, n_out, s, name);
+    if constexpr (!ATR && !WTR) {
+        if (f == 512) return launch_cfg<MODE, Cfg256w4, 6, ATR, WTR>(g, n_out, s, name);   // EXPERIMENT: 4 waves of 128 x 128
+    }
     if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
         if (f == 288) return launch_cfg<MODE, Cfg288, 5, ATR, WTR>(g, n_out, s, name);
         if (f == 289) return launch_cfg<MODE, Cfg288, 0, ATR, WTR>(g, n_out, s, name);
