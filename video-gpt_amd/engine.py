@@ -479,7 +479,8 @@ class StaticDenoiser:
         S = self.S
         x_rows, t_rows = (self.x_rows_a, self.t_rows_a) if S else (self.x_rows, self.t_rows)
         rope = self.rope_a if S else self.rope
-        ops.embed_gather(self.ids_a if S else self.input_ids, m.llm.embed_tokens.weight, out=self.hid)
+        if not self.hoist:   # a hoisted step's live rows are image rows only: the patch embedding below writes every one
+            ops.embed_gather(self.ids_a if S else self.input_ids, m.llm.embed_tokens.weight, out=self.hid)
         if self.cond is not None and not S:
             ops.patch_embed(self.cond, m.input_x_embedder.proj.weight, m.input_x_embedder.proj.bias, pos,
                             self.cond_rows, seq2d, m.pos_embed_max_size)
