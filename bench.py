@@ -295,7 +295,13 @@ def tag_rehearsal(line, args):
 
 
 def bench_stage1(args, rank, world, device, M, P, D, ops):
+    cal = None
+    if rank == 0 and not args.no_calibration:
+        cal = [calibrate(device, torch.cuda.Stream(device=device), ops, "before the timed region")]
     line = measure_stage1(args.steps, args.warmup, args.layers, rank, world, device, M, P, D, grad_ckpt=args.grad_ckpt)
+    if cal is not None:
+        cal.append(calibrate(device, torch.cuda.Stream(device=device), ops, "right after the timed region"))
+    line["calibration"] = cal
     line = tag_rehearsal(line, args)
     if rank == 0:
         print(json.dumps(line), flush=True)
