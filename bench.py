@@ -126,7 +126,8 @@ def pmc_records(kind):
                 out[key + "_source"] = f"profiles/{stem}.json (separate --pmc pass, not this run)"
                 break
     if kind in ("o_proj", "down_proj") and out:
-        out["note"] = "o_proj and down_proj share one kernel instantiation: the counter figures are their launch-weighted mix"
+        out["note"] = ("o_proj and down_proj share one kernel instantiation: the counter figures are their launch-weighted mix "
+                       "(of the HAND-WRITTEN kernel; they do not describe a launch that went to the vendor library)")
     return out
 
 
@@ -634,7 +635,9 @@ def main():
                 e1.record(stream)
                 stream.synchronize()
                 return s1.elapsed_time(e1) * 1e3
+            vc0 = L_.load().vgpt_gemm_vendor_calls()
             one_forward()
+            vendor_calls_in_step = L_.load().vgpt_gemm_vendor_calls() - vc0
             t_b = min(one_forward() for _ in range(3))
             try:
                 ops.linear = wrap(saved["linear"], lin_kind)
@@ -654,13 +657,21 @@ def main():
             c_us = (t_a - t_b) / max(n_pairs, 1)
             layer_us = t_b / nl
             klist = []
+            lib_ = L_.load()
+            on_vendor = {"o_proj": bool(lib_.vgpt_gemm_vendor_applies(rows, H, nq_ * hd_, 0, 0)) and vendor_calls_in_step > 0,
+                         "down_proj": bool(lib_.vgpt_gemm_vendor_applies(rows, H, I, 0, 0)) and vendor_calls_in_step > 0}
             for name, kname, alg, fn in kinds:
                 us = m_us[name] - c_us
-                rec = {"name": name, "kernel": kname, "launches_per_step": nl, "avg_us": round(us, 1),
+                if on_vendor.get(name):
+                    kname = ("hipBLASLt (vendor library behind vgpt_gemm_bf16, csrc/gemm_lt.hip: plain GEMM, residual through "
+                             "beta = 1) -- " + name + " + residual")
+                rec = {"name": name, "kernel": kname, "implementation": "vendor library" if on_vendor.get(name) else "hand-written HIP",
+                       "launches_per_step": nl, "avg_us": round(us, 1),
                        "avg_us_isolated_back_to_back": round(iso[name], 1),
                        "alg_gflop_per_launch": round(alg / 1e9, 1), "achieved_tflops": round(alg / us / 1e6, 1),
                        "frac": round(alg / us / 1e6 / PEAK_BF16_TFLOPS, 4), "share_of_step": round(us * nl / (ms_per_step * 1e3), 3)}
-                rec.update(pmc_records(name))
+                if not on_vendor.get(name):
+                    rec.update(pmc_records(name))
                 klist.append(rec)
             timing_note = {"method": "avg_us = inside one real eager denoise forward (a HIP-event pair around every launch of the "
                                      "five kinds, minus the fixed per-pair cost c = (forward with inner pairs - forward without) "
@@ -668,20 +679,26 @@ def main():
                                      "the MFMA-dense kinds)",
                            "event_pair_cost_us": round(c_us, 2), "pairs": n_pairs,
                            "eager_forward_us_per_layer": round(layer_us, 1)}
-        gem = [k for k in klist if k["name"] != "attn_fwd"]
+        # the dominant HAND-WRITTEN kernel: gemm_bf16_kernel (with o_proj / down_proj on the vendor library: its gate_up and
+        # qkv + RoPE instantiations, 64 launches and over half of the step; without the library all four)
+        gem = [k for k in klist if k["name"] != "attn_fwd" and k["implementation"] == "hand-written HIP"]
         t_gemm = sum(k["avg_us"] for k in gem) * 1e-6 * nl
         alg = sum(k["alg_gflop_per_launch"] for k in gem) * 1e9 * nl
         n_launch = len(gem) * nl
         achieved = alg / t_gemm / 1e12
         traf = [k.get("traffic_bytes_per_launch") for k in gem]
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all four instantiations of a decoder layer: gate_up, qkv_proj + RoPE, "
-                                           "down_proj, o_proj; 128 launches per step)",
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (the hand-written instantiations of a decoder layer: "
+                                           + ", ".join(k["name"] for k in gem) + f"; {n_launch} launches per step)",
                 "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                 "traffic": int(sum(traf) / len(traf)) if all(t is not None for t in traf) else None,
                 "traffic_source": gem[0].get("traffic_bytes_per_launch_source"),
                 "launches": n_launch, "avg_launch_us": round(t_gemm / n_launch * 1e6, 1),
                 "alg_flops_per_launch": alg / n_launch,
+                "gemm_vendor": {"origin": L_.load().vgpt_gemm_vendor_origin().decode(),
+                                "products_per_step": int(vendor_calls_in_step),
+                                "what": "o_proj and down_proj (GEMM + residual, nothing fused) go to hipBLASLt where its kernel is "
+                                        "measured ahead (csrc/gemm_lt.hip); VGPT_GEMM_VENDOR=0 runs them on gemm_bf16_kernel"},
                 "peak_note": "2500 = nominal dense bf16 peak (MI355X_MICROARCH.md); calibration.mfma_loop_tflops is what "
                              "nothing-but-MFMA loops on random operands sustain on THIS box in this run",
                 "kernels": klist, "kernel_timing": timing_note,

@@ -136,7 +136,24 @@ struct GemmArgs {
     // the plain GEMM followed by vgpt_silu_mul_fwd produces; null: inference (activation from the fp32 accumulators)
     bf16* gu_out = nullptr;
     int64_t ld_gu = 0;
+    // stream-K (vgpt_gemm_bf16_sk; MODE_PLAIN NT on 256 x 256 tiles, fewer tiles than CUs): the launch has one workgroup per
+    // CU and every workgroup takes an equal share of the (tile, k-tile) units -- at most the TAIL of one tile's reduction,
+    // whose fp32 partial sums it publishes in sk_ws[tile] (write-through stores, then a flag), followed by the HEAD of the
+    // next tile, which it completes with that tile's published tail and stores.  sk_ctl = {epoch, finished workgroups}.
+    float* sk_ws = nullptr;
+    int* sk_flags = nullptr;
+    int* sk_ctl = nullptr;
 };
+
+// write-through store / L1-bypassing load of 16 bytes: the hand-off of stream-K partial sums between workgroups
+// (MI355X_MICROARCH.md, inter-workgroup visibility: every byte stored `sc1`, every load of it `sc1`, the flag behind a
+// vmcnt(0) of every storing wave and a workgroup barrier)
+__device__ __forceinline__ void st16_wt(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ld16_sc1(f32x4& v, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+}
 
 __device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -240,9 +257,9 @@ __global__ __launch_bounds__(C::THREADS, (PIPE == 6 ? 1 : 2)) void gemm_bf16_ker
     int m0 = 0, n0 = 0;
     const char* a_org = nullptr;
     const char* w_org = nullptr;
-    auto set_tile = [&](int vt) {
+    auto set_tile = [&](int vt, bool remap = true) {
         int bid = vt;
-        {
+        if (remap) {
             const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
             bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         }
@@ -353,6 +370,44 @@ __global__ __launch_bounds__(C::THREADS, (PIPE == 6 ? 1 : 2)) void gemm_bf16_ker
     // rows through the same LDS, nor for the experimental loops.
     constexpr bool PERSIST = (PIPE == 0 || PIPE == 1) && !ROPE;
     bool prefetched = false;
+    int kbeg = 0, kend = nk;     // k-tiles of the current tile this workgroup multiplies (stream-K: a part of them)
+    // ---- stream-K segments of this workgroup ----
+    constexpr bool SKC = PIPE == 7 && MODE == MODE_PLAIN && !ATR && !WTR && BN == 256;   // PIPE 7 = the 4-phase loop + stream-K
+    // the current segment's tile (sk_tile), the workgroup's second segment if it has one (tile sk_tile2, k-tiles [0, sk_k2)),
+    // all wave-uniform scalars: a private ARRAY indexed by the segment number would make the tile origin -- and with it every
+    // staging address -- a per-lane value (16 more registers in the k-loop, spilled)
+    [[maybe_unused]] int sk_tile = 0, sk_tile2 = 0, sk_k2 = 0, sk_want = 0;
+    [[maybe_unused]] bool sk_any = true, sk_more = false;
+    [[maybe_unused]] const bool sk_on = SKC && g.sk_ws != nullptr;
+    if constexpr (SKC) {
+        if (sk_on) {
+            // workgroups of one XCD (blockIdx.x % 8) take neighbouring unit ranges: the same remap as the tile order
+            int w = blockIdx.x;
+            {
+                const int n_ = (int)gridDim.x, xcd = w & 7, q = n_ >> 3, r = n_ & 7;
+                w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+            }
+            const int64_t units = (int64_t)nwg * nk;
+            const int64_t u0 = units * w / gridDim.x, u1 = units * (w + 1) / gridDim.x;
+            sk_tile = (int)(u0 / nk);
+            kbeg = (int)(u0 % nk);
+            kend = (int)min((int64_t)nk, kbeg + (u1 - u0));
+            sk_any = u1 > u0;
+            if (u1 > (int64_t)(sk_tile + 1) * nk) {
+                sk_more = true;
+                sk_tile2 = sk_tile + 1;
+                sk_k2 = (int)(u1 - (int64_t)sk_tile2 * nk);
+            }
+            sk_tile = __builtin_amdgcn_readfirstlane(sk_tile);
+            sk_tile2 = __builtin_amdgcn_readfirstlane(sk_tile2);
+            sk_k2 = __builtin_amdgcn_readfirstlane(sk_k2);
+            kbeg = __builtin_amdgcn_readfirstlane(kbeg);
+            kend = __builtin_amdgcn_readfirstlane(kend);
+            sk_want = __builtin_amdgcn_readfirstlane(g.sk_ctl[0]) + 1;   // the flag value of THIS launch (bumped by the last workgroup to finish)
+            if (sk_any) set_tile(sk_tile, false);
+            else kbeg = kend = 0;
+        }
+    }
     for (;;) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -1108,17 +1163,17 @@ __global__ __launch_bounds__(C::THREADS, (PIPE == 6 ? 1 : 2)) void gemm_bf16_ker
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated fetches of the last tiles: their registers are reused below
         } else {
-        if (!prefetched) stage(0, 0);
+        if (!prefetched) stage(0, kbeg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (nk > 1) stage(1, 1);
+        if (kend - kbeg > 1) stage(1, kbeg + 1);
         ldW(Wf[0], 0, 0);
         ldA(Af[0], 0, 0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
+        for (int kt = kbeg; kt < kend; ++kt) {
+            const int buf = (kt - kbeg) & 1;
             // phase 1: (ks0, m-half 0)
             ldA(Af[1], buf, 0, 1);
-            if (kt >= 1 && kt + 1 < nk) stage_half(buf ^ 1, kt + 1, 1);
+            if (kt >= kbeg + 1 && kt + 1 < kend) stage_half(buf ^ 1, kt + 1, 1);
             mma(Wf[0], Af[0], H0{});
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: (ks0, m-half 1)
@@ -1134,8 +1189,8 @@ __global__ __launch_bounds__(C::THREADS, (PIPE == 6 ? 1 : 2)) void gemm_bf16_ker
             // its share of tile kt+1 has landed: after the barrier buffer `buf` is free for tile kt+2
             if constexpr ((kDebug & 16) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // 16: timing without the drain
             __syncthreads();
-            if (kt + 2 < nk) stage_half(buf, kt + 2, 0);
-            if (kt + 1 < nk) {
+            if (kt + 2 < kend) stage_half(buf, kt + 2, 0);
+            if (kt + 1 < kend) {
                 ldW(Wf[0], buf ^ 1, 0);
                 ldA(Af[0], buf ^ 1, 0, 0);
             }
@@ -1145,12 +1200,93 @@ __global__ __launch_bounds__(C::THREADS, (PIPE == 6 ? 1 : 2)) void gemm_bf16_ker
         }
     }
 
+    // ---- stream-K: a tail segment publishes its partial sums and the walk goes on; a head segment completes its tile ----
+    if constexpr (SKC) {
+        if (sk_on) {
+            const bool is_tail = kbeg > 0;                 // the tile's reduction started in another workgroup
+            const bool is_head = kend < nk;                // ... or ends in another one
+            float* ws = g.sk_ws + (int64_t)sk_tile * (BM * BN);
+            if (is_tail && sk_any) {
+                {
+                    float* wp = ws + tid * 4;        // one running pointer (32 separate addresses would cost 64 registers)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < MI; ++j) {
+                            st16_wt(wp, acc[i][j]);
+                            wp += C::THREADS * 4;
+                            asm volatile("" : "+v"(wp));
+                        }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are out
+                __syncthreads();                                     // ... and every wave's
+                if (tid == 0) {
+                    int* fp = g.sk_flags + sk_tile;
+                    asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(fp), "v"(sk_want) : "memory");
+                }
+                // next segment of this workgroup (the head of the following tile), if any
+                if (sk_more) {
+                    sk_more = false;
+                    __syncthreads();
+                    sk_tile = sk_tile2;
+                    set_tile(sk_tile, false);
+                    kbeg = 0;
+                    kend = sk_k2;
+                    continue;
+                }
+                break;
+            }
+            if (is_head && sk_any) {
+                if (tid == 0) {
+                    const int* fp = g.sk_flags + sk_tile;
+                    int v_ = 0;
+                    for (int spin = 0; spin < (1 << 16); ++spin) {   // bounded: a lost partner shows as a wrong result, not a hang
+                        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v_) : "v"(fp) : "memory");
+                        if (v_ == sk_want) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                __syncthreads();
+                // the published tail in groups of SKG accumulator quads (16 registers), the next group requested before
+                // the current one is added: counted waits, all of it next to the 128 accumulator registers
+                constexpr int SKG = 4, NGRP = NI * MI / SKG;
+                static_assert(MI % SKG == 0, "stream-K: groups must not straddle accumulator rows");
+                f32x4 part[2][SKG];
+                const float* rp = ws + tid * 4;     // one running pointer, as on the publishing side
+                auto pl = [&](f32x4(&dst)[SKG]) {
+#pragma unroll
+                    for (int j = 0; j < SKG; ++j) {
+                        ld16_sc1(dst[j], rp);
+                        rp += C::THREADS * 4;
+                        asm volatile("" : "+v"(rp));
+                    }
+                };
+                pl(part[0]);
+#pragma unroll
+                for (int gi = 0; gi < NGRP; ++gi) {
+                    if (gi + 1 < NGRP) {
+                        pl(part[(gi + 1) & 1]);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SKG) : "memory");   // all but the SKG loads just issued
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+#pragma unroll
+                    for (int j = 0; j < SKG; ++j) {
+                        asm volatile("" : "+v"(part[gi & 1][j]));     // the value is valid only behind the wait above
+                        acc[(gi * SKG + j) / MI][(gi * SKG + j) % MI] += part[gi & 1][j];
+                    }
+                }
+            }
+            if (!sk_any) break;
+        }
+    }
+
     // ---- the tile whose accumulators are stored now; then (persistent walk) the next tile's first k-tile is requested ----
     const int m0e = m0, n0e = n0;
     bool more = false;
     if constexpr (PERSIST) {
         const int vt_next = vt_cur + (int)gridDim.x;
-        more = vt_next < nwg;
+        more = vt_next < nwg && !sk_on;
         if (more) {
             __syncthreads();          // every wave has read its last fragments: both staging buffers are free
             vt_cur = vt_next;
@@ -1342,8 +1478,33 @@ __global__ __launch_bounds__(C::THREADS, (PIPE == 6 ? 1 : 2)) void gemm_bf16_ker
             else gated_store(std::integral_constant<int, VGPT_ACT_GELU_TANH>{}, KF{});
         }
     }
+    if constexpr (SKC) {
+        if (sk_on) {   // a head (or whole-tile) segment was stored: the next segment of this workgroup, if any
+            if (sk_more) {
+                sk_more = false;
+                __syncthreads();
+                sk_tile = sk_tile2;
+                set_tile(sk_tile, false);
+                kbeg = 0;
+                kend = sk_k2;
+                continue;
+            }
+        }
+    }
     if (!more) break;
     }   // persistent walk
+    if constexpr (SKC) {
+        if (sk_on) {   // the last workgroup to finish opens the next launch's epoch
+            __syncthreads();
+            if (tid == 0) {
+                const int prev = atomicAdd(g.sk_ctl + 1, 1);
+                if (prev == (int)gridDim.x - 1) {
+                    g.sk_ctl[1] = 0;
+                    g.sk_ctl[0] = sk_want;
+                }
+            }
+        }
+    }
 }
 
 // Persistent walk: OFF unless VGPT_GEMM_PERSIST=1.  Measured in round 3 on one box (bench.py, same process order): sampler
@@ -1389,6 +1550,7 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     // persistent walk (kernel: PERSIST): one round of the chip's workgroup slots, each workgroup taking tiles
     // blockIdx.x, + gridDim.x, ...; the slot count is a multiple of 8 (XCD remap).  Off by default (persist_enabled()).
     int grid = g.tiles_m * g.tiles_n;
+    if (PIPE == 7) grid = cu_count();   // stream-K: one workgroup per CU, equal shares of the (tile, k-tile) units
     if ((PIPE == 0 || PIPE == 1) && MODE != MODE_ROPE && persist_enabled()) {
         const int slots = cu_count() * (C::LDS_BYTES > 80 * 1024 ? 1 : 2);
         if (slots % 8 == 0 && grid > slots) grid = slots;
@@ -1518,6 +1680,27 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// Stream-K pays where 256 x 256 tiles leave a good part of the chip idle in the ONE round they need (o_proj and down_proj
+// of a 4096-row sampler step: 192 tiles on 256 CUs) and every workgroup's share still spans at most two tiles.
+bool sk_applies(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = cdiv(M, 256) * cdiv(N, 256), nk = K / BK, cus = cu_count();
+    if (K % BK != 0 || tiles >= cus || tiles * 8 < cus * 5) return false;       // between 5/8 and one round of the chip
+    const int64_t share = tiles * nk / cus;
+    if (share < 8 || share > nk) return false;
+    // every workgroup's share must be the TAIL of one tile and / or the HEAD of the next (the kernel's two roles): no
+    // share may lie strictly inside a tile's reduction (that tile would have three contributors)
+    const int64_t units = tiles * nk;
+    for (int64_t w = 0; w < cus; ++w) {
+        const int64_t u0 = units * w / cus, u1 = units * (w + 1) / cus;
+        if (u1 <= u0) return false;
+        const int64_t t0 = u0 / nk, k0 = u0 % nk;
+        if (u1 > (t0 + 2) * nk) return false;                       // more than two tiles
+        if (k0 > 0 && u1 < (t0 + 1) * nk) return false;             // strictly inside one tile
+    }
+    return true;
+}
+constexpr int64_t SK_CTL_BYTES = 256;   // {epoch, finished workgroups}, padded
+
 }  // namespace
 
 VGPT_EXPORT int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void* extra, int64_t M,
@@ -1539,6 +1722,9 @@ VGPT_EXPORT int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void
     VGPT_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), VGPT_ERR_UNSUPPORTED,
                  "vgpt_gemm_bf16: dimension too large");
     if (M == 0) return VGPT_OK;
+    // a plain product the vendor library is measured ahead on (gemm_lt.hip): enqueued there; everything else, and whatever
+    // the library declines, on the kernels of this file
+    if (vgpt_lt_try_gemm(A, W, C, extra, M, N, K, lda, ldw, ldc, ldr, epilogue, 0, 0, (hipStream_t)stream)) return VGPT_OK;
     GemmArgs g;
     g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = (bf16*)C; g.extra = (const bf16*)extra;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -1573,6 +1759,9 @@ VGPT_EXPORT int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const v
                      (!a_transposed || K * lda < (1ll << 30)),
                  VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_tr: dimension too large (a transposed operand must stay below 2 GiB)");
     if (M == 0) return VGPT_OK;
+    if (vgpt_lt_try_gemm(A, W, C, extra, M, N, K, lda, ldw, ldc, ldr, epilogue, a_transposed ? 1 : 0, w_transposed ? 1 : 0,
+                         (hipStream_t)stream))
+        return VGPT_OK;
     GemmArgs g;
     g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = (bf16*)C; g.extra = (const bf16*)extra;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -1652,4 +1841,46 @@ VGPT_EXPORT int vgpt_gemm_bf16_rope(const void* A, const void* W, void* C, const
     g.tiles_m = g.tiles_n = 0;
     g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_cols = n_rot_heads * head_dim; g.head_dim = head_dim;
     return launch<MODE_ROPE>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_rope");
+}
+
+/* ---- stream-K form of vgpt_gemm_bf16 (see GemmArgs::sk_ws) ---- */
+VGPT_EXPORT int vgpt_gemm_sk_applies(int64_t M, int64_t N, int64_t K) { return M > 0 && N > 0 && K > 0 && sk_applies(M, N, K); }
+
+VGPT_EXPORT int64_t vgpt_gemm_sk_workspace_bytes(int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return -1;
+    const int64_t tiles = cdiv(M, 256) * cdiv(N, 256);
+    // control words | one flag per tile (padded to 256 bytes) | one fp32 256 x 256 partial per tile
+    return SK_CTL_BYTES + (tiles * 4 + 255) / 256 * 256 + tiles * 256 * 256 * 4;
+}
+
+VGPT_EXPORT int vgpt_gemm_bf16_sk(const void* A, const void* W, void* C, const void* extra, int64_t M, int64_t N, int64_t K,
+                                  int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int epilogue, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    VGPT_REQUIRE(A && W && C && workspace, VGPT_ERR_INVALID, "vgpt_gemm_bf16_sk: null pointer");
+    VGPT_REQUIRE(M > 0 && N > 0 && K > 0 && sk_applies(M, N, K), VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_sk: shape %ld x %ld x %ld is not a stream-K case (vgpt_gemm_sk_applies)", (long)M, (long)N, (long)K);
+    VGPT_REQUIRE(epilogue == VGPT_EPI_NONE || epilogue == VGPT_EPI_RESID || epilogue == VGPT_EPI_BIAS, VGPT_ERR_INVALID,
+                 "vgpt_gemm_bf16_sk: unknown epilogue %d", epilogue);
+    VGPT_REQUIRE(epilogue == VGPT_EPI_NONE || extra, VGPT_ERR_INVALID, "vgpt_gemm_bf16_sk: epilogue operand missing");
+    VGPT_REQUIRE(N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && aligned16(A) && aligned16(W) &&
+                     ((uintptr_t)C & 7) == 0 && ((uintptr_t)workspace & 255) == 0,
+                 VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_sk: alignment (rows 16 bytes, workspace 256 bytes)");
+    VGPT_REQUIRE(epilogue != VGPT_EPI_RESID || (ldr % 4 == 0 && ((uintptr_t)extra & 7) == 0), VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_sk: residual must be 8-byte aligned");
+    VGPT_REQUIRE(workspace_bytes >= vgpt_gemm_sk_workspace_bytes(M, N), VGPT_ERR_INVALID,
+                 "vgpt_gemm_bf16_sk: workspace too small (vgpt_gemm_sk_workspace_bytes)");
+    VGPT_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_sk: dimension too large");
+    const int64_t tiles = cdiv(M, 256) * cdiv(N, 256);
+    GemmArgs g;
+    g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = (bf16*)C; g.extra = (const bf16*)extra;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+    g.epi = epilogue; g.act = 0; g.I = 0;
+    g.tiles_m = g.tiles_n = 0;
+    g.rope_cos = g.rope_sin = nullptr; g.rope_cols = g.head_dim = 0;
+    char* ws = (char*)workspace;
+    g.sk_ctl = (int*)ws;
+    g.sk_flags = (int*)(ws + SK_CTL_BYTES);
+    g.sk_ws = (float*)(ws + SK_CTL_BYTES + (tiles * 4 + 255) / 256 * 256);
+    return launch_cfg<MODE_PLAIN, Cfg256, 7>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_sk");
 }
