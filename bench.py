@@ -101,13 +101,15 @@ def calibrate(device, stream, ops, tag):
     return res
 
 
-def pmc_records(kind):
+def pmc_records(kind, vendor=False):
     """Counter evidence of one kernel kind from the committed rocprofv3 --pmc passes of THIS command (separate runs, as
     MI355X_MICROARCH.md prescribes; scripts/pmc_traffic.py / pmc_mfma.py): beyond-L2 bytes per launch and matrix-pipe busy
     fraction, each with the file it came from.  Not measured in this run -- `source` says so."""
     pat = {"gate_up": ("gemm_bf16_kernel<1", "<256"), "qkv_rope": ("gemm_bf16_kernel<2", "<256"),
            "o_proj": ("gemm_bf16_kernel<0", "<256"), "down_proj": ("gemm_bf16_kernel<0", "<256"),
            "attn_fwd": ("attn_fwd_kernel<96", "")}[kind]
+    if vendor:
+        pat = ("Cijk_Alik_Bljk", "")     # hipBLASLt's kernels of the NT products (o_proj and down_proj share one)
     out = {}
     for key, field, stems in (("traffic_bytes_per_launch", "traffic_bytes_per_launch", ("r03_pmc_traffic", "r02_pmc_traffic")),
                               ("mfma_busy", "mfma_busy_frac", ("r03_pmc_mfma", "r02_pmc_mfma"))):
@@ -126,8 +128,8 @@ def pmc_records(kind):
                 out[key + "_source"] = f"profiles/{stem}.json (separate --pmc pass, not this run)"
                 break
     if kind in ("o_proj", "down_proj") and out:
-        out["note"] = ("o_proj and down_proj share one kernel instantiation: the counter figures are their launch-weighted mix "
-                       "(of the HAND-WRITTEN kernel; they do not describe a launch that went to the vendor library)")
+        out["note"] = ("o_proj and down_proj share one kernel: the counter figures are their launch-weighted mix"
+                       + (" (hipBLASLt's kernel, incl. the per-clip pass's launches)" if vendor else ""))
     return out
 
 
@@ -554,9 +556,10 @@ def main():
 
     # ---- roofline: every hot kernel of the step timed live, back to back over the 32 layers on the step's own buffers and
     #      weights (so weights stream from HBM as in the step), one HIP-event pair per kernel KIND on the stream the
-    #      launches go to; agrees with the rocprofv3 --stats averages of the graph run (profiles/).  The dominant kernel is
-    #      gemm_bf16_kernel (its four instantiations are 77 % of the step): `achieved` = the algorithmic FLOPs of all four
-    #      GEMMs of a layer over their summed launch time; `kernels` lists each instantiation and the attention forward. ----
+    #      launches go to; agrees with the rocprofv3 --stats averages of the graph run (profiles/).  The dominant hand-written
+    #      kernel is gemm_bf16_kernel: `achieved` = the algorithmic FLOPs of its launches of a layer over their summed launch
+    #      time (gate_up and qkv + RoPE; o_proj / down_proj too when the vendor library is off); `kernels` lists every GEMM of
+    #      the layer with the implementation that served it, and the attention forward. ----
     roof = None
     if rank == 0:
         nq_, nk_, hd_ = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -670,8 +673,7 @@ def main():
                        "avg_us_isolated_back_to_back": round(iso[name], 1),
                        "alg_gflop_per_launch": round(alg / 1e9, 1), "achieved_tflops": round(alg / us / 1e6, 1),
                        "frac": round(alg / us / 1e6 / PEAK_BF16_TFLOPS, 4), "share_of_step": round(us * nl / (ms_per_step * 1e3), 3)}
-                if not on_vendor.get(name):
-                    rec.update(pmc_records(name))
+                rec.update(pmc_records(name, vendor=bool(on_vendor.get(name))))
                 klist.append(rec)
             timing_note = {"method": "avg_us = inside one real eager denoise forward (a HIP-event pair around every launch of the "
                                      "five kinds, minus the fixed per-pair cost c = (forward with inner pairs - forward without) "
