@@ -1806,6 +1806,13 @@ static int gated_mlp_impl(const void* A, const void* W_gate_up, void* out, void*
     VGPT_REQUIRE(M < (1 << 30) && I < (1 << 29) && K < (1 << 30), VGPT_ERR_UNSUPPORTED,
                  "vgpt_gated_mlp_act_fwd: dimension too large");
     if (M == 0) return VGPT_OK;
+    // training forward (the [gate | up] tensor is stored for the backward): where the library's plain GEMM followed by the
+    // activation kernel is measured ahead of the fused kernel that stores both (gemm_lt.hip, purpose 1), that pair runs --
+    // bit for bit the pair this entry is defined by, up to the library's order of fp32 additions
+    if (gate_up_out && ld_gu == 2 * I && ldo == I && I % 8 == 0 && ((uintptr_t)gate_up_out & 15) == 0 &&
+        vgpt_lt_try_gemm(A, W_gate_up, gate_up_out, nullptr, M, 2 * I, K, lda, ldw, ld_gu, 0, VGPT_EPI_NONE, 0, 0,
+                         (hipStream_t)stream, 1))
+        return vgpt_silu_mul_fwd(gate_up_out, out, M, I, act, stream);
     GemmArgs g;
     g.A = (const bf16*)A; g.W = (const bf16*)W_gate_up; g.C = (bf16*)out; g.extra = nullptr;
     g.M = (int)M; g.N = (int)I; g.K = (int)K;

@@ -120,7 +120,10 @@ bool load_api(Api& a) {
 //   dX = dY W with both widths <= 4096 (o_proj's input gradient): 1.09-1.12
 // and does not take: 9216-wide outputs at 7.7 k rows (0.91-0.95), dW = dY^T X (0.73-0.92 on the wide ones), the input
 // gradients of the wide layers (1.01-1.06: not worth a second code path's rounding), and of course nothing fused.
-bool table_says_vendor(int64_t M, int64_t N, int64_t K, bool a_tr, bool w_tr) {
+//   purpose 1, the training forward's [gate | up] = A W^T that has to be STORED anyway (16384-wide): the library's plain GEMM
+//       + the activation kernel 591 + 59 us at 7740 rows against 722 for the fused kernel that also stores [gate | up]
+bool table_says_vendor(int64_t M, int64_t N, int64_t K, bool a_tr, bool w_tr, int purpose) {
+    if (purpose == 1) return !a_tr && !w_tr && M >= 2048 && N >= 8192 && K >= 1024;
     if (a_tr) return false;
     if (M < 1024 || N < 1024 || N > 4096 || K < 1024) return false;
     return !w_tr || K <= 4096;
@@ -140,12 +143,12 @@ bool capturing(hipStream_t s) {
 // 1: the product was enqueued on the library's kernel; 0: not taken (the caller launches its own kernel).  Never an error:
 // whatever the library cannot or may not do, gemm_bf16.hip can.
 int vgpt_lt_try_gemm(const void* A, const void* W, void* C, const void* extra, int64_t M, int64_t N, int64_t K, int64_t lda,
-                     int64_t ldw, int64_t ldc, int64_t ldr, int epilogue, int a_tr, int w_tr, hipStream_t stream) {
+                     int64_t ldw, int64_t ldc, int64_t ldr, int epilogue, int a_tr, int w_tr, hipStream_t stream, int purpose) {
     State& s = st();
     std::lock_guard<std::mutex> lock(s.mu);
     if (s.mode < 0) s.mode = decide_mode();
     if (s.mode == 0) return 0;
-    if (s.mode == 1 && !table_says_vendor(M, N, K, a_tr, w_tr)) return 0;
+    if (s.mode == 1 && !table_says_vendor(M, N, K, a_tr, w_tr, purpose)) return 0;
     if (M < 16 || N < 16 || K < 16) return 0;
     if (!s.tried) {
         s.tried = true;
@@ -235,7 +238,7 @@ VGPT_EXPORT int vgpt_gemm_vendor_applies(int64_t M, int64_t N, int64_t K, int a_
     std::lock_guard<std::mutex> lock(s.mu);
     if (s.mode < 0) s.mode = decide_mode();
     if (s.mode == 0) return 0;
-    if (s.mode == 1) return table_says_vendor(M, N, K, a_transposed, w_transposed) ? 1 : 0;
+    if (s.mode == 1) return table_says_vendor(M, N, K, a_transposed, w_transposed, 0) ? 1 : 0;
     return M >= 16 && N >= 16 && K >= 16;
 }
 
