@@ -121,7 +121,8 @@ int vgpt_gemm_bf16_sk(const void* A, const void* W, void* C, const void* extra, 
  * they stand -- C = A W^T (+ residual through beta = 1 | + bias), nothing else fused -- AND whose shape is in the table of
  * measured wins (outputs 1024..4096 wide from 1024 rows up, K >= 1024, A not transposed, K <= 4096 if W is: o_proj and
  * down_proj of the 3.8 B decoder, o_proj's input gradient; and the [gate | up] product of vgpt_gated_mlp_act_fwd_keep from
- * 2048 rows up, followed by vgpt_silu_mul_fwd) are enqueued on hipBLASLt's kernel; every other product, every fused one (RoPE, gated activation), and
+ * 2048 rows up, followed by vgpt_silu_mul_fwd; every operand 16-byte aligned with row strides that are multiples of 8
+ * elements) are enqueued on hipBLASLt's kernel; every other product, every fused one (RoPE, gated activation), and
  * anything the library declines runs on the hand-written kernels.  hipBLASLt is bound with dlopen at the first such call (the
  * copy already in the process, else libhipblaslt.so.1 from the library path, or VGPT_HIPBLASLT_PATH); without it nothing
  * changes.  Environment VGPT_GEMM_VENDOR: unset / "auto" = the table, "0" = never, "all" = every plain product (probes).

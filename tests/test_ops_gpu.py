@@ -648,7 +648,7 @@ def _one_ulp(a, b):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(4096, 3072, 3072, "resid"), (4096, 3072, 8192, "resid_inplace"), (1448, 3072, 8192, "resid"),
-                                       (2050, 3072, 1024, "none"), (1030, 2052, 1088, "bias")])
+                                       (2050, 3072, 1024, "none"), (1030, 2056, 1088, "bias")])
 def test_vendor_gemm_is_the_same_product_as_the_hand_written_kernel(ops, M, N, K, epi):
     """vgpt_gemm_bf16 with the product enqueued on hipBLASLt (mode 2: every plain product) and on gemm_bf16_kernel (mode 0):
     both within the single-rounding tolerance of fp64, and within one bf16 ulp of each other on every element (fp32 sums in
@@ -721,6 +721,17 @@ def test_vendor_gemm_strided_operands_and_input_gradient(ops):
     assert outs[2][2] == 2 and outs[0][2] == 0
     assert rel_l2(outs[2][0], ref) < 4e-3 and rel_l2(outs[2][1], ref_dx) < 4e-3
     assert _one_ulp(outs[2][0], outs[0][0]) and _one_ulp(outs[2][1], outs[0][1])
+    # an output that is only 8-byte aligned (a view starting at column 4) is legal for vgpt_gemm_bf16 but not offered to the
+    # library (its kernels move 16 bytes per lane): served by the hand-written kernel, same values
+    with _vendor_mode(2) as lib:
+        c0 = lib.vgpt_gemm_vendor_calls()
+        wide = torch.zeros(M, N + 8, dtype=BF, device=DEV)
+        L_.call("vgpt_gemm_bf16", abuf.data_ptr(), w.data_ptr(), wide.data_ptr() + 8, None, M, N, K, K + 64, K, N + 8, 0,
+                ops.EPI_NONE, ops._stream())
+        torch.cuda.synchronize()
+        assert lib.vgpt_gemm_vendor_calls() == c0
+    assert rel_l2(wide[:, 4:4 + N], abuf[:, :K].double().cpu() @ w.double().cpu().t()) < 4e-3
+    assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + N:].abs().max()) == 0.0
 
 
 def test_vendor_gemm_table_and_capture(ops):

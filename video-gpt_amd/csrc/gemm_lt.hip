@@ -150,6 +150,11 @@ int vgpt_lt_try_gemm(const void* A, const void* W, void* C, const void* extra, i
     if (s.mode == 0) return 0;
     if (s.mode == 1 && !table_says_vendor(M, N, K, a_tr, w_tr, purpose)) return 0;
     if (M < 16 || N < 16 || K < 16) return 0;
+    // the library's kernels move 16 bytes per lane: rows it may not assume aligned stay on the hand-written kernel
+    // (vgpt_gemm_bf16 itself only asks 8-byte alignment of C and of the residual)
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (epilogue == VGPT_EPI_NONE ? 0 : (uintptr_t)extra)) & 15) != 0 ||
+        ((lda | ldw | ldc | (epilogue == VGPT_EPI_RESID ? ldr : 0)) & 7) != 0)
+        return 0;
     if (!s.tried) {
         s.tried = true;
         if (!load_api(s.api)) s.mode = 0;
