@@ -125,7 +125,8 @@ int vgpt_gemm_bf16_sk(const void* A, const void* W, void* C, const void* extra, 
  * elements) are enqueued on hipBLASLt's kernel; every other product, every fused one (RoPE, gated activation), and
  * anything the library declines runs on the hand-written kernels.  hipBLASLt is bound with dlopen at the first such call (the
  * copy already in the process, else libhipblaslt.so.1 from the library path, or VGPT_HIPBLASLT_PATH); without it nothing
- * changes.  Environment VGPT_GEMM_VENDOR: unset / "auto" = the table, "0" = never, "all" = every plain product (probes).
+ * changes.  VGPT_GEMM_VENDOR_TUNE=N (2..16) times the library's first N candidate kernels when a shape is first seen and keeps
+ * the fastest (measured: its first choice already is, for the decoder's shapes).  Environment VGPT_GEMM_VENDOR: unset / "auto" = the table, "0" = never, "all" = every plain product (probes).
  * Same operand and epilogue contract either way; the results differ by the order of the fp32 additions only.  The library's
  * first product on a stream allocates a 128 MiB workspace and must therefore not come inside a stream capture (it is then
  * left to the hand-written kernel).

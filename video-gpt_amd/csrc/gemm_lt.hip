@@ -208,13 +208,59 @@ int vgpt_lt_try_gemm(const void* A, const void* W, void* C, const void* extra, i
         const uint64_t wsmax = WORKSPACE_BYTES;
         ok = ok && s.api.PrefSet(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsmax, sizeof wsmax) == HIPBLAS_STATUS_SUCCESS;
         if (ok) {
-            hipblasLtMatmulHeuristicResult_t res[1];
+            // the library's heuristic ranks its kernels without running them; VGPT_GEMM_VENDOR_TUNE=N (N <= 16) runs its first
+            // N candidates on the caller's operands (output into a scratch buffer) when a shape is first seen OUTSIDE a capture
+            // and keeps the fastest (=2 and up also prints the times).  Off by default: the choice would depend on the box.
+            constexpr int MAXC = 16;
+            static int tune = -1;
+            if (tune < 0) { const char* e = getenv("VGPT_GEMM_VENDOR_TUNE"); tune = e ? atoi(e) : 0; if (tune > MAXC) tune = MAXC; }
+            const int want = (tune > 1 && !cap) ? tune : 1;
+            hipblasLtMatmulHeuristicResult_t res[MAXC];
             int got = 0;
-            ok = s.api.Heuristic(hit->second, p.desc, p.a, p.b, p.c, p.d, pref, 1, res, &got) == HIPBLAS_STATUS_SUCCESS &&
-                 got >= 1 && res[0].state == HIPBLAS_STATUS_SUCCESS && res[0].workspaceSize <= WORKSPACE_BYTES;
+            ok = s.api.Heuristic(hit->second, p.desc, p.a, p.b, p.c, p.d, pref, want, res, &got) == HIPBLAS_STATUS_SUCCESS &&
+                 got >= 1;
+            int best = -1;
+            for (int i = 0; ok && i < got && best < 0; ++i)
+                if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= WORKSPACE_BYTES) best = i;
+            ok = ok && best >= 0;
+            if (ok && want > 1 && got > 1) {
+                void* scratch = nullptr;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (hipMalloc(&scratch, (size_t)M * (size_t)ldc * 2) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+                    hipEventCreate(&e1) == hipSuccess) {
+                    const float one = 1.0f, zero = 0.0f;
+                    const bool resid = epilogue == VGPT_EPI_RESID;
+                    float best_ms = 1e30f;
+                    for (int i = 0; i < got; ++i) {
+                        if (res[i].state != HIPBLAS_STATUS_SUCCESS || res[i].workspaceSize > WORKSPACE_BYTES) continue;
+                        bool fine = true;
+                        for (int rep = 0; rep < 5 && fine; ++rep) {   // 2 untimed, 3 timed
+                            if (rep == 2) (void)hipEventRecord(e0, stream);
+                            fine = s.api.Matmul(hit->second, p.desc, &one, W, p.a, A, p.b, resid ? &one : &zero,
+                                                resid ? extra : scratch, p.c, scratch, p.d, &res[i].algo, wit->second,
+                                                WORKSPACE_BYTES, stream) == HIPBLAS_STATUS_SUCCESS;
+                        }
+                        (void)hipEventRecord(e1, stream);
+                        (void)hipEventSynchronize(e1);
+                        float ms = 0.f;
+                        if (!fine || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+                        if (tune >= 3)
+                            fprintf(stderr, "[vgpt gemm_lt] %ld x %ld x %ld epi %d tr %d%d: candidate %d %.1f us\n", (long)M, (long)N,
+                                    (long)K, epilogue, a_tr, w_tr, i, ms / 3 * 1e3);
+                        if (ms < best_ms) { best_ms = ms; best = i; }
+                    }
+                    if (tune >= 2)
+                        fprintf(stderr, "[vgpt gemm_lt] %ld x %ld x %ld epi %d tr %d%d: candidate %d of %d kept (%.1f us)\n", (long)M,
+                                (long)N, (long)K, epilogue, a_tr, w_tr, best, got, best_ms / 3 * 1e3);
+                }
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+                if (scratch) (void)hipFree(scratch);
+                (void)hipGetLastError();
+            }
             if (ok) {
-                p.algo = res[0].algo;
-                p.ws = res[0].workspaceSize;
+                p.algo = res[best].algo;
+                p.ws = res[best].workspaceSize;
             }
         }
         p.ok = ok;    // a refused problem is remembered too: it goes to the hand-written kernel from now on
