@@ -272,10 +272,13 @@ __global__ __launch_bounds__(C::THREADS, (PIPE == 6 ? 1 : 2)) void gemm_bf16_ker
         const int tn = (bid % in_group) / gsz;
         m0 = tm * BM;
         n0 = tn * (MODE == MODE_GATED ? BN / 2 : BN);
-        a_org = reinterpret_cast<const char*>(ATR ? g.A + m0 : g.A + (int64_t)m0 * g.lda);
-        if constexpr (WTR) w_org = reinterpret_cast<const char*>(g.W + n0);
+        // diagnostics bit 64 (results are garbage): every workgroup reads the operands of tile (0, 0) -- an L2-resident operand
+        // stream under the product's instruction stream, to tell memory latency under load from issue / clock limits
+        const int m0l = (kDebug & 64) ? 0 : m0, n0l = (kDebug & 64) ? 0 : n0;
+        a_org = reinterpret_cast<const char*>(ATR ? g.A + m0l : g.A + (int64_t)m0l * g.lda);
+        if constexpr (WTR) w_org = reinterpret_cast<const char*>(g.W + n0l);
         else if constexpr (MODE == MODE_GATED || ROPE) w_org = reinterpret_cast<const char*>(g.W);
-        else w_org = reinterpret_cast<const char*>(g.W + (int64_t)n0 * g.ldw);
+        else w_org = reinterpret_cast<const char*>(g.W + (int64_t)n0l * g.ldw);
 #pragma unroll
         for (int i = 0; i < C::A_SLABS; ++i) {
             if constexpr (ATR) {
