@@ -8,7 +8,7 @@
 //
 // No link-time dependency: the library is looked up with dlopen when the first such product arrives -- the copy already in the
 // process if there is one (PyTorch ships its own next to its HIP runtime, and two hipBLASLt builds in one process are one
-// too many), else the ROCm installation's -- and only seven C entry points are bound.  If it is absent, disabled
+// too many), else the ROCm installation's -- and only nine C entry points are bound.  If it is absent, disabled
 // (VGPT_GEMM_VENDOR=0) or refuses a problem, the caller launches the hand-written kernel: same operands, same epilogue.
 #include "common.h"
 
@@ -31,6 +31,7 @@ struct Api {
     hipblasStatus_t (*DescSet)(hipblasLtMatmulDesc_t, hipblasLtMatmulDescAttributes_t, const void*, size_t) = nullptr;
     hipblasStatus_t (*PrefCreate)(hipblasLtMatmulPreference_t*) = nullptr;
     hipblasStatus_t (*PrefSet)(hipblasLtMatmulPreference_t, hipblasLtMatmulPreferenceAttributes_t, const void*, size_t) = nullptr;
+    hipblasStatus_t (*PrefDestroy)(const hipblasLtMatmulPreference_t) = nullptr;   // optional: a missing symbol leaks a few bytes per shape
     hipblasStatus_t (*Heuristic)(hipblasLtHandle_t, hipblasLtMatmulDesc_t, hipblasLtMatrixLayout_t, hipblasLtMatrixLayout_t,
                                  hipblasLtMatrixLayout_t, hipblasLtMatrixLayout_t, hipblasLtMatmulPreference_t, int,
                                  hipblasLtMatmulHeuristicResult_t*, int*) = nullptr;
@@ -109,6 +110,7 @@ bool load_api(Api& a) {
         snprintf(a.origin, sizeof a.origin, "hipBLASLt found but an entry point is missing");
         return false;
     }
+    (void)bind(so, a.PrefDestroy, "hipblasLtMatmulPreferenceDestroy");
     a.so = so;
     return true;
 }
@@ -263,6 +265,7 @@ int vgpt_lt_try_gemm(const void* A, const void* W, void* C, const void* extra, i
                 p.ws = res[best].workspaceSize;
             }
         }
+        if (pref && s.api.PrefDestroy) (void)s.api.PrefDestroy(pref);
         p.ok = ok;    // a refused problem is remembered too: it goes to the hand-written kernel from now on
         pit = s.plans.emplace(key, p).first;
     }
