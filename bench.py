@@ -336,7 +336,10 @@ def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=No
     x1, x0, clean, x0i = mk(nd), mk(nd), mk(nc), mk(nc)
     t = torch.rand(nd, generator=g).to(device)
     ti = (0.9 + 0.1 * torch.rand(nc, generator=g)).to(device)
-    trainer = TR.Stage1Trainer(model, lr=1e-4, weight_decay=0.1, max_grad_norm=1.0, gradient_checkpointing=grad_ckpt)
+    # the update of step k runs on its own stream under the forward of step k + 1 (Stage1Trainer.overlap_optimizer); the timed
+    # region's closing device-wide synchronize includes the last update
+    trainer = TR.Stage1Trainer(model, lr=1e-4, weight_decay=0.1, max_grad_norm=1.0, gradient_checkpointing=grad_ckpt,
+                               overlap_optimizer=os.environ.get("VGPT_OPT_OVERLAP", "1") == "1")
     for _ in range(warmup):
         loss = trainer.step(batch, x1, x0, t, clean, x0i, ti)
     losses = []

@@ -255,6 +255,39 @@ def test_gradient_checkpointing_gives_bit_identical_gradients():
             assert rel_l2(out[True][1][k], v) < 1e-5, k
 
 
+def test_optimizer_overlapped_with_the_next_forward_is_the_same_training_run():
+    """Stage1Trainer(overlap_optimizer=True): the AdamW launches of step k go to a stream of their own behind the clip
+    coefficient and the forward of step k + 1 waits, layer by layer, for the event of the parameters it is about to read --
+    same kernels on the same data in the same order per tensor, so four chained steps give the same losses, parameters and
+    optimizer state (with gradient checkpointing too: the recomputed layers wait on the same events)."""
+    cfg = R.TINY
+    p, batch, x1, x0, t, clean, x0i, ti = _stage1_case(cfg)
+    TR = importlib.import_module("video-gpt_amd.train")
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    for ck in (False, True):
+        out = {}
+        for ov in (False, True):
+            model = SC.build_product_model(cfg, p, DEV, cls_name="LVMTraining")
+            if ck:
+                model.llm.gradient_checkpointing_enable()
+            tr = TR.Stage1Trainer(model, lr=1e-3, weight_decay=0.1, max_grad_norm=0.5, overlap_optimizer=ov)
+            assert tr.overlap_optimizer == ov
+            losses = [tr.step(dbatch, x1 * (1 + 0.1 * i), x0, t, clean, x0i, ti).clone() for i in range(4)]
+            tr.finish_optimizer()
+            torch.cuda.synchronize()
+            out[ov] = (torch.stack(losses), [m_.clone() for m_ in tr.master_layers] + [tr.master_small.clone()],
+                       [v_.clone() for v_ in tr.v_layers], {k: v.detach().clone() for k, v in model.state_dict().items()})
+        # the gradient norm and the small fp32 gradients are summed with atomics (their order varies from run to run, with or
+        # without the overlap), so the clip coefficient moves in its last bits: equality to fp32 rounding, where a forward
+        # that read a parameter before its update would be off by the size of an update (lr = 1e-3)
+        assert rel_l2(out[True][0], out[False][0]) < 1e-5
+        for a_, b_ in zip(out[False][1] + out[False][2], out[True][1] + out[True][2]):
+            assert rel_l2(b_, a_) < 2e-6
+        for k, v in out[False][3].items():
+            if v.dtype.is_floating_point:
+                assert rel_l2(out[True][3][k], v) < 1e-4, k      # bf16 parameters: a flipped last bit here and there
+
+
 def test_constant_with_warmup_schedule():
     """diffusers get_scheduler("constant_with_warmup") (train_x1_stage1_noiseinput.py:279-283): optimizer step k runs at
     lr * min(1, k / warmup) -- the very first step at lr 0, so it leaves the weights unchanged."""

@@ -37,7 +37,8 @@ class Stage1Trainer:
     def __init__(self, model, lr: float = 1e-4, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: Optional[float] = 1.0, input_noise: float = 0.9, pack_padding: bool = True,
                  lr_scheduler: str = "constant", lr_warmup_steps: int = 0, gradient_checkpointing: Optional[bool] = None,
-                 forward_only: bool = False, lr_scheduler_steps_per_optimizer_step: int = 1):
+                 forward_only: bool = False, lr_scheduler_steps_per_optimizer_step: int = 1,
+                 overlap_optimizer: bool = False):
         """lr_scheduler / lr_warmup_steps: diffusers' get_scheduler("constant" | "constant_with_warmup")
         (train_x1_stage1_noiseinput.py:279-283; the scripts use constant_with_warmup): the k-th optimizer step (k = 0, 1,
         ...) runs at lr * min(1, k * lr_scheduler_steps_per_optimizer_step / warmup).
@@ -71,6 +72,11 @@ class Stage1Trainer:
         self.input_noise = input_noise
         self.pack_padding = pack_padding
         self.dev = model.llm.norm.weight.device
+        # AdamW behind the clip coefficient on a stream of its own (see optimizer_step): events of the update of the small
+        # bucket and of every layer bucket, waited for where the next forward first reads those parameters
+        self.overlap_optimizer = bool(overlap_optimizer) and self.dev.type == "cuda" and not forward_only
+        self._opt_stream = torch.cuda.Stream(device=self.dev) if self.overlap_optimizer else None
+        self._opt_events = None      # (small, [layer 0 .. nl-1]) of the update in flight
         self.step_count = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.skip_allreduce = False   # measurement only (bench.py's exposed-communication leg): ranks stop agreeing when set
@@ -136,6 +142,7 @@ class Stage1Trainer:
         self.param_small = flat
         self.sumsq = torch.zeros(1, dtype=F32, device=self.dev)
         self.coef = torch.ones(1, dtype=F32, device=self.dev)
+
         self.grad_norm = torch.zeros(1, dtype=F32, device=self.dev)
 
     @classmethod
@@ -194,6 +201,9 @@ class Stage1Trainer:
         clean/x0_in/t_in: the clean-frame latents and their noise (loss.py:166-192).  Returns the per-frame losses."""
         m, cfg = self.model, self.cfg
         prep = self._prepare(batch)
+        pending = self._opt_events           # the previous step's update may still be running on its own stream
+        if pending is not None:
+            torch.cuda.current_stream().wait_event(pending[0])      # embeddings, heads, final norm: read from the start
         B, L, M, H, I = prep["B"], prep["L"], prep["B"] * prep["L"], cfg.hidden_size, cfg.intermediate_size
         nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         nl = cfg.num_hidden_layers
@@ -234,6 +244,8 @@ class Stage1Trainer:
         def layer_forward(li, with_output=True):
             layer = m.llm.layers[li]
             at, mlp, k = layer.self_attn, layer.mlp, sv(li)
+            if pending is not None:
+                torch.cuda.current_stream().wait_event(pending[1][li])   # this layer's parameters are updated
             ops.rmsnorm(hbuf[li], layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=n1[k])
             ops.linear_qkv_rope(n1[k], at.qkv_proj.weight, prep["rope"][0], prep["rope"][1], nq, nk, hd, out=qkv[k])
             T.attention_qkv_train(qkv[k].view(B, L, -1), prep["pm"], nq, nk, hd, ctx[k].view(B, L, -1), lse[k])
@@ -372,11 +384,41 @@ class Stage1Trainer:
         # norm of the AVERAGED gradient = norm(sum)/world; coefficient already carries the 1/world factor
         T.clip_coef(self.sumsq, self.coef, self.grad_norm, (self.max_grad_norm or 0.0) * w, 1.0 / w)
         b1, b2 = self.betas
-        for i in range(len(self.layer_buckets)):
-            T.adamw_step(self.master_layers[i], self.param_layers[i], self.layer_buckets[i], self.m_layers[i],
-                         self.v_layers[i], lr, b1, b2, self.eps, self.wd, self.step_count, self.coef)
-        T.adamw_step(self.master_small, self.param_small, self.small_bucket, self.m_small, self.v_small, lr, b1, b2,
-                     self.eps, self.wd, self.step_count, self.coef)
+        if not self.overlap_optimizer:
+            for i in range(len(self.layer_buckets)):
+                T.adamw_step(self.master_layers[i], self.param_layers[i], self.layer_buckets[i], self.m_layers[i],
+                             self.v_layers[i], lr, b1, b2, self.eps, self.wd, self.step_count, self.coef)
+            T.adamw_step(self.master_small, self.param_small, self.small_bucket, self.m_small, self.v_small, lr, b1, b2,
+                         self.eps, self.wd, self.step_count, self.coef)
+            return
+        # The update is a pure HBM stream (28 bytes per parameter) and the next step's forward is matrix work: they run side by
+        # side.  Everything below goes to the optimizer's stream behind the clip coefficient; the small bucket (embeddings,
+        # heads: read first) and then the layers in forward order, each followed by an event the next forward waits for right
+        # where it first reads that layer.  Readers outside step() call finish_optimizer() first.
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._opt_stream.wait_event(ready)
+        with torch.cuda.stream(self._opt_stream):
+            T.adamw_step(self.master_small, self.param_small, self.small_bucket, self.m_small, self.v_small, lr, b1, b2,
+                         self.eps, self.wd, self.step_count, self.coef)
+            ev_small = torch.cuda.Event()
+            ev_small.record(self._opt_stream)
+            evs = []
+            for i in range(len(self.layer_buckets)):
+                T.adamw_step(self.master_layers[i], self.param_layers[i], self.layer_buckets[i], self.m_layers[i],
+                             self.v_layers[i], lr, b1, b2, self.eps, self.wd, self.step_count, self.coef)
+                e = torch.cuda.Event()
+                e.record(self._opt_stream)
+                evs.append(e)
+        self._opt_events = (ev_small, evs)
+
+    def finish_optimizer(self):
+        """With overlap_optimizer: makes the current stream wait for the update in flight (call before reading parameters or
+        optimizer state outside step(): checkpoints, evaluation, the end of a timed region)."""
+        if self._opt_events is not None:
+            torch.cuda.current_stream().wait_event(self._opt_events[1][-1])
+            self._opt_events = None
 
 
     # ---- checkpoints (LVM/train/train_x1_stage1_noiseinput.py:304-334,437-451: accelerate's checkpoint-{step}
@@ -385,6 +427,7 @@ class Stage1Trainer:
     #      LVM.from_pretrained), optimizer.safetensors the fp32 master weights and Adam moments per bucket. ----
     def save_checkpoint(self, results_dir: str, global_step: Optional[int] = None) -> str:
         """Rank 0 writes (replicas are identical under data parallelism); every rank returns after the files exist."""
+        self.finish_optimizer()
         import json
         import os
         from safetensors.torch import save_file
@@ -413,6 +456,7 @@ class Stage1Trainer:
         Only checkpoints written by this trainer resume (the reference's are accelerate / DeepSpeed `save_state`
         directories, whose optimizer shards are pickles: warm-start from those through LVM.from_pretrained's weight
         loaders instead)."""
+        self.finish_optimizer()
         import json
         import os
         from safetensors.torch import load_file
