@@ -55,7 +55,9 @@
 // (`sc0 sc1`: the line is not kept dirty in the XCD's L2), to see what the write-back of a GEMM's dirty output lines costs
 // at the kernel boundary behind it (MI355X_MICROARCH.md, price list row `boundary`: + B / 6 TB/s for B dirty bytes).
 // Measured in round 3: 35.3 ms per sampler step against 32.0 (o_proj 97 vs 72 us, qkv 242 vs 205): the consumer kernel
-// finds its input in neither L2 nor -- apparently -- as readily in the Infinity Cache; the plain stores stay.
+// finds its input in neither L2 nor -- apparently -- as readily in the Infinity Cache; the plain stores stay.  VAL=2 (`nt`,
+// non-temporal) is worse still: gate_up 366 vs 326 us, qkv + RoPE 303 vs 201 us, 35.2 vs 30.8 ms per step -- the epilogue's
+// stores are 8 bytes per lane and it is the write-back L2 that merges them into whole lines.
 // Also measured and removed (round 3): software prefetch into the XCD's L2 -- wave 0 / 1 of every workgroup touching one dword
 // per 128-byte line of a 1/4 (A) / 1/8 (W) slice of the k-pieces three k-tiles ahead, so that the first of the 4 / 8
 // workgroups of an XCD that want a piece no longer misses L2 (12 of 64 piece fetches per k-tile do: the 16-19 % beyond-L2
@@ -68,10 +70,14 @@
 namespace {
 
 __device__ __forceinline__ void store_out4(bf16* p, bf16x4 v) {
-#if VGPT_GEMM_STORE_WT
+#if VGPT_GEMM_STORE_WT == 1
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     const u32x2_t d = __builtin_bit_cast(u32x2_t, v);
     asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+#elif VGPT_GEMM_STORE_WT == 2   // non-temporal: the output streams through the L2 instead of displacing the operand panels
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t d = __builtin_bit_cast(u32x2_t, v);
+    asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
 #else
     *reinterpret_cast<bf16x4*>(p) = v;
 #endif
