@@ -101,15 +101,13 @@ def calibrate(device, stream, ops, tag):
     return res
 
 
-def pmc_records(kind, vendor=False):
+def pmc_records(kind):
     """Counter evidence of one kernel kind from the committed rocprofv3 --pmc passes of THIS command (separate runs, as
     MI355X_MICROARCH.md prescribes; scripts/pmc_traffic.py / pmc_mfma.py): beyond-L2 bytes per launch and matrix-pipe busy
     fraction, each with the file it came from.  Not measured in this run -- `source` says so."""
     pat = {"gate_up": ("gemm_bf16_kernel<1", "<256"), "qkv_rope": ("gemm_bf16_kernel<2", "<256"),
            "o_proj": ("gemm_bf16_kernel<0", "<256"), "down_proj": ("gemm_bf16_kernel<0", "<256"),
            "attn_fwd": ("attn_fwd_kernel<96", "")}[kind]
-    if vendor:
-        pat = ("Cijk_Alik_Bljk", "")     # hipBLASLt's kernels of the NT products (o_proj and down_proj share one)
     out = {}
     for key, field, stems in (("traffic_bytes_per_launch", "traffic_bytes_per_launch", ("r03_pmc_traffic", "r02_pmc_traffic")),
                               ("mfma_busy", "mfma_busy_frac", ("r03_pmc_mfma", "r02_pmc_mfma"))):
@@ -128,8 +126,7 @@ def pmc_records(kind, vendor=False):
                 out[key + "_source"] = f"profiles/{stem}.json (separate --pmc pass, not this run)"
                 break
     if kind in ("o_proj", "down_proj") and out:
-        out["note"] = ("o_proj and down_proj share one kernel: the counter figures are their launch-weighted mix"
-                       + (" (hipBLASLt's kernel, incl. the per-clip pass's launches)" if vendor else ""))
+        out["note"] = "o_proj and down_proj share one kernel: the counter figures are their launch-weighted mix"
     return out
 
 
@@ -413,6 +410,18 @@ def measure_stage1(steps, warmup, layers, rank, world, device, M, P, D, model=No
     return line
 
 
+def self_launch_argv(argv, n_gpus, port=None):
+    """The command a bare `python bench.py --gpus N ...` (N > 1, no WORLD_SIZE in the environment) re-launches itself with:
+    N ranks of this same file with the same flags under torch.distributed.run on 127.0.0.1 (the driver's own launch line)."""
+    if port is None:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -449,9 +458,15 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # a bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run, the
+        # launch of LVM/script/train/pretrain_stage1_nv.sh:15-49) as a CHILD process, before anything here touches the GPU,
+        # and leave with its exit code
+        import subprocess
+        raise SystemExit(subprocess.call(self_launch_argv(sys.argv[1:], args.gpus)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     if args.rehearse_on_one_gpu:   # every rank on cuda:0, gloo collectives: exercises the N > 1 code path on a 1-GPU box
@@ -641,9 +656,7 @@ def main():
                 e1.record(stream)
                 stream.synchronize()
                 return s1.elapsed_time(e1) * 1e3
-            vc0 = L_.load().vgpt_gemm_vendor_calls()
             one_forward()
-            vendor_calls_in_step = L_.load().vgpt_gemm_vendor_calls() - vc0
             t_b = min(one_forward() for _ in range(3))
             try:
                 ops.linear = wrap(saved["linear"], lin_kind)
@@ -663,20 +676,14 @@ def main():
             c_us = (t_a - t_b) / max(n_pairs, 1)
             layer_us = t_b / nl
             klist = []
-            lib_ = L_.load()
-            on_vendor = {"o_proj": bool(lib_.vgpt_gemm_vendor_applies(rows, H, nq_ * hd_, 0, 0)) and vendor_calls_in_step > 0,
-                         "down_proj": bool(lib_.vgpt_gemm_vendor_applies(rows, H, I, 0, 0)) and vendor_calls_in_step > 0}
             for name, kname, alg, fn in kinds:
                 us = m_us[name] - c_us
-                if on_vendor.get(name):
-                    kname = ("hipBLASLt (vendor library behind vgpt_gemm_bf16, csrc/gemm_lt.hip: plain GEMM, residual through "
-                             "beta = 1) -- " + name + " + residual")
-                rec = {"name": name, "kernel": kname, "implementation": "vendor library" if on_vendor.get(name) else "hand-written HIP",
+                rec = {"name": name, "kernel": kname, "implementation": "hand-written HIP",
                        "launches_per_step": nl, "avg_us": round(us, 1),
                        "avg_us_isolated_back_to_back": round(iso[name], 1),
                        "alg_gflop_per_launch": round(alg / 1e9, 1), "achieved_tflops": round(alg / us / 1e6, 1),
                        "frac": round(alg / us / 1e6 / PEAK_BF16_TFLOPS, 4), "share_of_step": round(us * nl / (ms_per_step * 1e3), 3)}
-                rec.update(pmc_records(name, vendor=bool(on_vendor.get(name))))
+                rec.update(pmc_records(name))
                 klist.append(rec)
             timing_note = {"method": "avg_us = inside one real eager denoise forward (a HIP-event pair around every launch of the "
                                      "five kinds, minus the fixed per-pair cost c = (forward with inner pairs - forward without) "
@@ -684,8 +691,35 @@ def main():
                                      "the MFMA-dense kinds)",
                            "event_pair_cost_us": round(c_us, 2), "pairs": n_pairs,
                            "eager_forward_us_per_layer": round(layer_us, 1)}
-        # the dominant HAND-WRITTEN kernel: gemm_bf16_kernel (with o_proj / down_proj on the vendor library: its gate_up and
-        # qkv + RoPE instantiations, 64 launches and over half of the step; without the library all four)
+        # a yardstick from OUTSIDE the product, timed beside it and never part of `value`: torch.addmm / torch.matmul (hipBLASLt
+        # through PyTorch) on the plain products of a layer, 32 launches back to back over the layers' own weights, to be read
+        # against `avg_us_isolated_back_to_back` of the hand-written kernels (same launch pattern)
+        vendor_yard = None
+        try:
+            with torch.cuda.stream(stream):
+                yard = {}
+                res_ = eng.hid[:rows]
+                prods = (("o_proj", eng.ctx[:rows], lambda l: l.self_attn.o_proj.weight, True),
+                         ("down_proj", eng.act[:rows], lambda l: l.mlp.down_proj.weight, True),
+                         ("qkv_proj_plain_gemm_only", eng.nrm[:rows], lambda l: l.self_attn.qkv_proj.weight, False),
+                         ("gate_up_plain_gemm_only", eng.nrm[:rows], lambda l: l.mlp.gate_up_proj.weight, False))
+                for name, x_, wf_, with_res in prods:
+                    f_ = (lambda w_: torch.addmm(res_, x_, w_.t())) if with_res else (lambda w_: torch.matmul(x_, w_.t()))
+                    for l in model.llm.layers[:2]:
+                        f_(wf_(l))
+                    s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s_.record(stream)
+                    for l in model.llm.layers:
+                        f_(wf_(l))
+                    e_.record(stream)
+                    stream.synchronize()
+                    yard[name] = round(s_.elapsed_time(e_) / nl * 1e3, 1)
+            vendor_yard = {"what": "torch.addmm / torch.matmul (hipBLASLt inside PyTorch) on the same operands, 32 launches back to "
+                                   "back; compare with kernels[].avg_us_isolated_back_to_back; not part of the product or of `value`",
+                           "avg_us_isolated_back_to_back": yard}
+        except Exception as ex:   # the yardstick must never break the benchmark line
+            vendor_yard = {"error": repr(ex)[:200]}
+        # the dominant HAND-WRITTEN kernel: gemm_bf16_kernel, all four GEMM instantiations of a decoder layer
         gem = [k for k in klist if k["name"] != "attn_fwd" and k["implementation"] == "hand-written HIP"]
         t_gemm = sum(k["avg_us"] for k in gem) * 1e-6 * nl
         alg = sum(k["alg_gflop_per_launch"] for k in gem) * 1e9 * nl
@@ -700,10 +734,11 @@ def main():
                 "traffic_source": gem[0].get("traffic_bytes_per_launch_source"),
                 "launches": n_launch, "avg_launch_us": round(t_gemm / n_launch * 1e6, 1),
                 "alg_flops_per_launch": alg / n_launch,
-                "gemm_vendor": {"origin": L_.load().vgpt_gemm_vendor_origin().decode(),
-                                "products_per_step": int(vendor_calls_in_step),
-                                "what": "o_proj and down_proj (GEMM + residual, nothing fused) go to hipBLASLt where its kernel is "
-                                        "measured ahead (csrc/gemm_lt.hip); VGPT_GEMM_VENDOR=0 runs them on gemm_bf16_kernel"},
+                "gemm_vendor": {"products_per_step": 0,
+                                "what": "no vendor library is linked, loaded or called by libvgpt_hip.so: every product of the step "
+                                        "runs on the hand-written kernels (round 3's hipBLASLt bridge is gone from the product; "
+                                        "csrc/experiments/gemm_lt.hip keeps its source)"},
+                "vendor_yardstick": vendor_yard,
                 "peak_note": "2500 = nominal dense bf16 peak (MI355X_MICROARCH.md); calibration.mfma_loop_tflops is what "
                              "nothing-but-MFMA loops on random operands sustain on THIS box in this run",
                 "kernels": klist, "kernel_timing": timing_note,

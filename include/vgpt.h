@@ -103,44 +103,6 @@ int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const void* extra, 
                       int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int epilogue, int a_transposed,
                       int w_transposed, void* stream);
 
-/* Stream-K form of vgpt_gemm_bf16 for problems whose 256 x 256 output tiles number between 5/8 of the CUs and the CUs (o_proj
- * and down_proj of a 4096-row sampler step: 192 tiles on 256 CUs, which a tile-per-workgroup launch runs as ONE round of 0.75
- * of the chip, or as 256 narrower tiles whose k-step is no shorter).  One workgroup per CU takes an equal share of the
- * (tile, k-tile) units: the tail of one tile's reduction -- published as fp32 partial sums through `workspace` -- and the head
- * of the next, which it completes with that tile's published tail.  Same epilogues as vgpt_gemm_bf16; the result differs from
- * it by the order of ONE fp32 addition per element (deterministic).  workspace: vgpt_gemm_sk_workspace_bytes(M, N) bytes,
- * 256-byte aligned, ZEROED ONCE by the caller before its first use and then left alone (it carries a launch counter); it may
- * be shared by all stream-K calls of one stream.  vgpt_gemm_sk_applies tells whether a shape is such a case. */
-int vgpt_gemm_sk_applies(int64_t M, int64_t N, int64_t K);
-int64_t vgpt_gemm_sk_workspace_bytes(int64_t M, int64_t N);
-int vgpt_gemm_bf16_sk(const void* A, const void* W, void* C, const void* extra, int64_t M, int64_t N, int64_t K,
-                      int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int epilogue, void* workspace,
-                      int64_t workspace_bytes, void* stream);
-
-/* The vendor GEMM library behind vgpt_gemm_bf16 / vgpt_gemm_bf16_tr (csrc/gemm_lt.hip).  Products that are library GEMMs as
- * they stand -- C = A W^T (+ residual through beta = 1 | + bias), nothing else fused -- AND whose shape is in the table of
- * measured wins (outputs 1024..4096 wide from 1024 rows up, K >= 1024, A not transposed, K <= 4096 if W is: o_proj and
- * down_proj of the 3.8 B decoder, o_proj's input gradient; and the [gate | up] product of vgpt_gated_mlp_act_fwd_keep from
- * 2048 rows up, followed by vgpt_silu_mul_fwd; every operand 16-byte aligned with row strides that are multiples of 8
- * elements) are enqueued on hipBLASLt's kernel; every other product, every fused one (RoPE, gated activation), and
- * anything the library declines runs on the hand-written kernels.  hipBLASLt is bound with dlopen at the first such call (the
- * copy already in the process, else libhipblaslt.so.1 from the library path, or VGPT_HIPBLASLT_PATH); without it nothing
- * changes.  VGPT_GEMM_VENDOR_TUNE=N (2..16) times the library's first N candidate kernels when a shape is first seen and keeps
- * the fastest (measured: its first choice already is, for the decoder's shapes).  Environment VGPT_GEMM_VENDOR: unset / "auto" = the table, "0" = never, "all" = every plain product (probes).
- * Same operand and epilogue contract either way; the results differ by the order of the fp32 additions only.  The library's
- * first product on a stream allocates a 128 MiB workspace and must therefore not come inside a stream capture (it is then
- * left to the hand-written kernel).
- *   vgpt_gemm_vendor_applies: 1 if such a product would be offered to the library under the current mode
- *   vgpt_gemm_vendor_ready:   1 if the library has served `stream` on the current device before (a capture on it may use it)
- *   vgpt_gemm_vendor_calls:   products enqueued on the library so far in this process
- *   vgpt_gemm_vendor_origin:  where the library was found, or why it is not in use (static string)
- *   vgpt_gemm_vendor_set_mode: 0 off, 1 table, 2 all; returns the previous mode */
-int vgpt_gemm_vendor_applies(int64_t M, int64_t N, int64_t K, int a_transposed, int w_transposed);
-int vgpt_gemm_vendor_ready(void* stream);
-int64_t vgpt_gemm_vendor_calls(void);
-const char* vgpt_gemm_vendor_origin(void);
-int vgpt_gemm_vendor_set_mode(int mode);
-
 /* Phi3MLP first half, fused: out[M,I] = act(A Wg^T) * (A Wu^T) where
  * W_gate_up (2I, K) = [Wg ; Wu] as stored by Phi3MLP.gate_up_proj.
  * K % 64 == 0, I % 64 == 0. */

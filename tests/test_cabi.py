@@ -77,27 +77,3 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
-
-
-def test_vendor_gemm_table_is_decided_on_the_host(lib):
-    """csrc/gemm_lt.hip: which products vgpt_gemm_bf16 offers to the vendor library is a host-side table (no GPU, no library
-    needed to ask): o_proj / down_proj shapes and o_proj's input gradient, nothing wide, nothing with a transposed A; mode 0
-    offers nothing, mode 2 every plain product; the query never loads hipBLASLt."""
-    cdll = lib.load()
-    prev = cdll.vgpt_gemm_vendor_set_mode(1)
-    try:
-        yes = [(4096, 3072, 3072, 0, 0), (4096, 3072, 8192, 0, 0), (1448, 3072, 8192, 0, 0), (7740, 3072, 3072, 0, 0),
-               (7740, 3072, 3072, 0, 1)]
-        no = [(4096, 9216, 3072, 0, 0), (4096, 16384, 3072, 0, 0), (516, 3072, 3072, 0, 0), (4096, 3072, 512, 0, 0),
-              (3072, 3072, 7680, 1, 1), (7740, 8192, 3072, 0, 1), (7740, 3072, 16384, 0, 1)]
-        assert all(cdll.vgpt_gemm_vendor_applies(*a) == 1 for a in yes)
-        assert all(cdll.vgpt_gemm_vendor_applies(*a) == 0 for a in no)
-        assert cdll.vgpt_gemm_vendor_set_mode(0) == 1
-        assert all(cdll.vgpt_gemm_vendor_applies(*a) == 0 for a in yes)
-        assert cdll.vgpt_gemm_vendor_set_mode(2) == 0
-        assert all(cdll.vgpt_gemm_vendor_applies(*a) == 1 for a in yes + no)
-        assert cdll.vgpt_gemm_vendor_set_mode(7) == 2 and cdll.vgpt_gemm_vendor_set_mode(1) == 2   # an unknown mode changes nothing
-        assert cdll.vgpt_gemm_vendor_calls() == 0 and cdll.vgpt_gemm_vendor_ready(None) == 0
-        assert cdll.vgpt_gemm_vendor_origin() == b"not loaded"
-    finally:
-        cdll.vgpt_gemm_vendor_set_mode(prev)

@@ -124,3 +124,39 @@ def test_bf16_gradient_sum_over_8_ranks_stays_within_bf16_rounding():
     assert max(rels) < 6e-3, rels                          # ~ sqrt(7) x 2^-9 / sqrt(3) = 3e-3 expected
     assert max(r[2] for r in res) < 1e-2
     assert len({r[3] for r in res}) == 1                   # all ranks agree bit for bit
+
+
+def test_bench_launches_its_own_ranks_for_gpus_n():
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE): the parent builds the driver's own launch line -- N ranks of
+    bench.py with the same flags under torch.distributed.run on 127.0.0.1 -- and runs it as a child before touching the GPU
+    (LVM/script/train/pretrain_stage1_nv.sh:15-49 launches its ranks the same way); here: the argv it builds, and that a
+    child started with it really runs N ranks of the file it is given."""
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        bench = importlib.import_module("bench")
+    finally:
+        sys.path.remove(root)
+    argv = bench.self_launch_argv(["--gpus", "2", "--steps", "3", "--workload", "stage1"], 2, port=29711)
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=2" in argv and "--nnodes=1" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29711"
+    i = argv.index(os.path.join(root, "bench.py"))
+    assert argv[i + 1:] == ["--gpus", "2", "--steps", "3", "--workload", "stage1"]
+    free = bench.self_launch_argv([], 2)
+    assert 1024 < int(free[free.index("--master-port") + 1]) < 65536
+    # the same launcher line on a stand-in script: two ranks start, each sees WORLD_SIZE=2 and its flags
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "probe.py")
+        with open(script, "w") as f:
+            f.write("import os, sys\nopen(os.path.join(sys.argv[2], 'r' + os.environ['RANK']), 'w').write("
+                    "os.environ['WORLD_SIZE'] + ' ' + sys.argv[1])\n")
+        cmd = list(free)
+        cmd[cmd.index(os.path.join(root, "bench.py"))] = script
+        rc = subprocess.call(cmd + ["--flag", d], timeout=300)
+        assert rc == 0
+        assert sorted(os.listdir(d)) == ["probe.py", "r0", "r1"]
+        assert open(os.path.join(d, "r1")).read() == "2 --flag"

@@ -580,194 +580,3 @@ def test_hip_graph_replay(ops):
     assert rel_l2(y, R.rmsnorm(x.cpu().float(), w.cpu().float(), 1e-5)) < 4e-3
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(4096, 3072, 3072, "resid"), (4096, 3072, 8192, "resid"), (4096, 3072, 3072, "none"),
-                                       (4000, 3000, 1024, "bias")])
-def test_linear_stream_k_matches_the_tile_per_workgroup_launch(ops, M, N, K, epi):
-    """Stream-K launches (vgpt_gemm_bf16_sk: fewer 256 x 256 tiles than CUs, every workgroup an equal share of the k-tiles,
-    partial sums handed from workgroup to workgroup through a workspace) against fp64 and against the plain launch: same
-    values up to the order of one fp32 addition per element (a stale or torn partial would be off by far more than the one
-    bf16 ulp allowed on a few elements), over repeated launches on the SAME workspace with CHANGING operands."""
-    import importlib
-    L_ = importlib.import_module("video-gpt_amd._lib")
-    assert L_.load().vgpt_gemm_sk_applies(M, N, K)
-    saved = ops._SK_ON
-    vendor_before = L_.load().vgpt_gemm_vendor_set_mode(0)      # the yardstick is the hand-written tile-per-workgroup launch
-    try:
-        for it in range(6):
-            a = torch.randn(M, K, generator=g(200 + it)).to(DEV, BF)
-            w = (torch.randn(N, K, generator=g(300 + it)) * 0.05).to(DEV, BF)
-            kw = {}
-            if epi == "resid":
-                kw["residual"] = torch.randn(M, N, generator=g(400 + it)).to(DEV, BF)
-            if epi == "bias":
-                kw["bias"] = torch.randn(N, generator=g(500 + it)).to(DEV, BF)
-            ops._SK_ON = True
-            y_sk = ops.linear(a, w, **kw)
-            ops._SK_ON = False
-            y_pl = ops.linear(a, w, **kw)
-            d = (y_sk.float() - y_pl.float()).abs()
-            # one bf16 ulp of the larger value; near zero the two fp32 sums differ by their own rounding (~1e-6 at |y| ~ 5)
-            tol = torch.maximum(y_pl.float().abs(), y_sk.float().abs()) * 2.0 ** -7 + 3e-5
-            assert bool((d <= tol).all()), (it, float(d.max()))
-            assert float((d > 0).float().mean()) < 0.02                    # and only where the fp32 sum sat on a rounding edge
-            if it == 0:
-                ref = a.double().cpu() @ w.double().cpu().t()
-                if epi == "resid":
-                    ref = ref + kw["residual"].double().cpu()
-                if epi == "bias":
-                    ref = ref + kw["bias"].double().cpu()
-                assert rel_l2(y_sk, ref) < 4e-3
-    finally:
-        ops._SK_ON = saved
-        L_.load().vgpt_gemm_vendor_set_mode(vendor_before)
-
-
-# ---- the vendor library behind vgpt_gemm_bf16 (csrc/gemm_lt.hip) -------------------------------------------------------------
-
-def _vendor_lib():
-    import importlib
-    return importlib.import_module("video-gpt_amd._lib").load()
-
-
-class _vendor_mode:
-    def __init__(self, mode):
-        self.mode = mode
-
-    def __enter__(self):
-        self.prev = _vendor_lib().vgpt_gemm_vendor_set_mode(self.mode)
-        return _vendor_lib()
-
-    def __exit__(self, *exc):
-        _vendor_lib().vgpt_gemm_vendor_set_mode(self.prev)
-
-
-def _one_ulp(a, b):
-    """|a - b| within one bf16 ulp of the larger value (+ the fp32 sums' own rounding near zero)."""
-    a, b = a.float(), b.float()
-    return bool(((a - b).abs() <= torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + 3e-5).all())
-
-
-@pytest.mark.parametrize("M,N,K,epi", [(4096, 3072, 3072, "resid"), (4096, 3072, 8192, "resid_inplace"), (1448, 3072, 8192, "resid"),
-                                       (2050, 3072, 1024, "none"), (1030, 2056, 1088, "bias")])
-def test_vendor_gemm_is_the_same_product_as_the_hand_written_kernel(ops, M, N, K, epi):
-    """vgpt_gemm_bf16 with the product enqueued on hipBLASLt (mode 2: every plain product) and on gemm_bf16_kernel (mode 0):
-    both within the single-rounding tolerance of fp64, and within one bf16 ulp of each other on every element (fp32 sums in
-    another order).  `resid_inplace`: the residual IS the output buffer (o_proj / down_proj in the engine)."""
-    a = torch.randn(M, K, generator=g(700 + K)).to(DEV, BF)
-    w = (torch.randn(N, K, generator=g(701 + N)) * 0.05).to(DEV, BF)
-    r = torch.randn(M, N, generator=g(702 + M)).to(DEV, BF)
-    b = torch.randn(N, generator=g(703)).to(DEV, BF)
-    ref = a.double().cpu() @ w.double().cpu().t()
-    if epi.startswith("resid"):
-        ref = ref + r.double().cpu()
-    if epi == "bias":
-        ref = ref + b.double().cpu()
-
-    def run():
-        if epi == "resid":
-            return ops.linear(a, w, residual=r)
-        if epi == "resid_inplace":
-            buf = r.clone()
-            return ops.linear(a, w, residual=buf, out=buf)
-        if epi == "bias":
-            return ops.linear(a, w, bias=b)
-        return ops.linear(a, w)
-    with _vendor_mode(2) as lib:
-        c0 = lib.vgpt_gemm_vendor_calls()
-        y_v = run()
-        torch.cuda.synchronize()
-        took = lib.vgpt_gemm_vendor_calls() - c0
-        origin = lib.vgpt_gemm_vendor_origin().decode()
-    if took == 0:
-        pytest.skip(f"hipBLASLt not in use on this box ({origin}): the hand-written kernel served the call")
-    with _vendor_mode(0) as lib:
-        c0 = lib.vgpt_gemm_vendor_calls()
-        y_h = run()
-        torch.cuda.synchronize()
-        assert lib.vgpt_gemm_vendor_calls() == c0
-    assert rel_l2(y_v, ref) < 4e-3 and rel_l2(y_h, ref) < 4e-3
-    assert _one_ulp(y_v, y_h)
-    assert float((y_v != y_h).float().mean()) < 0.02
-
-
-def test_vendor_gemm_strided_operands_and_input_gradient(ops):
-    """Row strides wider than the rows (slices of wider buffers: the engine's qkv / ctx views) and the transposed-W form
-    dX = dY W (vgpt_gemm_bf16_tr), each against the hand-written kernel and fp64."""
-    import importlib
-    L_ = importlib.import_module("video-gpt_amd._lib")
-    M, N, K = 2048, 3072, 3072
-    abuf = torch.randn(M, K + 64, generator=g(710)).to(DEV, BF)
-    cbuf = torch.zeros(M, N + 64, dtype=BF, device=DEV)
-    rbuf = torch.randn(M, N + 64, generator=g(711)).to(DEV, BF)
-    w = (torch.randn(N, K, generator=g(712)) * 0.05).to(DEV, BF)
-    wt = w.t().contiguous()                                   # (K, N): the layer's weight as dX = dY W reads it
-    ref = abuf[:, :K].double().cpu() @ w.double().cpu().t() + rbuf[:, :N].double().cpu()
-    ref_dx = abuf[:, :K].double().cpu() @ wt.double().cpu()    # (M, K) x (K, N)
-    outs = {}
-    for mode in (2, 0):
-        with _vendor_mode(mode) as lib:
-            c0 = lib.vgpt_gemm_vendor_calls()
-            cbuf.zero_()
-            L_.call("vgpt_gemm_bf16", abuf.data_ptr(), w.data_ptr(), cbuf.data_ptr(), rbuf.data_ptr(), M, N, K, K + 64, K, N + 64,
-                    N + 64, ops.EPI_RESID, ops._stream())
-            dx = torch.empty(M, N, dtype=BF, device=DEV)
-            L_.call("vgpt_gemm_bf16_tr", abuf.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, M, N, K, K + 64, N, N, 0, ops.EPI_NONE,
-                    0, 1, ops._stream())
-            torch.cuda.synchronize()
-            outs[mode] = (cbuf[:, :N].clone(), dx, lib.vgpt_gemm_vendor_calls() - c0)
-            assert float(cbuf[:, N:].abs().max()) == 0.0            # nothing written past the row's N columns
-    if outs[2][2] == 0:
-        pytest.skip("hipBLASLt not in use on this box")
-    assert outs[2][2] == 2 and outs[0][2] == 0
-    assert rel_l2(outs[2][0], ref) < 4e-3 and rel_l2(outs[2][1], ref_dx) < 4e-3
-    assert _one_ulp(outs[2][0], outs[0][0]) and _one_ulp(outs[2][1], outs[0][1])
-    # an output that is only 8-byte aligned (a view starting at column 4) is legal for vgpt_gemm_bf16 but not offered to the
-    # library (its kernels move 16 bytes per lane): served by the hand-written kernel, same values
-    with _vendor_mode(2) as lib:
-        c0 = lib.vgpt_gemm_vendor_calls()
-        wide = torch.zeros(M, N + 8, dtype=BF, device=DEV)
-        L_.call("vgpt_gemm_bf16", abuf.data_ptr(), w.data_ptr(), wide.data_ptr() + 8, None, M, N, K, K + 64, K, N + 8, 0,
-                ops.EPI_NONE, ops._stream())
-        torch.cuda.synchronize()
-        assert lib.vgpt_gemm_vendor_calls() == c0
-    assert rel_l2(wide[:, 4:4 + N], abuf[:, :K].double().cpu() @ w.double().cpu().t()) < 4e-3
-    assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + N:].abs().max()) == 0.0
-
-
-def test_vendor_gemm_table_and_capture(ops):
-    """The table of the default mode names o_proj / down_proj shapes only; and a product whose stream the library has not
-    served yet is NOT handed to it inside a capture (its workspace cannot be allocated there): the hand-written kernel is
-    recorded instead and the replayed result is right."""
-    lib = _vendor_lib()
-    with _vendor_mode(1):
-        assert lib.vgpt_gemm_vendor_applies(4096, 3072, 3072, 0, 0) == 1 and lib.vgpt_gemm_vendor_applies(4096, 3072, 8192, 0, 0) == 1
-        assert lib.vgpt_gemm_vendor_applies(1448, 3072, 8192, 0, 0) == 1 and lib.vgpt_gemm_vendor_applies(4096, 3072, 3072, 0, 1) == 1
-        assert lib.vgpt_gemm_vendor_applies(4096, 9216, 3072, 0, 0) == 0 and lib.vgpt_gemm_vendor_applies(4096, 16384, 3072, 0, 0) == 0
-        assert lib.vgpt_gemm_vendor_applies(516, 3072, 3072, 0, 0) == 0 and lib.vgpt_gemm_vendor_applies(3072, 3072, 4096, 1, 1) == 0
-        assert lib.vgpt_gemm_vendor_applies(4096, 8192, 3072, 0, 1) == 0 and lib.vgpt_gemm_vendor_applies(4096, 256, 256, 0, 0) == 0
-    with _vendor_mode(0):
-        assert lib.vgpt_gemm_vendor_applies(4096, 3072, 3072, 0, 0) == 0
-    M, N, K = 1024, 1024, 1024
-    a = torch.randn(M, K, generator=g(720)).to(DEV, BF)
-    w = (torch.randn(N, K, generator=g(721)) * 0.05).to(DEV, BF)
-    y = torch.zeros(M, N, dtype=BF, device=DEV)
-    s = None
-    for _ in range(40):               # torch hands out pooled streams: look for one the library has not served yet
-        cand = torch.cuda.Stream()
-        if not lib.vgpt_gemm_vendor_ready(cand.cuda_stream):
-            s = cand
-            break
-    if s is None:
-        pytest.skip("every pooled stream has been served by the library already")
-    with _vendor_mode(0), torch.cuda.stream(s):
-        ops.linear(a, w, out=y)       # first launch of the hand-written instantiation outside the capture (it sets attributes)
-    torch.cuda.synchronize()
-    y.zero_()
-    with _vendor_mode(2):
-        c0 = lib.vgpt_gemm_vendor_calls()
-        with torch.cuda.stream(s):
-            graph = ops.HipGraph().capture(lambda: ops.linear(a, w, out=y))
-            assert lib.vgpt_gemm_vendor_calls() == c0
-            graph.replay()
-        s.synchronize()
-    assert rel_l2(y, a.double().cpu() @ w.double().cpu().t()) < 4e-3

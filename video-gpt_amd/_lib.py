@@ -34,14 +34,6 @@ SIGNATURES = {
     "vgpt_gemm_bf16": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
     "vgpt_gemm_bf16_rope": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_int, _P]),
     "vgpt_gemm_bf16_tr": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_int, c_int, _P]),
-    "vgpt_gemm_sk_applies": (c_int, [_I64, _I64, _I64]),
-    "vgpt_gemm_sk_workspace_bytes": (_I64, [_I64, _I64]),
-    "vgpt_gemm_bf16_sk": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P, _I64, _P]),
-    "vgpt_gemm_vendor_applies": (c_int, [_I64, _I64, _I64, c_int, c_int]),
-    "vgpt_gemm_vendor_ready": (c_int, [_P]),
-    "vgpt_gemm_vendor_calls": (_I64, []),
-    "vgpt_gemm_vendor_origin": (ctypes.c_char_p, []),
-    "vgpt_gemm_vendor_set_mode": (c_int, [c_int]),
     "vgpt_gated_mlp_act_fwd": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
     "vgpt_gated_mlp_act_fwd_keep": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
     "vgpt_mask_pack_bool": (c_int, [_P, _P, _I64, _I64, _P]),

@@ -19,13 +19,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 void vgpt_set_error(const char* fmt, ...);
 
-// gemm_lt.hip: 1 when the product C = A W^T (+ epilogue) was enqueued on the vendor library's kernel, 0 when the caller is to
-// launch its own (library absent / disabled / shape not in its table / problem refused)
-int vgpt_lt_try_gemm(const void* A, const void* W, void* C, const void* extra, int64_t M, int64_t N, int64_t K, int64_t lda,
-                     int64_t ldw, int64_t ldc, int64_t ldr, int epilogue, int a_tr, int w_tr, hipStream_t stream, int purpose = 0);
-// purpose: 0 = a plain product of the caller's, 1 = the [gate | up] product of the TRAINING forward (the caller runs the
-// activation as a second kernel if the library takes it)
-
 #define VGPT_REQUIRE(cond, code, ...)  \
     do {                               \
         if (!(cond)) {                 \

@@ -27,10 +27,26 @@
 #ifndef VGPT_GEMM_SETPRIO
 #define VGPT_GEMM_SETPRIO 0
 #endif
+// 1: the big-tile NT launches use the two-group ("ping-pong") loop (PIPE == 2 below) instead of the 4-phase loop.
+// EXPERIMENT, not compiled into the product (make gemm-variant-VGPT_GEMM_PP): parity-green, and with the LDS-DMA left out
+// 8 % faster than the 4-phase loop without its DMA (61.6 vs 67.5 us for 4096 x 3072 x 3072), but 20-25 % SLOWER with it
+// (97 vs 79 us; 230 vs 194 at K = 8192; 372 vs 330 for gate_up) wherever the issues are placed and with or without the
+// counted waits: an LDS-DMA issue blocks its wave for 60-185 cycles, and under strict alternation nobody fills the matrix
+// pipe meanwhile -- the free-running 4-phase loop lets the partner wave's MFMAs cover it.
+#ifndef VGPT_GEMM_PP
+#define VGPT_GEMM_PP 0
+#endif
 // Diagnostics build (make gemm-debug-N, results are garbage): 1 = skip the LDS-DMA staging, 2 = skip the LDS fragment
 // reads, 3 = both, 4 = skip the epilogue, 16 = no wait for the LDS-DMA (what the per-tile drain costs).  A COMPILE-time switch: as a run-time flag the skipped reads became conditional, and at the join
 // hipcc's s_waitcnt insertion assumes the shorter path — every MFMA phase then waited for the fragment reads issued
 // right in front of it (lgkmcnt(3..0) instead of (7..4)), exposing the LDS latency twice per k-tile.
+// EXPERIMENT, not compiled into the product (make gemm-variant-VGPT_GEMM_RS [VAL=2]): operand tiles fetched into registers
+// (global_load_dwordx4) and written to LDS with ds_write_b128 instead of LDS-DMA -- PIPE == 3 in the 4-phase loop, with
+// VAL=2 also PIPE == 4, the ping-pong schedule on 256 x 256 tiles.  Parity-green; within +-3 % of the LDS-DMA loop
+// (PIPE 3) and 9 % behind it (PIPE 4), DESIGN.md section 4.
+#ifndef VGPT_GEMM_RS
+#define VGPT_GEMM_RS 0
+#endif
 #ifndef VGPT_GEMM_DEBUG_BUILD
 #define VGPT_GEMM_DEBUG_BUILD 0
 #endif
@@ -126,8 +142,24 @@ struct GemmArgs {
     // the plain GEMM followed by vgpt_silu_mul_fwd produces; null: inference (activation from the fp32 accumulators)
     bf16* gu_out = nullptr;
     int64_t ld_gu = 0;
+    // stream-K (vgpt_gemm_bf16_sk; MODE_PLAIN NT on 256 x 256 tiles, fewer tiles than CUs): the launch has one workgroup per
+    // CU and every workgroup takes an equal share of the (tile, k-tile) units -- at most the TAIL of one tile's reduction,
+    // whose fp32 partial sums it publishes in sk_ws[tile] (write-through stores, then a flag), followed by the HEAD of the
+    // next tile, which it completes with that tile's published tail and stores.  sk_ctl = {epoch, finished workgroups}.
+    float* sk_ws = nullptr;
+    int* sk_flags = nullptr;
+    int* sk_ctl = nullptr;
 };
 
+// write-through store / L1-bypassing load of 16 bytes: the hand-off of stream-K partial sums between workgroups
+// (MI355X_MICROARCH.md, inter-workgroup visibility: every byte stored `sc1`, every load of it `sc1`, the flag behind a
+// vmcnt(0) of every storing wave and a workgroup barrier)
+__device__ __forceinline__ void st16_wt(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ld16_sc1(f32x4& v, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+}
 
 __device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -194,7 +226,7 @@ constexpr bool getenv_prio = VGPT_GEMM_SETPRIO;
 // 32-byte units of a row are XOR-swizzled with ((row>>3)&1)<<2 | (row&3) (on the DMA source address and on the
 // read) so that the 8 rows x 32 B a half-wave reads transposed hit 64 different banks.
 template <int MODE, typename C, int PIPE, bool ATR = false, bool WTR = false>
-__global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
+__global__ __launch_bounds__(C::THREADS, (PIPE == 6 ? 1 : 2)) void gemm_bf16_kernel(GemmArgs g) {
     static_assert(!(ATR || WTR) || MODE == MODE_PLAIN, "transposed operands: plain kernel only");
     constexpr bool ROPE = MODE == MODE_ROPE;
     constexpr int BM = C::BM, BN = C::BN, MI = C::MI, NI = C::NI;
@@ -347,7 +379,44 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     // rows through the same LDS, nor for the experimental loops.
     constexpr bool PERSIST = (PIPE == 0 || PIPE == 1) && !ROPE;
     bool prefetched = false;
-    const int kbeg = 0, kend = nk;
+    int kbeg = 0, kend = nk;     // k-tiles of the current tile this workgroup multiplies (stream-K: a part of them)
+    // ---- stream-K segments of this workgroup ----
+    constexpr bool SKC = PIPE == 7 && MODE == MODE_PLAIN && !ATR && !WTR && BN == 256;   // PIPE 7 = the 4-phase loop + stream-K
+    // the current segment's tile (sk_tile), the workgroup's second segment if it has one (tile sk_tile2, k-tiles [0, sk_k2)),
+    // all wave-uniform scalars: a private ARRAY indexed by the segment number would make the tile origin -- and with it every
+    // staging address -- a per-lane value (16 more registers in the k-loop, spilled)
+    [[maybe_unused]] int sk_tile = 0, sk_tile2 = 0, sk_k2 = 0, sk_want = 0;
+    [[maybe_unused]] bool sk_any = true, sk_more = false;
+    [[maybe_unused]] const bool sk_on = SKC && g.sk_ws != nullptr;
+    if constexpr (SKC) {
+        if (sk_on) {
+            // workgroups of one XCD (blockIdx.x % 8) take neighbouring unit ranges: the same remap as the tile order
+            int w = blockIdx.x;
+            {
+                const int n_ = (int)gridDim.x, xcd = w & 7, q = n_ >> 3, r = n_ & 7;
+                w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+            }
+            const int64_t units = (int64_t)nwg * nk;
+            const int64_t u0 = units * w / gridDim.x, u1 = units * (w + 1) / gridDim.x;
+            sk_tile = (int)(u0 / nk);
+            kbeg = (int)(u0 % nk);
+            kend = (int)min((int64_t)nk, kbeg + (u1 - u0));
+            sk_any = u1 > u0;
+            if (u1 > (int64_t)(sk_tile + 1) * nk) {
+                sk_more = true;
+                sk_tile2 = sk_tile + 1;
+                sk_k2 = (int)(u1 - (int64_t)sk_tile2 * nk);
+            }
+            sk_tile = __builtin_amdgcn_readfirstlane(sk_tile);
+            sk_tile2 = __builtin_amdgcn_readfirstlane(sk_tile2);
+            sk_k2 = __builtin_amdgcn_readfirstlane(sk_k2);
+            kbeg = __builtin_amdgcn_readfirstlane(kbeg);
+            kend = __builtin_amdgcn_readfirstlane(kend);
+            sk_want = __builtin_amdgcn_readfirstlane(g.sk_ctl[0]) + 1;   // the flag value of THIS launch (bumped by the last workgroup to finish)
+            if (sk_any) set_tile(sk_tile, false);
+            else kbeg = kend = 0;
+        }
+    }
     for (;;) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -384,6 +453,124 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
             }
         }
+    } else if constexpr (PIPE == 6) {
+        // One wave per SIMD, wave tile 128 x 128: a k-tile is 16 STEPS of 8 MFMAs (step s: W sub-tile s & 7 of k-step s >> 3
+        // against the eight A sub-tiles).  Operands go global -> registers -> LDS (same swizzled images as the LDS-DMA
+        // loops); every step carries, between its MFMAs, one piece of the staging pipeline and its share of the fragment
+        // stream:
+        //   steps 0..12 : piece p of tile kt+1 (fetched one whole iteration ago: counted vmcnt) -> LDS buffer buf^1, then
+        //                 the same piece of tile kt+2 fetched into the same registers (16 pieces over 13 steps);
+        //   every step  : the W fragment of step s+3 into a ring of four; k-step 0's steps also the A fragment s of
+        //                 k-step 1;
+        //   behind step 12: lgkmcnt(0) + s_barrier -- tile kt+1 complete in buf^1, nobody reads buf any more except through
+        //                 fragments already requested;
+        //   steps 13..15: the eight A fragments of tile kt+1's k-step 0 (and, through the ring, its first W fragments).
+        static_assert(MI == 8 && NI == 8 && !ATR && !WTR, "fragment-streaming loop: 2x2 waves of 128 x 128, NT operands");
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int NP = C::A_SLABS + C::W_SLABS;   // 16 pieces of 1 KiB per wave and k-tile
+        static_assert(NP == 16, "16 staging pieces per wave");
+        u32x4 R[NP];
+        bf16x8 A0[MI], A1[MI], Wr[4];
+        const int lane16 = lane * 16;
+        const int last = nk - 1;
+        auto gl = [&](u32x4& dst, const char* base, uint32_t voff) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base));
+        };
+        auto gload1 = [&](auto pc, int kt) {
+            constexpr int p = decltype(pc)::value;
+            if constexpr (p < C::A_SLABS) gl(R[p], a_org + (int64_t)kt * a_step, a_off[p]);
+            else gl(R[p], w_org + (int64_t)kt * w_step, w_off[p - C::A_SLABS]);
+        };
+        auto lwrite1 = [&](auto pc, int buf) {
+            constexpr int p = decltype(pc)::value;
+            if constexpr (p < C::A_SLABS)
+                *reinterpret_cast<u32x4*>(sA + buf * C::A_BYTES + (wave * C::A_SLABS + p) * 1024 + lane16) = R[p];
+            else
+                *reinterpret_cast<u32x4*>(sW + buf * C::W_BYTES + C::w_slab(wave, p - C::A_SLABS) * 1024 + lane16) = R[p];
+        };
+        auto ldWf = [&](bf16x8& dst, int buf, int ks, int i) {
+            dst = *reinterpret_cast<const bf16x8*>(sW + buf * C::W_BYTES + w_base + ((ks * 4 + fk) ^ sw) * 16 + i * 2048);
+        };
+        auto ldAf = [&](bf16x8& dst, int buf, int ks, int j) {
+            dst = *reinterpret_cast<const bf16x8*>(sA + buf * C::A_BYTES + a_base + ((ks * 4 + fk) ^ sw) * 16 + j * 2048);
+        };
+        auto mm2 = [&](const bf16x8& wf, const bf16x8(&af)[MI], auto ic, auto j0) {
+            constexpr int i = decltype(ic)::value, j = decltype(j0)::value;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[j], acc[i][j], 0, 0, 0);
+            acc[i][j + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[j + 1], acc[i][j + 1], 0, 0, 0);
+        };
+        // one step; `kt` is the tile being multiplied (buffer buf = kt & 1)
+        auto step = [&](auto sc, int buf, int kt) {
+            constexpr int S = decltype(sc)::value, KS = S >> 3, I = S & 7, SLOT = S & 3;
+            using IC = std::integral_constant<int, I>;
+            const bf16x8(&af)[MI] = KS == 0 ? A0 : A1;
+            // pieces of the staging pipeline carried by this step: steps 0..2 two each, steps 3..12 one each
+            constexpr int P0 = S < 3 ? 2 * S : (S < 13 ? S + 3 : -1);
+            constexpr int PN = S < 3 ? 2 : (S < 13 ? 1 : 0);
+            mm2(Wr[SLOT], af, IC{}, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PN > 0) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP - PN) : "memory");   // the PN oldest of the 16 fetches in flight
+                lwrite1(std::integral_constant<int, P0>{}, buf ^ 1);
+                if constexpr (PN > 1) lwrite1(std::integral_constant<int, P0 + 1>{}, buf ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm2(Wr[SLOT], af, IC{}, std::integral_constant<int, 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PN > 0) {
+                gload1(std::integral_constant<int, P0>{}, min(kt + 2, last));
+                if constexpr (PN > 1) gload1(std::integral_constant<int, P0 + 1>{}, min(kt + 2, last));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm2(Wr[SLOT], af, IC{}, std::integral_constant<int, 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+            // W fragment of step S + 3 (this tile, or the next one's first steps: behind the barrier of step 12)
+            if constexpr (S + 3 < 16) ldWf(Wr[(S + 3) & 3], buf, (S + 3) >> 3, (S + 3) & 7);
+            else ldWf(Wr[(S + 3) & 3], buf ^ 1, 0, (S + 3) & 7);
+            // A fragments: k-step 1 of this tile during k-step 0; the next tile's k-step 0 during steps 13..15
+            if constexpr (KS == 0) ldAf(A1[I], buf, 1, I);
+            if constexpr (S == 13) { ldAf(A0[0], buf ^ 1, 0, 0); ldAf(A0[1], buf ^ 1, 0, 1); ldAf(A0[2], buf ^ 1, 0, 2); }
+            if constexpr (S == 14) { ldAf(A0[3], buf ^ 1, 0, 3); ldAf(A0[4], buf ^ 1, 0, 4); ldAf(A0[5], buf ^ 1, 0, 5); }
+            if constexpr (S == 15) { ldAf(A0[6], buf ^ 1, 0, 6); ldAf(A0[7], buf ^ 1, 0, 7); }
+            __builtin_amdgcn_sched_barrier(0);
+            mm2(Wr[SLOT], af, IC{}, std::integral_constant<int, 6>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (S == 12) {   // tile kt+1 is in buf^1 (every wave's 16 pieces) and buf is read no more
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        };
+        // prologue: tile 0 through the registers into buffer 0, tile 1 fetched, first fragments
+        {
+#define VGPT_P16(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+#define VGPT_GL0(p) gload1(std::integral_constant<int, p>{}, 0);
+#define VGPT_LW0(p) lwrite1(std::integral_constant<int, p>{}, 0);
+#define VGPT_GL1(p) gload1(std::integral_constant<int, p>{}, min(1, last));
+            VGPT_P16(VGPT_GL0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            VGPT_P16(VGPT_LW0)
+            VGPT_P16(VGPT_GL1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < MI; ++j) ldAf(A0[j], 0, 0, j);
+            ldWf(Wr[0], 0, 0, 0);
+            ldWf(Wr[1], 0, 0, 1);
+            ldWf(Wr[2], 0, 0, 2);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+#define VGPT_STEP(sidx) step(std::integral_constant<int, sidx>{}, buf, kt);
+            VGPT_P16(VGPT_STEP)
+#undef VGPT_STEP
+        }
+#undef VGPT_GL0
+#undef VGPT_LW0
+#undef VGPT_GL1
+#undef VGPT_P16
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated fetches behind the last tile
     } else if constexpr (PIPE == 5) {
         // 4x2-wave tiles of 64 x 144 (256 x 288): six phases of 12 MFMAs per k-tile -- (ks, third of the wave's nine n
         // sub-tiles) -- with the W fragments of phase p+1 (three reads) and the A fragments of the other k-step (four) in
@@ -453,6 +640,339 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                 ldA4(Af2[0], buf ^ 1, 0);
             }
             mma3(Wt[1], Af2[1], T2{});
+        }
+    } else if constexpr (PIPE == 2 || PIPE == 4) {
+        constexpr bool RS = PIPE == 4;   // register-staged operands (see PIPE == 3) in the ping-pong schedule
+        // Two wave groups in alternation ("ping-pong"): the four waves of tile row 0 and the four of tile row 1 sit one
+        // per SIMD each; while one group runs a cluster of 16 (or 8) MFMAs at raised priority the other reads fragments
+        // from LDS and issues LDS-DMA, and every hand-over is a workgroup barrier (group 1 runs one barrier behind).
+        // A k-tile is four phases = the four quadrants of the wave tile, (m0,n0) (m0,n1) (m1,n1) (m1,n0), each over the
+        // whole K = 64.  The tile lives in LDS as four 16-KiB half-tile images that die one per phase -- W.n0 after the
+        // fragment reads of phase 4 of the tile before (its fragments wait in registers), A.m0 after phase 1, W.n1 after
+        // phase 2, A.m1 after phase 3 -- and each is re-staged with the data of two tiles ahead three phases after its
+        // last read, five to six phases before its first: W.n1(t+1) in phase 1, A.m1(t+1) in 2, W.n0(t+2) in 3,
+        // A.m0(t+2) in 4.  Every phase issues exactly two LDS-DMA instructions (dummies into a scratch area where the
+        // schedule has nothing to fetch), so `s_waitcnt vmcnt(6)` at the end of a phase's load part always means "all
+        // but the last three half-tiles have landed" -- what the NEXT phase reads -- and nothing ever drains.
+        static_assert(!ATR && !WTR && MI == 8 && (NI == 4 || NI == 3), "ping-pong loop: NT operands, 2x4-wave tiles");
+        constexpr int HT = 16384;
+        constexpr int STRIDE = C::A_BYTES + C::W_BYTES;
+        constexpr int AM0 = 0, AM1 = HT, WN0 = 2 * HT, WN1 = 3 * HT;
+        const uint32_t scratch = lds_base + 2 * STRIDE + wave * 2048;
+        auto a_row_off = [&](int r_local) {
+            const int r = min(r_local, g.M - 1 - m0);
+            return (uint32_t)(r * (int)g.lda + schunk * 8) * 2u;
+        };
+        auto w_row_off = [&](int r) {
+            int wr;
+            if constexpr (ROPE) wr = min(rope_col_of_slot(n0 + r, g.rope_cols, g.head_dim), n_rows_w - 1);
+            else wr = min(w_row_of_slot<MODE>(n0, r, g.I), n_rows_w - 1) - (MODE == MODE_GATED ? 0 : n0);
+            return (uint32_t)(wr * (int)g.ldw + schunk * 8) * 2u;
+        };
+        // this wave stages pieces `wave` and `wave + 8` (8 rows x 128 B each) of every half-tile
+        uint32_t oA[2][2], oW0[2], oW1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int lr = (wave + 8 * u) * 8 + srow;   // row inside the 128-row half-tile image
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) oA[mh][u] = a_row_off((lr >> 6) * 128 + mh * 64 + (lr & 63));
+            oW0[u] = w_row_off((lr >> 5) * (NI * 16) + (lr & 31));
+            if constexpr (NI == 4) oW1[u] = w_row_off((lr >> 5) * 64 + 32 + (lr & 31));
+            else oW1[u] = u == 0 ? w_row_off((lr >> 4) * 48 + 32 + (lr & 15)) : 0u;   // 64-row image: pieces 0..7 only
+        }
+        auto dummy = [&]() {
+            if constexpr ((kDebug & 1) == 0) glds16_asm(a_org, oA[0][0], scratch);
+        };
+        // RS: every staging site (image, u) owns one register quad; a site writes the piece it fetched one tile earlier and
+        // fetches the piece of the following tile (tile indices clamped to the last: the surplus writes hit dead images),
+        // so eight fetches are always in flight and `vmcnt(7)` means "the oldest has landed"
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        static_assert(!RS || NI == 4, "register-staged ping-pong: 256 x 256 tiles");
+        u32x4 Rw1[2], Ra1[2], Rw0[2], Ra0[2];
+        const int lane16 = lane * 16, last_kt = nk - 1;
+        auto gl = [&](u32x4& dst, const char* base, uint32_t voff) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base));
+        };
+        auto site = [&](u32x4& r, int lds_off, const char* next_base, uint32_t voff) {
+            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            *reinterpret_cast<u32x4*>(smem + lds_off + lane16) = r;
+            gl(r, next_base, voff);
+        };
+        // one of the two pieces (u) this wave stages of a half-tile; past the last k-tile a dummy keeps the count uniform
+        auto stage_a = [&](int buf, int kt, int mh, int u) {
+            if constexpr ((kDebug & 1) != 0) return;
+            if constexpr (RS) {
+                site(mh ? Ra1[u] : Ra0[u], buf * STRIDE + (mh ? AM1 : AM0) + (wave + 8 * u) * 1024,
+                     a_org + min(kt + 1, last_kt) * a_step, oA[mh][u]);
+                return;
+            }
+            if (kt < nk) glds16_asm(a_org + kt * a_step, oA[mh][u], lds_base + (uint32_t)(buf * STRIDE + (mh ? AM1 : AM0) + (wave + 8 * u) * 1024));
+            else dummy();
+        };
+        auto stage_w0 = [&](int buf, int kt, int u) {
+            if constexpr ((kDebug & 1) != 0) return;
+            if constexpr (RS) {
+                site(Rw0[u], buf * STRIDE + WN0 + (wave + 8 * u) * 1024, w_org + min(kt + 1, last_kt) * w_step, oW0[u]);
+                return;
+            }
+            if (kt < nk) glds16_asm(w_org + kt * w_step, oW0[u], lds_base + (uint32_t)(buf * STRIDE + WN0 + (wave + 8 * u) * 1024));
+            else dummy();
+        };
+        auto stage_w1 = [&](int buf, int kt, int u) {
+            if constexpr ((kDebug & 1) != 0) return;
+            if constexpr (RS) {
+                site(Rw1[u], buf * STRIDE + WN1 + (wave + 8 * u) * 1024, w_org + min(kt + 1, last_kt) * w_step, oW1[u]);
+                return;
+            }
+            if (kt < nk && (NI == 4 || u == 0)) glds16_asm(w_org + kt * w_step, oW1[u], lds_base + (uint32_t)(buf * STRIDE + WN1 + (wave + 8 * u) * 1024));
+            else dummy();
+        };
+        constexpr int NI1 = NI - 2;   // n sub-tiles of the second n half
+        bf16x8 W0[2][2], W0n[2][2], W1[NI1][2], Af[4][2];   // [sub-tile][k-step]  (W0n: DMA schedule only)
+        const int a_rd = (wm * 64 + frow) * 128, w0_rd = (wn * 32 + frow) * 128, w1_rd = (wn * (NI1 * 16) + frow) * 128;
+        auto rd = [&](const char* img, int sub, int ks) {
+            return *reinterpret_cast<const bf16x8*>(img + sub * 2048 + ((ks * 4 + fk) ^ sw) * 16);
+        };
+        auto load_end = [&]() {   // end of a phase's load part
+            if constexpr ((kDebug & 16) == 0 && !RS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mma_end = [&]() {
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+        };
+
+        if constexpr (RS) {
+            // With the operands waiting in registers nothing has to be in LDS more than two phases before its first read
+            // (two: group 1 runs a barrier behind), so plain double buffering is enough: during tile kt the images of tile
+            // kt+1 go to buffer buf^1 -- W.n0 in phase 1, A.m0 in 2 (both first read in phase 1 of the next tile), W.n1
+            // in 3, A.m1 in 4 -- and each site fetches its piece of tile kt+2 right behind its write.
+            const int k1 = min(1, last_kt);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                gl(Rw0[u], w_org, oW0[u]);
+                gl(Ra0[u], a_org, oA[0][u]);
+                gl(Rw1[u], w_org, oW1[u]);
+                gl(Ra1[u], a_org, oA[1][u]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pc = (wave + 8 * u) * 1024 + lane16;
+                *reinterpret_cast<u32x4*>(smem + WN0 + pc) = Rw0[u];
+                *reinterpret_cast<u32x4*>(smem + AM0 + pc) = Ra0[u];
+                *reinterpret_cast<u32x4*>(smem + WN1 + pc) = Rw1[u];
+                *reinterpret_cast<u32x4*>(smem + AM1 + pc) = Ra1[u];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) gl(Rw0[u], w_org + k1 * w_step, oW0[u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) gl(Ra0[u], a_org + k1 * a_step, oA[0][u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) gl(Rw1[u], w_org + k1 * w_step, oW1[u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) gl(Ra1[u], a_org + k1 * a_step, oA[1][u]);
+            if (wm == 1) {   // the stagger: group 1 runs one barrier behind group 0
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            auto mma_end_rs = [&]() {
+                __builtin_amdgcn_s_setprio(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this cluster's LDS writes
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" ::: "memory");
+            };
+            // 8 MFMAs of one k-step of a quadrant, then one staging site
+            auto cluster = [&](const bf16x8(&w)[2][2], const bf16x8(&a)[4][2], auto nh, auto mh, auto st) {
+                constexpr int NH = decltype(nh)::value, MH = decltype(mh)::value;
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[NH * 2 + i][MH * 4 + j] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][ks], a[j][ks], acc[NH * 2 + i][MH * 4 + j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    st(ks);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mma_end_rs();
+            };
+            using Z0 = std::integral_constant<int, 0>;
+            using Z1 = std::integral_constant<int, 1>;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int buf = kt & 1;
+                const char* tb = smem + buf * STRIDE;
+                // ---- phase 1: quadrant (m0, n0) ----
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) W0[i][ks] = rd(tb + WN0 + w0_rd, i, ks);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) Af[j][ks] = rd(tb + AM0 + a_rd, j, ks);
+                load_end();
+                cluster(W0, Af, Z0{}, Z0{}, [&](int u) { stage_w0(buf ^ 1, kt + 1, u); });
+                // ---- phase 2: (m0, n1) ----
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) W1[i][ks] = rd(tb + WN1 + w1_rd, i, ks);
+                load_end();
+                cluster(W1, Af, Z1{}, Z0{}, [&](int u) { stage_a(buf ^ 1, kt + 1, 0, u); });
+                // ---- phase 3: (m1, n1) ----
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) Af[j][ks] = rd(tb + AM1 + a_rd, j, ks);
+                load_end();
+                cluster(W1, Af, Z1{}, Z1{}, [&](int u) { stage_w1(buf ^ 1, kt + 1, u); });
+                // ---- phase 4: (m1, n0) ----
+                load_end();
+                cluster(W0, Af, Z0{}, Z1{}, [&](int u) { stage_a(buf ^ 1, kt + 1, 1, u); });
+            }
+            if (wm == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated fetches of the last tile
+        } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_w0(0, 0, u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_a(0, 0, 0, u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_w1(0, 0, u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_a(0, 0, 1, u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_w0(1, 1, u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) stage_a(1, 1, 0, u);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W.n0 and A.m0 of tile 0 have landed
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) W0n[i][ks] = rd(smem + WN0 + w0_rd, i, ks);
+        if (wm == 1) {   // the stagger: group 1 runs one barrier behind group 0
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            const char* tb = smem + buf * STRIDE;
+            // ---- phase 1: quadrant (m0, n0) ----
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) W0[i][ks] = W0n[i][ks];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) Af[j][ks] = rd(tb + AM0 + a_rd, j, ks);
+            load_end();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W0[i][ks], Af[j][ks], acc[i][j], 0, 0, 0);
+                // the LDS-DMA of this phase goes out under the cluster: its issue (~60 cycles each) would otherwise
+                // lengthen the load part, which the other group's cluster has to cover
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) stage_w1(buf ^ 1, kt + 1, 0); else stage_w1(buf ^ 1, kt + 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma_end();
+            // ---- phase 2: (m0, n1) ----
+#pragma unroll
+            for (int i = 0; i < NI1; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) W1[i][ks] = rd(tb + WN1 + w1_rd, i, ks);
+            load_end();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < NI1; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W1[i][ks], Af[j][ks], acc[2 + i][j], 0, 0, 0);
+                // the LDS-DMA of this phase goes out under the cluster: its issue (~60 cycles each) would otherwise
+                // lengthen the load part, which the other group's cluster has to cover
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) stage_a(buf ^ 1, kt + 1, 1, 0); else stage_a(buf ^ 1, kt + 1, 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma_end();
+            // ---- phase 3: (m1, n1) ----
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) Af[j][ks] = rd(tb + AM1 + a_rd, j, ks);
+            load_end();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < NI1; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W1[i][ks], Af[j][ks], acc[2 + i][4 + j], 0, 0, 0);
+                // the LDS-DMA of this phase goes out under the cluster: its issue (~60 cycles each) would otherwise
+                // lengthen the load part, which the other group's cluster has to cover
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) stage_w0(buf, kt + 2, 0); else stage_w0(buf, kt + 2, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma_end();
+            // ---- phase 4: (m1, n0); the W.n0 fragments of the next tile are fetched here ----
+            if (kt + 1 < nk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) W0n[i][ks] = rd(smem + (buf ^ 1) * STRIDE + WN0 + w0_rd, i, ks);
+            }
+            load_end();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W0[i][ks], Af[j][ks], acc[i][4 + j], 0, 0, 0);
+                // the LDS-DMA of this phase goes out under the cluster: its issue (~60 cycles each) would otherwise
+                // lengthen the load part, which the other group's cluster has to cover
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) stage_a(buf, kt + 2, 0, 0); else stage_a(buf, kt + 2, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma_end();
+        }
+        if (wm == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummies of the last phases
         }
     } else {
         // Software-pipelined 4-phase loop (256x256 tile, wave tile 128(m) x 64(n)).  A k-tile is four
@@ -533,6 +1053,125 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
         using H0 = std::integral_constant<int, 0>;
         using H1 = std::integral_constant<int, 1>;
 
+        if constexpr (PIPE == 3) {
+            // Register-staged operands: each wave fetches its 8 (7) 1-KiB pieces of tile kt+2 into registers right after
+            // it has written those of tile kt+1 to LDS (phase 3 of tile kt), so a fetch has a whole tile of time to land
+            // and no instruction of the loop is an LDS-DMA.  Same LDS images, same single barrier per tile.
+            static_assert(!ATR && !WTR, "register staging: NT operands");
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            constexpr int NP = C::A_SLABS + C::W_SLABS;
+            u32x4 R[NP];
+            const int lane16 = lane * 16;
+            // the fetches are inline asm so that the waits are the counted ones written below (hipcc's own bookkeeping
+            // falls back to vmcnt(0) at the loop header, which would expose the latency of the youngest fetch every tile)
+            auto gl = [&](u32x4& dst, const char* base, uint32_t voff) {
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base));
+            };
+            auto gload = [&](int kt) {
+#pragma unroll
+                for (int p = 0; p < C::A_SLABS; ++p) gl(R[p], a_org + kt * a_step, a_off[p]);
+#pragma unroll
+                for (int p = 0; p < C::W_SLABS; ++p) gl(R[C::A_SLABS + p], w_org + kt * w_step, w_off[p]);
+            };
+            auto lwrite = [&](int buf) {
+#pragma unroll
+                for (int p = 0; p < C::A_SLABS; ++p)
+                    *reinterpret_cast<u32x4*>(sA + buf * C::A_BYTES + (wave * C::A_SLABS + p) * 1024 + lane16) = R[p];
+#pragma unroll
+                for (int p = 0; p < C::W_SLABS; ++p)
+                    *reinterpret_cast<u32x4*>(sW + buf * C::W_BYTES + (wave * C::W_SLABS + p) * 1024 + lane16) = R[C::A_SLABS + p];
+            };
+            // piece p of tile T goes to LDS in slot (p / 2 + 3) % 4 of the tile before (slot 3 = phase 4 of tile T-2 for
+            // pieces 0, 1 .. slot 2 = phase 3 of tile T-1 for pieces 6, 7) and the same piece of tile T+1 is fetched right
+            // behind it; past the last tile the fetches repeat tile nk-1 and the writes land in a dead buffer
+            auto gload1 = [&](auto pc, int kt) {
+                constexpr int p = decltype(pc)::value;
+                if constexpr (p < C::A_SLABS) gl(R[p], a_org + kt * a_step, a_off[p]);
+                else if constexpr (p < NP) gl(R[p], w_org + kt * w_step, w_off[p - C::A_SLABS]);
+            };
+            auto lwrite1 = [&](auto pc, int buf) {
+                constexpr int p = decltype(pc)::value;
+                if constexpr (p < C::A_SLABS)
+                    *reinterpret_cast<u32x4*>(sA + buf * C::A_BYTES + (wave * C::A_SLABS + p) * 1024 + lane16) = R[p];
+                else if constexpr (p < NP)
+                    *reinterpret_cast<u32x4*>(sW + buf * C::W_BYTES + (wave * C::W_SLABS + p - C::A_SLABS) * 1024 + lane16) = R[p];
+            };
+            // one phase: 16 (12) MFMAs with the fragment reads of the next phase in front, the LDS writes of pieces p, p+1
+            // (of the tile whose fetches are oldest) after the first half and the fetches of the same pieces of tile
+            // kt_next after three quarters
+            auto mma_part = [&](const bf16x8(&wf)[NI], const bf16x8(&af)[4], auto mh, auto q0, auto q1) {
+                constexpr int MH = decltype(mh)::value;
+#pragma unroll
+                for (int q = decltype(q0)::value; q < decltype(q1)::value; ++q)
+                    acc[q >> 2][MH * 4 + (q & 3)] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q >> 2], af[q & 3], acc[q >> 2][MH * 4 + (q & 3)], 0, 0, 0);
+            };
+            auto phase = [&](const bf16x8(&wf)[NI], const bf16x8(&af)[4], auto mh, auto pc, int buf, int kt_next) {
+                constexpr int p = decltype(pc)::value;
+                constexpr int Q = NI * 4;
+                using I0 = std::integral_constant<int, 0>;
+                using IA = std::integral_constant<int, Q / 2>;
+                using IB = std::integral_constant<int, Q * 3 / 4>;
+                using IQ = std::integral_constant<int, Q>;
+                __builtin_amdgcn_sched_barrier(0);
+                mma_part(wf, af, mh, I0{}, IA{});
+                __builtin_amdgcn_sched_barrier(0);
+                // NP fetches are in flight, oldest first the pieces written now: all but the NP - 2 (NP - 1) younger ones
+                if constexpr (p + 1 < NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP - 2) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP - 1) : "memory");
+                lwrite1(std::integral_constant<int, p>{}, buf);
+                lwrite1(std::integral_constant<int, p + 1>{}, buf);
+                mma_part(wf, af, mh, IA{}, IB{});
+                __builtin_amdgcn_sched_barrier(0);
+                gload1(std::integral_constant<int, p>{}, kt_next);
+                gload1(std::integral_constant<int, p + 1>{}, kt_next);
+                mma_part(wf, af, mh, IB{}, IQ{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using P0 = std::integral_constant<int, 0>;
+            using P2 = std::integral_constant<int, 2>;
+            using P4 = std::integral_constant<int, 4>;
+            using P6 = std::integral_constant<int, 6>;
+            const int last = nk - 1;
+            gload(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lwrite(0);
+            gload1(P0{}, min(1, last));
+            gload1(std::integral_constant<int, 1>{}, min(1, last));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lwrite1(P0{}, 1);
+            lwrite1(std::integral_constant<int, 1>{}, 1);
+            __syncthreads();
+            {   // the order the loop keeps (2..7 of the next tile, then 0, 1 of the one after): the counted waits hold from tile 0
+                const int k1 = min(1, last);
+                gload1(P2{}, k1);
+                gload1(std::integral_constant<int, 3>{}, k1);
+                gload1(P4{}, k1);
+                gload1(std::integral_constant<int, 5>{}, k1);
+                gload1(P6{}, k1);
+                gload1(std::integral_constant<int, 7>{}, k1);
+                gload1(P0{}, min(2, last));
+                gload1(std::integral_constant<int, 1>{}, min(2, last));
+            }
+            ldW(Wf[0], 0, 0);
+            ldA(Af[0], 0, 0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                const int buf = kt & 1;
+                const int k2 = min(kt + 2, last), k3 = min(kt + 3, last);
+                ldA(Af[1], buf, 0, 1);
+                phase(Wf[0], Af[0], H0{}, P2{}, buf ^ 1, k2);
+                ldW(Wf[1], buf, 1);
+                ldA(Af[0], buf, 1, 0);
+                phase(Wf[0], Af[1], H1{}, P4{}, buf ^ 1, k2);
+                ldA(Af[1], buf, 1, 1);
+                phase(Wf[1], Af[0], H0{}, P6{}, buf ^ 1, k2);
+                __syncthreads();                       // tile kt+1 is in LDS; every wave holds its last fragments of tile kt
+                ldW(Wf[0], buf ^ 1, 0);
+                ldA(Af[0], buf ^ 1, 0, 0);
+                phase(Wf[1], Af[1], H1{}, P0{}, buf, k3);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated fetches of the last tiles: their registers are reused below
+        } else {
         if (!prefetched) stage(0, kbeg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -567,15 +1206,96 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             mma(Wf[1], Af[1], H1{});
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
     }
 
+    // ---- stream-K: a tail segment publishes its partial sums and the walk goes on; a head segment completes its tile ----
+    if constexpr (SKC) {
+        if (sk_on) {
+            const bool is_tail = kbeg > 0;                 // the tile's reduction started in another workgroup
+            const bool is_head = kend < nk;                // ... or ends in another one
+            float* ws = g.sk_ws + (int64_t)sk_tile * (BM * BN);
+            if (is_tail && sk_any) {
+                {
+                    float* wp = ws + tid * 4;        // one running pointer (32 separate addresses would cost 64 registers)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < MI; ++j) {
+                            st16_wt(wp, acc[i][j]);
+                            wp += C::THREADS * 4;
+                            asm volatile("" : "+v"(wp));
+                        }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are out
+                __syncthreads();                                     // ... and every wave's
+                if (tid == 0) {
+                    int* fp = g.sk_flags + sk_tile;
+                    asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(fp), "v"(sk_want) : "memory");
+                }
+                // next segment of this workgroup (the head of the following tile), if any
+                if (sk_more) {
+                    sk_more = false;
+                    __syncthreads();
+                    sk_tile = sk_tile2;
+                    set_tile(sk_tile, false);
+                    kbeg = 0;
+                    kend = sk_k2;
+                    continue;
+                }
+                break;
+            }
+            if (is_head && sk_any) {
+                if (tid == 0) {
+                    const int* fp = g.sk_flags + sk_tile;
+                    int v_ = 0;
+                    for (int spin = 0; spin < (1 << 16); ++spin) {   // bounded: a lost partner shows as a wrong result, not a hang
+                        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v_) : "v"(fp) : "memory");
+                        if (v_ == sk_want) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                __syncthreads();
+                // the published tail in groups of SKG accumulator quads (16 registers), the next group requested before
+                // the current one is added: counted waits, all of it next to the 128 accumulator registers
+                constexpr int SKG = 4, NGRP = NI * MI / SKG;
+                static_assert(MI % SKG == 0, "stream-K: groups must not straddle accumulator rows");
+                f32x4 part[2][SKG];
+                const float* rp = ws + tid * 4;     // one running pointer, as on the publishing side
+                auto pl = [&](f32x4(&dst)[SKG]) {
+#pragma unroll
+                    for (int j = 0; j < SKG; ++j) {
+                        ld16_sc1(dst[j], rp);
+                        rp += C::THREADS * 4;
+                        asm volatile("" : "+v"(rp));
+                    }
+                };
+                pl(part[0]);
+#pragma unroll
+                for (int gi = 0; gi < NGRP; ++gi) {
+                    if (gi + 1 < NGRP) {
+                        pl(part[(gi + 1) & 1]);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SKG) : "memory");   // all but the SKG loads just issued
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+#pragma unroll
+                    for (int j = 0; j < SKG; ++j) {
+                        asm volatile("" : "+v"(part[gi & 1][j]));     // the value is valid only behind the wait above
+                        acc[(gi * SKG + j) / MI][(gi * SKG + j) % MI] += part[gi & 1][j];
+                    }
+                }
+            }
+            if (!sk_any) break;
+        }
+    }
 
     // ---- the tile whose accumulators are stored now; then (persistent walk) the next tile's first k-tile is requested ----
     const int m0e = m0, n0e = n0;
     bool more = false;
     if constexpr (PERSIST) {
         const int vt_next = vt_cur + (int)gridDim.x;
-        more = vt_next < nwg;
+        more = vt_next < nwg && !sk_on;
         if (more) {
             __syncthreads();          // every wave has read its last fragments: both staging buffers are free
             vt_cur = vt_next;
@@ -767,8 +1487,33 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
             else gated_store(std::integral_constant<int, VGPT_ACT_GELU_TANH>{}, KF{});
         }
     }
+    if constexpr (SKC) {
+        if (sk_on) {   // a head (or whole-tile) segment was stored: the next segment of this workgroup, if any
+            if (sk_more) {
+                sk_more = false;
+                __syncthreads();
+                sk_tile = sk_tile2;
+                set_tile(sk_tile, false);
+                kbeg = 0;
+                kend = sk_k2;
+                continue;
+            }
+        }
+    }
     if (!more) break;
     }   // persistent walk
+    if constexpr (SKC) {
+        if (sk_on) {   // the last workgroup to finish opens the next launch's epoch
+            __syncthreads();
+            if (tid == 0) {
+                const int prev = atomicAdd(g.sk_ctl + 1, 1);
+                if (prev == (int)gridDim.x - 1) {
+                    g.sk_ctl[1] = 0;
+                    g.sk_ctl[0] = sk_want;
+                }
+            }
+        }
+    }
 }
 
 // Persistent walk: OFF unless VGPT_GEMM_PERSIST=1.  Measured in round 3 on one box (bench.py, same process order): sampler
@@ -802,7 +1547,7 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + (PIPE == 2 || PIPE == 4 ? 16384 : 0));
         if (e != hipSuccess) {
             vgpt_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return VGPT_ERR_HIP;
@@ -814,12 +1559,13 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     // persistent walk (kernel: PERSIST): one round of the chip's workgroup slots, each workgroup taking tiles
     // blockIdx.x, + gridDim.x, ...; the slot count is a multiple of 8 (XCD remap).  Off by default (persist_enabled()).
     int grid = g.tiles_m * g.tiles_n;
+    if (PIPE == 7) grid = cu_count();   // stream-K: one workgroup per CU, equal shares of the (tile, k-tile) units
     if ((PIPE == 0 || PIPE == 1) && MODE != MODE_ROPE && persist_enabled()) {
         const int slots = cu_count() * (C::LDS_BYTES > 80 * 1024 ? 1 : 2);
         if (slots % 8 == 0 && grid > slots) grid = slots;
     }
     hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>), dim3(grid), dim3(C::THREADS),
-                       C::LDS_BYTES, s, g);
+                       C::LDS_BYTES + (PIPE == 2 || PIPE == 4 ? 16384 : 0), s, g);
     VGPT_CHECK_LAUNCH(name);
     return VGPT_OK;
 }
@@ -880,6 +1626,9 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const bool use256 = f == 256 || f == 257 || f == 192 || f == 288 || f == 289 || f == 512 || (f != 128 && big_tiles >= 128);
     if (!use256) return launch_cfg<MODE, Cfg128, 0, ATR, WTR>(g, n_out, s, name);
     if (f == 257) return launch_cfg<MODE, Cfg256, 0, ATR, WTR>(g, n_out, s, name);
+    if constexpr (!ATR && !WTR) {
+        if (f == 512) return launch_cfg<MODE, Cfg256w4, 6, ATR, WTR>(g, n_out, s, name);   // EXPERIMENT: 4 waves of 128 x 128
+    }
     if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
         if (f == 288) return launch_cfg<MODE, Cfg288, 5, ATR, WTR>(g, n_out, s, name);
         if (f == 289) return launch_cfg<MODE, Cfg288, 0, ATR, WTR>(g, n_out, s, name);
@@ -909,8 +1658,15 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     }
     auto big = [&](const GemmArgs& ga) {
         if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
-            if (use192) return launch_cfg<MODE, Cfg192, 1, ATR, WTR>(ga, n_out, s, name);
+            if (use192) return launch_cfg<MODE, Cfg192, (VGPT_GEMM_RS ? 3 : VGPT_GEMM_PP ? 2 : 1), ATR, WTR>(ga, n_out, s, name);
         }
+        if constexpr (!ATR && !WTR && VGPT_GEMM_PP) {
+            if (ga.K >= 2 * BK) return launch_cfg<MODE, Cfg256, 2, ATR, WTR>(ga, n_out, s, name);
+        }
+        if constexpr (!ATR && !WTR && VGPT_GEMM_RS == 2) {
+            if (ga.K >= 2 * BK) return launch_cfg<MODE, Cfg256, 4, ATR, WTR>(ga, n_out, s, name);
+        }
+        if constexpr (!ATR && !WTR && VGPT_GEMM_RS) return launch_cfg<MODE, Cfg256, 3, ATR, WTR>(ga, n_out, s, name);
         return launch_cfg<MODE, Cfg256, 1, ATR, WTR>(ga, n_out, s, name);
     };
     if (p.rows_big >= g.M) return big(g);
@@ -933,6 +1689,26 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// Stream-K pays where 256 x 256 tiles leave a good part of the chip idle in the ONE round they need (o_proj and down_proj
+// of a 4096-row sampler step: 192 tiles on 256 CUs) and every workgroup's share still spans at most two tiles.
+bool sk_applies(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = cdiv(M, 256) * cdiv(N, 256), nk = K / BK, cus = cu_count();
+    if (K % BK != 0 || tiles >= cus || tiles * 8 < cus * 5) return false;       // between 5/8 and one round of the chip
+    const int64_t share = tiles * nk / cus;
+    if (share < 8 || share > nk) return false;
+    // every workgroup's share must be the TAIL of one tile and / or the HEAD of the next (the kernel's two roles): no
+    // share may lie strictly inside a tile's reduction (that tile would have three contributors)
+    const int64_t units = tiles * nk;
+    for (int64_t w = 0; w < cus; ++w) {
+        const int64_t u0 = units * w / cus, u1 = units * (w + 1) / cus;
+        if (u1 <= u0) return false;
+        const int64_t t0 = u0 / nk, k0 = u0 % nk;
+        if (u1 > (t0 + 2) * nk) return false;                       // more than two tiles
+        if (k0 > 0 && u1 < (t0 + 1) * nk) return false;             // strictly inside one tile
+    }
+    return true;
+}
+constexpr int64_t SK_CTL_BYTES = 256;   // {epoch, finished workgroups}, padded
 
 }  // namespace
 
@@ -955,6 +1731,9 @@ VGPT_EXPORT int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void
     VGPT_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), VGPT_ERR_UNSUPPORTED,
                  "vgpt_gemm_bf16: dimension too large");
     if (M == 0) return VGPT_OK;
+    // a plain product the vendor library is measured ahead on (gemm_lt.hip): enqueued there; everything else, and whatever
+    // the library declines, on the kernels of this file
+    if (vgpt_lt_try_gemm(A, W, C, extra, M, N, K, lda, ldw, ldc, ldr, epilogue, 0, 0, (hipStream_t)stream)) return VGPT_OK;
     GemmArgs g;
     g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = (bf16*)C; g.extra = (const bf16*)extra;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -989,6 +1768,9 @@ VGPT_EXPORT int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const v
                      (!a_transposed || K * lda < (1ll << 30)),
                  VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_tr: dimension too large (a transposed operand must stay below 2 GiB)");
     if (M == 0) return VGPT_OK;
+    if (vgpt_lt_try_gemm(A, W, C, extra, M, N, K, lda, ldw, ldc, ldr, epilogue, a_transposed ? 1 : 0, w_transposed ? 1 : 0,
+                         (hipStream_t)stream))
+        return VGPT_OK;
     GemmArgs g;
     g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = (bf16*)C; g.extra = (const bf16*)extra;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -1033,6 +1815,13 @@ static int gated_mlp_impl(const void* A, const void* W_gate_up, void* out, void*
     VGPT_REQUIRE(M < (1 << 30) && I < (1 << 29) && K < (1 << 30), VGPT_ERR_UNSUPPORTED,
                  "vgpt_gated_mlp_act_fwd: dimension too large");
     if (M == 0) return VGPT_OK;
+    // training forward (the [gate | up] tensor is stored for the backward): where the library's plain GEMM followed by the
+    // activation kernel is measured ahead of the fused kernel that stores both (gemm_lt.hip, purpose 1), that pair runs --
+    // bit for bit the pair this entry is defined by, up to the library's order of fp32 additions
+    if (gate_up_out && ld_gu == 2 * I && ldo == I && I % 8 == 0 && ((uintptr_t)gate_up_out & 15) == 0 &&
+        vgpt_lt_try_gemm(A, W_gate_up, gate_up_out, nullptr, M, 2 * I, K, lda, ldw, ld_gu, 0, VGPT_EPI_NONE, 0, 0,
+                         (hipStream_t)stream, 1))
+        return vgpt_silu_mul_fwd(gate_up_out, out, M, I, act, stream);
     GemmArgs g;
     g.A = (const bf16*)A; g.W = (const bf16*)W_gate_up; g.C = (bf16*)out; g.extra = nullptr;
     g.M = (int)M; g.N = (int)I; g.K = (int)K;
@@ -1070,3 +1859,44 @@ VGPT_EXPORT int vgpt_gemm_bf16_rope(const void* A, const void* W, void* C, const
     return launch<MODE_ROPE>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_rope");
 }
 
+/* ---- stream-K form of vgpt_gemm_bf16 (see GemmArgs::sk_ws) ---- */
+VGPT_EXPORT int vgpt_gemm_sk_applies(int64_t M, int64_t N, int64_t K) { return M > 0 && N > 0 && K > 0 && sk_applies(M, N, K); }
+
+VGPT_EXPORT int64_t vgpt_gemm_sk_workspace_bytes(int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return -1;
+    const int64_t tiles = cdiv(M, 256) * cdiv(N, 256);
+    // control words | one flag per tile (padded to 256 bytes) | one fp32 256 x 256 partial per tile
+    return SK_CTL_BYTES + (tiles * 4 + 255) / 256 * 256 + tiles * 256 * 256 * 4;
+}
+
+VGPT_EXPORT int vgpt_gemm_bf16_sk(const void* A, const void* W, void* C, const void* extra, int64_t M, int64_t N, int64_t K,
+                                  int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int epilogue, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    VGPT_REQUIRE(A && W && C && workspace, VGPT_ERR_INVALID, "vgpt_gemm_bf16_sk: null pointer");
+    VGPT_REQUIRE(M > 0 && N > 0 && K > 0 && sk_applies(M, N, K), VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_sk: shape %ld x %ld x %ld is not a stream-K case (vgpt_gemm_sk_applies)", (long)M, (long)N, (long)K);
+    VGPT_REQUIRE(epilogue == VGPT_EPI_NONE || epilogue == VGPT_EPI_RESID || epilogue == VGPT_EPI_BIAS, VGPT_ERR_INVALID,
+                 "vgpt_gemm_bf16_sk: unknown epilogue %d", epilogue);
+    VGPT_REQUIRE(epilogue == VGPT_EPI_NONE || extra, VGPT_ERR_INVALID, "vgpt_gemm_bf16_sk: epilogue operand missing");
+    VGPT_REQUIRE(N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && aligned16(A) && aligned16(W) &&
+                     ((uintptr_t)C & 7) == 0 && ((uintptr_t)workspace & 255) == 0,
+                 VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_sk: alignment (rows 16 bytes, workspace 256 bytes)");
+    VGPT_REQUIRE(epilogue != VGPT_EPI_RESID || (ldr % 4 == 0 && ((uintptr_t)extra & 7) == 0), VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_sk: residual must be 8-byte aligned");
+    VGPT_REQUIRE(workspace_bytes >= vgpt_gemm_sk_workspace_bytes(M, N), VGPT_ERR_INVALID,
+                 "vgpt_gemm_bf16_sk: workspace too small (vgpt_gemm_sk_workspace_bytes)");
+    VGPT_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_sk: dimension too large");
+    const int64_t tiles = cdiv(M, 256) * cdiv(N, 256);
+    GemmArgs g;
+    g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = (bf16*)C; g.extra = (const bf16*)extra;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+    g.epi = epilogue; g.act = 0; g.I = 0;
+    g.tiles_m = g.tiles_n = 0;
+    g.rope_cos = g.rope_sin = nullptr; g.rope_cols = g.head_dim = 0;
+    char* ws = (char*)workspace;
+    g.sk_ctl = (int*)ws;
+    g.sk_flags = (int*)(ws + SK_CTL_BYTES);
+    g.sk_ws = (float*)(ws + SK_CTL_BYTES + (tiles * 4 + 255) / 256 * 256);
+    return launch_cfg<MODE_PLAIN, Cfg256, 7>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_sk");
+}

@@ -101,17 +101,6 @@ def rope_qk_inplace(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_q
     return qkv
 
 
-_SK_WS = {}      # device -> zero-initialised stream-K workspace (include/vgpt.h, vgpt_gemm_bf16_sk); shared by all calls
-_SK_ON = None    # VGPT_GEMM_SK=0 switches the stream-K launches off (same-box A/B)
-
-
-def _sk_workspace(device, nbytes: int) -> torch.Tensor:
-    ws = _SK_WS.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = _SK_WS[device] = torch.zeros(nbytes, dtype=torch.uint8, device=device)   # zeroed ONCE: it carries a launch counter
-    return ws
-
-
 def linear(x: torch.Tensor, weight: torch.Tensor, residual: Optional[torch.Tensor] = None,
            bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
     """out = x @ weight.T (+ residual | + bias) on the MFMA GEMM; x (..., K), weight (N, K)."""
@@ -136,17 +125,6 @@ def linear(x: torch.Tensor, weight: torch.Tensor, residual: Optional[torch.Tenso
     elif bias is not None:
         _chk(bias, BF16, "linear.bias")
         epi, extra = EPI_BIAS, bias
-    global _SK_ON
-    if _SK_ON is None:
-        import os
-        _SK_ON = os.environ.get("VGPT_GEMM_SK", "0") == "1"
-    lib = _lib.load()
-    if _SK_ON and M > 0 and lib.vgpt_gemm_sk_applies(M, N, K):
-        # fewer 256 x 256 tiles than CUs (o_proj / down_proj of a sampler step): equal shares of the k-tiles per CU
-        ws = _sk_workspace(x.device, int(lib.vgpt_gemm_sk_workspace_bytes(M, N)))
-        call("vgpt_gemm_bf16_sk", x.data_ptr(), weight.data_ptr(), out.data_ptr(), _ptr(extra), M, N, K, K, K, N, ldr, epi,
-             ws.data_ptr(), ws.numel(), _stream())
-        return out
     call("vgpt_gemm_bf16", x.data_ptr(), weight.data_ptr(), out.data_ptr(), _ptr(extra), M, N, K, K, K, N,
          ldr, epi, _stream())
     return out
