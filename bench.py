@@ -698,11 +698,12 @@ def main():
         try:
             with torch.cuda.stream(stream):
                 yard = {}
-                res_ = eng.hid[:rows]
-                prods = (("o_proj", eng.ctx[:rows], lambda l: l.self_attn.o_proj.weight, True),
-                         ("down_proj", eng.act[:rows], lambda l: l.mlp.down_proj.weight, True),
-                         ("qkv_proj_plain_gemm_only", eng.nrm[:rows], lambda l: l.self_attn.qkv_proj.weight, False),
-                         ("gate_up_plain_gemm_only", eng.nrm[:rows], lambda l: l.mlp.gate_up_proj.weight, False))
+                two_d = lambda t_: t_.reshape(-1, t_.shape[-1])[:rows]
+                res_ = two_d(eng.hid)
+                prods = (("o_proj", two_d(eng.ctx), lambda l: l.self_attn.o_proj.weight, True),
+                         ("down_proj", two_d(eng.act), lambda l: l.mlp.down_proj.weight, True),
+                         ("qkv_proj_plain_gemm_only", two_d(eng.nrm), lambda l: l.self_attn.qkv_proj.weight, False),
+                         ("gate_up_plain_gemm_only", two_d(eng.nrm), lambda l: l.mlp.gate_up_proj.weight, False))
                 for name, x_, wf_, with_res in prods:
                     f_ = (lambda w_: torch.addmm(res_, x_, w_.t())) if with_res else (lambda w_: torch.matmul(x_, w_.t()))
                     for l in model.llm.layers[:2]:

@@ -771,6 +771,252 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     }   // persistent walk
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Four-wave kernel with the hand-scheduled main loop (gen/gemm_w4_gen.py -> gemm_w4_loop.inc): 256 x (NI * 32) x 64 tiles,
+// one wave per SIMD holding a 128 x (NI * 16) accumulator block in AGPRs, operands global -> registers -> LDS (the same
+// XOR-swizzled row images as above) with counted waits, one barrier per k-tile.  NT operands, K % 64 == 0, nk >= 2.
+// The loop is ONE asm statement; the C++ here computes the tile's addresses (the per-piece row offsets travel in the lanes
+// of one VGPR) and runs the epilogue straight from the accumulator registers.
+#include "gemm_w4_loop.inc"
+
+template <int I0, int N0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < N0) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, N0>(f);
+    }
+}
+
+// accumulator quad IDX (registers a[4 IDX .. 4 IDX + 3]) of the asm loop
+template <int IDX>
+__device__ __forceinline__ f32x4 w4_acc() {
+    float x0, x1, x2, x3;
+    asm volatile("v_accvgpr_read_b32 %0, a%c4\n\tv_accvgpr_read_b32 %1, a%c5\n\tv_accvgpr_read_b32 %2, a%c6\n\tv_accvgpr_read_b32 %3, a%c7"
+                 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3)
+                 : "n"(IDX * 4), "n"(IDX * 4 + 1), "n"(IDX * 4 + 2), "n"(IDX * 4 + 3));
+    return f32x4{x0, x1, x2, x3};
+}
+
+template <int MODE, int NI>
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
+    constexpr bool ROPE = MODE == MODE_ROPE;
+    constexpr int BM = 256, BN = NI * 32, MI = 8;
+    constexpr int A_BYTES = BM * BK * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds_base =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    if (lds_base != 0) __builtin_trap();   // the loop toggles its staging buffers by XOR on absolute LDS addresses
+
+    // ---- tile order: as gemm_bf16_kernel (XCD-aware remap, grouped along m) ----
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GROUP = 8;
+    const int in_group = GROUP * g.tiles_n;
+    const int group_id = bid / in_group;
+    const int first_m = group_id * GROUP;
+    const int gsz = min(g.tiles_m - first_m, GROUP);
+    const int tm = first_m + (bid % in_group) % gsz;
+    const int tn = (bid % in_group) / gsz;
+    const int m0 = tm * BM;
+    const int n0 = tn * (MODE == MODE_GATED ? BN / 2 : BN);
+    const int n_rows_w = (MODE == MODE_GATED) ? 2 * g.I : g.N;
+
+    // ---- operands of the loop ----
+    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    const uint32_t va = (uint32_t)(srow * (int)g.lda + schunk * 8) * 2u;
+    const uint32_t vw = (uint32_t)(srow * (int)g.ldw + schunk * 8) * 2u;
+    // lane p < 8: byte offset of the 8-row A piece p of this wave (rows clamped into the matrix: rows past M are never
+    // stored); lane 8 + p: of its W piece p (8 weight rows behind 8 consecutive n-slots)
+    uint32_t tab = 0;
+    {
+        const int pa = lane & 7;
+        const int ra = min((wave * 8 + pa) * 8, max(g.M - m0 - 8, 0));
+        const int pw = min(max(lane - 8, 0), NI - 1);
+        const int s8 = (wave * NI + pw) * 8;   // first n-slot of the piece inside the tile
+        int rw;
+        if constexpr (MODE == MODE_GATED) {
+            rw = ((s8 >> 4) & 1 ? g.I : 0) + min(n0 + (s8 >> 5) * 16 + (s8 & 15), g.I - 8);
+        } else if constexpr (ROPE) {
+            rw = min(rope_col_of_slot(n0 + s8, g.rope_cols, g.head_dim), n_rows_w - 8);
+        } else {
+            rw = min(s8, max(g.N - n0 - 8, 0));
+        }
+        tab = lane < 8 ? (uint32_t)(ra * (int)g.lda) * 2u : (uint32_t)(rw * (int)g.ldw) * 2u;
+    }
+    const bf16* a_org = g.A + (int64_t)m0 * g.lda;
+    const bf16* w_org = (MODE == MODE_GATED || ROPE) ? g.W : g.W + (int64_t)n0 * g.ldw;
+    auto srd = [](const void* base) {
+        const uint64_t b = (uint64_t)(uintptr_t)base;
+        v4i32 r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+        r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32) & 0xffff);
+        r[2] = -1;             // num_records: every offset the loop forms stays inside the matrix by construction
+        r[3] = 0x00020000;
+        return r;
+    };
+    const v4i32 srdA = srd(a_org), srdW = srd(w_org);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fk = lane >> 4, sw = frow & 7;
+    const uint32_t rdA = (uint32_t)((wm * 128 + frow) * 128 + ((fk ^ sw) * 16));
+    const uint32_t rdW = (uint32_t)(2 * A_BYTES + (wn * NI * 16 + frow) * 128 + ((fk ^ sw) * 16));
+    const uint32_t wrA = (uint32_t)(wave * 8192 + lane * 16);
+    const uint32_t wrW = (uint32_t)(2 * A_BYTES + wave * NI * 1024 + lane * 16);
+    const int nk = __builtin_amdgcn_readfirstlane(g.K / BK);
+
+    if constexpr (NI == 8) {
+        asm volatile(VGPT_W4_ASM_NI8
+                     :
+                     : [srdA] "s"(srdA), [srdW] "s"(srdW), [tab] "v"(tab), [va] "v"(va), [vw] "v"(vw), [rdA] "v"(rdA),
+                       [rdW] "v"(rdW), [wrA] "v"(wrA), [wrW] "v"(wrW), [nk] "s"(nk)
+                     : VGPT_W4_CLOBBERS);
+    } else {
+        asm volatile(VGPT_W4_ASM_NI6
+                     :
+                     : [srdA] "s"(srdA), [srdW] "s"(srdW), [tab] "v"(tab), [va] "v"(va), [vw] "v"(vw), [rdA] "v"(rdA),
+                       [rdW] "v"(rdW), [wrA] "v"(wrA), [wrW] "v"(wrW), [nk] "s"(nk)
+                     : VGPT_W4_CLOBBERS);
+    }
+
+    // ---- epilogue: lane holds m = lane & 15, n = (lane >> 4) * 4 + reg of each 16 x 16 sub-tile (i: n, j: m) ----
+    const int em = lane & 15, en = (lane >> 4) * 4;
+    if constexpr (ROPE) {
+        // as gemm_bf16_kernel: product rounded to bf16, rotated in fp32 with the partner column from lane ^ 32, the cos / sin
+        // rows of the tile staged through the (now free) LDS
+        const int half = g.head_dim >> 1;
+        const int tab_bytes = (BM * half * 4 + 1023) & ~1023;
+        const bool staged = 2 * tab_bytes <= 4 * A_BYTES;
+        if (staged) {
+            __syncthreads();
+            const int64_t row0_bytes = (int64_t)m0 * half * 4;
+            const uint32_t last = (uint32_t)min((int64_t)g.M * half * 4 - row0_bytes - 16, (int64_t)tab_bytes);
+            const char* cbase = reinterpret_cast<const char*>(g.rope_cos) + row0_bytes;
+            const char* sbase = reinterpret_cast<const char*>(g.rope_sin) + row0_bytes;
+            for (int pc = wave; pc * 1024 < tab_bytes; pc += 4) {
+                const uint32_t off = min((uint32_t)(pc * 1024 + lane * 16), last);
+                glds16_asm(cbase, off, lds_base + (uint32_t)(pc * 1024));
+                glds16_asm(sbase, off, lds_base + (uint32_t)(tab_bytes + pc * 1024));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        const bool upper = (lane & 32) != 0;
+        static_for<0, MI>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int ml = wm * 128 + j * 16 + em;
+            const int m = m0 + ml;
+            const bool m_ok = m < g.M;
+            static_for<0, NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const int gs = n0 + wn * (NI * 16) + i * 16 + en;
+                if (gs >= g.N) return;          // N % 16 == 0: uniform over a lane and its partner
+                const int n = rope_col_of_slot(gs, g.rope_cols, g.head_dim);
+                const f32x4 v = w4_acc<i * 8 + j>();
+                bf16x4 o;
+                if (gs < g.rope_cols) {
+                    const int d = (n % g.head_dim) - (upper ? half : 0);
+                    const int mr = m_ok ? ml : 0;
+                    f32x4 cs, sn;
+                    if (staged) {
+                        cs = *reinterpret_cast<const f32x4*>(smem + (mr * half + d) * 4);
+                        sn = *reinterpret_cast<const f32x4*>(smem + tab_bytes + (mr * half + d) * 4);
+                    } else {
+                        const int64_t mg = m_ok ? m : 0;
+                        cs = *reinterpret_cast<const f32x4*>(g.rope_cos + mg * half + d);
+                        sn = *reinterpret_cast<const f32x4*>(g.rope_sin + mg * half + d);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float own = bf2f(f2bf(v[t]));
+                        auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
+                        const float other = __uint_as_float(upper ? sw2[0] : sw2[1]);
+                        o[t] = f2bf(upper ? own * cs[t] + other * sn[t] : own * cs[t] - other * sn[t]);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = f2bf(v[t]);
+                }
+                if (m_ok) store_out4(g.C + (int64_t)m * g.ldc + n, o);
+            });
+        });
+    } else if constexpr (MODE == MODE_PLAIN) {
+        static_for<0, MI>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int m = m0 + wm * 128 + j * 16 + em;
+            if (m >= g.M) return;
+            static_for<0, NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const int n = n0 + wn * (NI * 16) + i * 16 + en;
+                if (n >= g.N) return;
+                f32x4 v = w4_acc<i * 8 + j>();
+                if (g.epi == VGPT_EPI_RESID) {
+                    bf16x4 r = *reinterpret_cast<const bf16x4*>(g.extra + (int64_t)m * g.ldr + n);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] += bf2f(r[t]);
+                } else if (g.epi == VGPT_EPI_BIAS) {
+                    bf16x4 r = *reinterpret_cast<const bf16x4*>(g.extra + n);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] += bf2f(r[t]);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = f2bf(v[t]);
+                store_out4(g.C + (int64_t)m * g.ldc + n, o);
+            });
+        });
+    } else {
+        auto gated_store = [&](auto actc, auto keepc) {
+            constexpr int ACT = decltype(actc)::value;
+            constexpr bool KEEP = decltype(keepc)::value;
+            static_for<0, MI>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int m = m0 + wm * 128 + j * 16 + em;
+                if (m >= g.M) return;
+                static_for<0, NI / 2>([&](auto pc) {
+                    constexpr int p = decltype(pc)::value;
+                    const int n = n0 + (wn * (NI / 2) + p) * 16 + en;  // output column
+                    if (n >= g.I) return;
+                    const f32x4 gate = w4_acc<(2 * p) * 8 + j>(), up = w4_acc<(2 * p + 1) * 8 + j>();
+                    bf16x4 o;
+                    if constexpr (KEEP) {
+                        bf16x4 gb, ub;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            gb[t] = f2bf(gate[t]);
+                            ub[t] = f2bf(up[t]);
+                            o[t] = f2bf(act_apply(bf2f(gb[t]), ACT) * bf2f(ub[t]));
+                        }
+                        store_out4(g.gu_out + (int64_t)m * g.ld_gu + n, gb);
+                        store_out4(g.gu_out + (int64_t)m * g.ld_gu + g.I + n, ub);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o[t] = f2bf(act_apply(gate[t], ACT) * up[t]);
+                    }
+                    store_out4(g.C + (int64_t)m * g.ldc + n, o);
+                });
+            });
+        };
+        using KT = std::true_type;
+        using KF = std::false_type;
+        if (g.act == VGPT_ACT_SILU) {
+            if (g.gu_out) gated_store(std::integral_constant<int, VGPT_ACT_SILU>{}, KT{});
+            else gated_store(std::integral_constant<int, VGPT_ACT_SILU>{}, KF{});
+        } else if (g.act == VGPT_ACT_GELU) {
+            if (g.gu_out) gated_store(std::integral_constant<int, VGPT_ACT_GELU>{}, KT{});
+            else gated_store(std::integral_constant<int, VGPT_ACT_GELU>{}, KF{});
+        } else {
+            if (g.gu_out) gated_store(std::integral_constant<int, VGPT_ACT_GELU_TANH>{}, KT{});
+            else gated_store(std::integral_constant<int, VGPT_ACT_GELU_TANH>{}, KF{});
+        }
+    }
+}
+
 // Persistent walk: OFF unless VGPT_GEMM_PERSIST=1.  Measured in round 3 on one box (bench.py, same process order): sampler
 // step 31.996 ms with it against 32.03 without (gate_up 318 vs 322 us), stage-1 step 216.0 ms WITH it against 213.5 without --
 // hardware dispatch already starts the next workgroup's prologue while other CUs store, and it balances the ragged last
@@ -870,6 +1116,66 @@ BigPlan plan_big(int64_t M, int64_t n_out, int bn_out, int64_t nk) {
     return {M, whole};
 }
 
+// The four-wave kernel (gemm_w4_kernel).  VGPT_GEMM_W4=0 keeps the eight-wave kernels for same-box A/B runs.
+bool w4_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VGPT_GEMM_W4");
+        v = e ? (atoi(e) != 0) : 1;
+    }
+    return v != 0;
+}
+
+template <int MODE, int NI>
+int launch_w4_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
+    constexpr int LDS = 128 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_kernel<MODE, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            vgpt_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+            return VGPT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    constexpr int BN = NI * 32;
+    g.tiles_m = (int)cdiv(g.M, 256);
+    g.tiles_n = (int)cdiv(n_out, MODE == MODE_GATED ? BN / 2 : BN);
+    hipLaunchKernelGGL((gemm_w4_kernel<MODE, NI>), dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, s, g);
+    VGPT_CHECK_LAUNCH(name);
+    return VGPT_OK;
+}
+
+// Shapes the four-wave kernel takes: NT operands, at least two k-tiles, 8 rows / columns to clamp into, every byte offset the
+// loop forms below 2 GiB (A: relative to the tile's first row; W: relative to the matrix for the row-permuting modes)
+template <int MODE>
+bool w4_ok(const GemmArgs& g, int64_t n_out) {
+    const int64_t rows_w = MODE == MODE_GATED ? 2 * (int64_t)g.I : g.N;
+    if (g.K % BK != 0 || g.K < 2 * BK || g.M < 8 || n_out < 8 || rows_w < 8) return false;
+    if (MODE == MODE_GATED && g.I < 8) return false;
+    if ((256 + 8) * g.lda * 2 + (int64_t)g.K * 2 >= (1ll << 31)) return false;
+    if ((rows_w + 8) * g.ldw * 2 + (int64_t)g.K * 2 >= (1ll << 31)) return false;
+    return true;
+}
+
+// 256- or 192-wide tiles: rounds of 256 workgroups, a round of 192-wide tiles costs 3/4 of the k-loop (the loop is paced by
+// its MFMAs) plus the same fixed part
+template <int MODE>
+int launch_w4(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
+    const int64_t nk = g.K / BK, tiles_m = cdiv(g.M, 256);
+    const int64_t t256 = tiles_m * cdiv(n_out, MODE == MODE_GATED ? 128 : 256), t192 = tiles_m * cdiv(n_out, MODE == MODE_GATED ? 96 : 192);
+    const double FIXED = 7.0;
+    const double c256 = (double)cdiv(t256, cu_count()) * ((double)nk + FIXED), c192 = (double)cdiv(t192, cu_count()) * (0.75 * (double)nk + FIXED);
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("VGPT_GEMM_W4_NI");
+        forced = e ? atoi(e) : 0;
+    }
+    const bool use192 = forced == 6 || (forced != 8 && c192 < c256);
+    if (use192) return launch_w4_cfg<MODE, 6>(g, n_out, s, name);
+    return launch_w4_cfg<MODE, 8>(g, n_out, s, name);
+}
+
 template <int MODE, bool ATR = false, bool WTR = false>
 int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const int f = forced_tile();
@@ -879,6 +1185,9 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const int64_t big_tiles = tiles_m * tiles_n;
     const bool use256 = f == 256 || f == 257 || f == 192 || f == 288 || f == 289 || f == 512 || (f != 128 && big_tiles >= 128);
     if (!use256) return launch_cfg<MODE, Cfg128, 0, ATR, WTR>(g, n_out, s, name);
+    if constexpr (!ATR && !WTR) {
+        if (f == 0 && w4_enabled() && w4_ok<MODE>(g, n_out)) return launch_w4<MODE>(g, n_out, s, name);
+    }
     if (f == 257) return launch_cfg<MODE, Cfg256, 0, ATR, WTR>(g, n_out, s, name);
     if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
         if (f == 288) return launch_cfg<MODE, Cfg288, 5, ATR, WTR>(g, n_out, s, name);

@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled main loop of the four-wave bf16 GEMM (csrc/gemm_w4_loop.inc, included by gemm_bf16.hip).
+
+One workgroup = 4 waves (one per SIMD), tile 256 x (NI * 32) x 64, wave tile 128 x (NI * 16): MI = 8 A sub-tiles x NI W
+sub-tiles of v_mfma_f32_16x16x32_bf16, all NI * 32 accumulator registers in AGPRs.  Operands go global -> VGPR
+(buffer_load_dwordx4) -> LDS (ds_write_b128, the XOR-swizzled row images of gemm_bf16.hip) -> fragments (ds_read_b128),
+with every wait counted by hand:
+
+  iteration t = k-tile t, two k-steps of NI "steps" (step = one W sub-tile against the eight A sub-tiles = 8 MFMAs);
+  k-step 0 multiplies fragment set 0 (A0, W0) and meanwhile reads set 1 (k-step 1 of the same tile, LDS buffer t & 1);
+  ONE barrier; k-step 1 multiplies set 1 and reads set 0 of tile t + 1 (buffer (t + 1) & 1);
+  staging: the interval between two barriers (k-step 1 of tile t - 1, k-step 0 of tile t) writes the pieces of tile t + 1
+  into buffer (t + 1) & 1 -- free since the barrier of tile t - 1, first read behind the barrier of tile t -- one piece per
+  step: s_waitcnt vmcnt(P - 1) (its fetch was issued a whole tile ago), ds_write_b128, and the fetch of the same piece of
+  the tile after into the same registers.
+
+The text is emitted as ONE asm statement (prologue, loop, drain); the C++ around it computes the tile's addresses and runs
+the epilogue from the AGPRs.  `python gemm_w4_gen.py > ../gemm_w4_loop.inc`.
+"""
+import sys
+
+# ---- physical registers (the asm statement's clobber list covers them; the compiler keeps v0..v39 / the low SGPRs) ----
+V_R = 40          # staging registers: P pieces x 4
+V_A = (104, 136)  # A fragments, set 0 / 1: 8 x 4 each
+V_W = (168, 200)  # W fragments, set 0 / 1: up to 8 x 4 each
+V_RDA = (232, 233)  # LDS read address, A, k-step 0 / 1
+V_RDW = (234, 235)
+V_WRA, V_WRW = 236, 237
+V_VA, V_VW = 238, 239
+V_LAST = 239
+S_PA, S_PW = 40, 48  # per-piece byte offsets (A: 8, W: up to 8)
+S_KLOAD, S_KLAST, S_CNT, S_TMP = 56, 57, 58, 59
+S_FIRST, S_LAST = 40, 59
+BUF_XOR = 0x8000
+
+
+def vr(base, n=4):
+    return f"v[{base}:{base + n - 1}]"
+
+
+class Gen:
+    def __init__(self, NI):
+        self.NI = NI
+        self.PA, self.PW = 8, NI          # pieces per wave and k-tile
+        self.P = self.PA + self.PW
+        self.lines = []
+        self.lgkm = []                    # tags of issued LGKM operations, program order
+        self.done = 0                     # lgkm[:done] are known complete
+        self.waits = []                   # (iteration, position, text) of the counted waits, for the periodicity check
+        # staging order: A and W pieces interleaved so that both operands' fetches are spread over the interval; the first
+        # half is written in k-step 1 (of the tile before), the second half in k-step 0
+        order = []
+        for k in range(max(self.PA, self.PW)):
+            if k < self.PA: order.append(k)
+            if k < self.PW: order.append(self.PA + k)
+        self.first, self.second = order[:self.P // 2], order[self.P // 2:]
+
+    def emit(self, s):
+        self.lines.append(s)
+
+    # -- LGKM scoreboard --
+    def issue(self, tag):
+        self.lgkm.append(tag)
+
+    def need(self, tags, it=None):
+        idx = -1
+        for t in tags:
+            for k in range(len(self.lgkm) - 1, -1, -1):
+                if self.lgkm[k] == t:
+                    idx = max(idx, k)
+                    break
+            else:
+                raise RuntimeError(f"fragment {t} was never requested")
+        if idx < self.done:
+            return
+        n = len(self.lgkm) - 1 - idx
+        n = min(n, 15)
+        self.emit(f"s_waitcnt lgkmcnt({n})")
+        self.waits.append((it, len(self.lines), n))
+        self.done = len(self.lgkm) - n
+
+    def drain(self):
+        self.emit("s_waitcnt lgkmcnt(0)")
+        self.done = len(self.lgkm)
+
+    # -- pieces --
+    def piece_regs(self, p):
+        return V_R + 4 * p
+
+    def piece_soff(self, p):
+        return (S_PA + p) if p < self.PA else (S_PW + p - self.PA)
+
+    def load_piece(self, p):
+        srd, vo = ("%[srdA]", V_VA) if p < self.PA else ("%[srdW]", V_VW)
+        self.emit(f"s_add_u32 s{S_TMP}, s{self.piece_soff(p)}, s{S_KLOAD}")
+        self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, v{vo}, {srd}, s{S_TMP} offen")
+
+    def write_piece(self, p):
+        addr, q = (V_WRA, p) if p < self.PA else (V_WRW, p - self.PA)
+        self.emit(f"ds_write_b128 v{addr}, {vr(self.piece_regs(p))} offset:{q * 1024}")
+        self.issue(("wr", p))
+
+    # -- fragments --
+    def read_A(self, s, j):
+        self.emit(f"ds_read_b128 {vr(V_A[s] + 4 * j)}, v{V_RDA[s]} offset:{j * 2048}")
+        self.issue(("A", s, j))
+
+    def read_W(self, s, i):
+        self.emit(f"ds_read_b128 {vr(V_W[s] + 4 * i)}, v{V_RDW[s]} offset:{i * 2048}")
+        self.issue(("W", s, i))
+
+    def mfma(self, s, i, j, it):
+        self.need([("A", s, j), ("W", s, i)], it)
+        a = (i * 8 + j) * 4
+        self.emit(f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], {vr(V_W[s] + 4 * i)}, {vr(V_A[s] + 4 * j)}, a[{a}:{a + 3}]")
+
+    def kstep(self, s, pieces, it):
+        """NI steps of 8 MFMAs on fragment set s; meanwhile: the reads of set s ^ 1, the given staging pieces, and the
+        address toggles.  Nothing but MFMAs in the last step (the barrier / the loop edge follows)."""
+        NI = self.NI
+        o = s ^ 1
+        reads = [("A", j) for j in range(8)] + [("W", i) for i in range(NI)]
+        nsteps = NI - 1                                    # steps that carry side work
+        def spread(n):                                     # n items over nsteps steps, front-loaded
+            base, extra = divmod(n, nsteps)
+            return [base + (1 if k < extra else 0) for k in range(nsteps)]
+        rd_per, pc_per = spread(len(reads)), spread(len(pieces))
+        ri = pi = 0
+        for i in range(NI):
+            side = []                                      # (slot after MFMA j, callable)
+            if i < nsteps:
+                slots_r = [0, 1, 2][:rd_per[i]] if rd_per[i] <= 3 else list(range(rd_per[i]))
+                for k in range(rd_per[i]):
+                    kind, x = reads[ri]; ri += 1
+                    side.append((slots_r[k], (lambda kind=kind, x=x: self.read_A(o, x) if kind == "A" else self.read_W(o, x))))
+                slot_w = [3, 5]
+                slot_l = [4, 6]
+                for k in range(pc_per[i]):
+                    p = pieces[pi]; pi += 1
+                    def wr(p=p):
+                        self.emit(f"s_waitcnt vmcnt({self.P - 1})")
+                        self.write_piece(p)
+                    side.append((slot_w[k] if k < 2 else 7, wr))
+                    side.append((slot_l[k] if k < 2 else 7, (lambda p=p: self.load_piece(p))))
+            if i == NI - 1:
+                # address toggles (VALU, no memory operation): the read addresses of the set just requested from
+                def tog():
+                    self.emit(f"v_xor_b32 v{V_RDA[o]}, 0x{BUF_XOR:x}, v{V_RDA[o]}")
+                    self.emit(f"v_xor_b32 v{V_RDW[o]}, 0x{BUF_XOR:x}, v{V_RDW[o]}")
+                side.append((1, tog))
+            for j in range(8):
+                self.mfma(s, i, j, it)
+                for slot, fn in side:
+                    if slot == j:
+                        fn()
+        assert ri == len(reads) and pi == len(pieces)
+
+    def body(self, it):
+        P, PA, PW = self.P, self.PA, self.PW
+        first, second = self.first, self.second
+        # k-step 0: set 0; reads set 1 of this tile; writes the second half of tile t + 1, refetches it for tile t + 2
+        self.kstep(0, second, it)
+        self.drain()
+        self.emit("s_barrier")
+        self.emit(f"v_xor_b32 v{V_WRA}, 0x{BUF_XOR:x}, v{V_WRA}")
+        self.emit(f"v_xor_b32 v{V_WRW}, 0x{BUF_XOR:x}, v{V_WRW}")
+        self.emit(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
+        self.emit(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
+        self.emit(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+        # k-step 1: set 1; reads set 0 of tile t + 1; writes the first half of tile t + 2, refetches it for tile t + 3
+        self.kstep(1, first, it)
+
+    def generate(self):
+        NI, P, PA, PW = self.NI, self.P, self.PA, self.PW
+        e = self.emit
+        lab = f"%="
+        # ---- prologue ----
+        e(f"v_mov_b32 v{V_RDA[0]}, %[rdA]")
+        e(f"v_xor_b32 v{V_RDA[1]}, 64, %[rdA]")
+        e(f"v_mov_b32 v{V_RDW[0]}, %[rdW]")
+        e(f"v_xor_b32 v{V_RDW[1]}, 64, %[rdW]")
+        e(f"v_mov_b32 v{V_WRA}, %[wrA]")
+        e(f"v_mov_b32 v{V_WRW}, %[wrW]")
+        e(f"v_mov_b32 v{V_VA}, %[va]")
+        e(f"v_mov_b32 v{V_VW}, %[vw]")
+        for p in range(PA):
+            e(f"v_readlane_b32 s{S_PA + p}, %[tab], {p}")
+        for p in range(PW):
+            e(f"v_readlane_b32 s{S_PW + p}, %[tab], {8 + p}")
+        e(f"s_mov_b32 s{S_KLOAD}, 0")
+        e(f"s_sub_u32 s{S_KLAST}, %[nk], 1")
+        e(f"s_lshl_b32 s{S_KLAST}, s{S_KLAST}, 7")
+        e(f"s_mov_b32 s{S_CNT}, %[nk]")
+        e("s_nop 4")                                       # v_readlane (VALU writes SGPR) -> SALU / VMEM readers
+        first, second = self.first, self.second
+        order = first + second
+        for p in order:                                    # tile 0
+            self.load_piece(p)
+        for a in range(0, NI * 32, 1):                     # accumulators = 0 while the fetches fly
+            e(f"v_accvgpr_write_b32 a{a}, 0")
+        e("s_waitcnt vmcnt(0)")
+        for p in order:
+            self.write_piece(p)
+        e(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
+        e(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
+        for p in order:                                    # tile 1 (fetch order = the loop's consumption order)
+            self.load_piece(p)
+        e(f"v_xor_b32 v{V_WRA}, 0x{BUF_XOR:x}, v{V_WRA}")
+        e(f"v_xor_b32 v{V_WRW}, 0x{BUF_XOR:x}, v{V_WRW}")
+        e(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
+        e(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
+        for p in first:                                    # "k-step 1 of tile -1": first half of tile 1 -> buffer 1, refetch for tile 2
+            e(f"s_waitcnt vmcnt({P - 1})")
+            self.write_piece(p)
+            self.load_piece(p)
+        self.drain()
+        e("s_barrier")
+        for j in range(8):
+            self.read_A(0, j)
+        for i in range(NI):
+            self.read_W(0, i)
+        # the read addresses of set 0 now point at the buffer of tile 1 (they are toggled at the end of every k-step 1 ... see kstep)
+        e(f"v_xor_b32 v{V_RDA[0]}, 0x{BUF_XOR:x}, v{V_RDA[0]}")
+        e(f"v_xor_b32 v{V_RDW[0]}, 0x{BUF_XOR:x}, v{V_RDW[0]}")
+        self.drain()
+        # ---- loop: the body is generated three times on the scoreboard; the text of the last two must agree ----
+        texts = []
+        for it in range(3):
+            n0 = len(self.lines)
+            self.body(it)
+            texts.append(self.lines[n0:])
+            del self.lines[n0:]
+        assert texts[1] == texts[2], "the counted waits are not periodic"
+        e(f"1:")
+        self.lines.extend(texts[2])
+        e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+        e(f"s_cbranch_scc1 1b")
+        # ---- drain ----
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e("s_nop 15")
+        e("s_nop 15")
+        return self.lines
+
+
+def c_string(lines):
+    return "\n".join('    "' + l + '\\n\\t"' for l in lines)
+
+
+def main():
+    out = ["// GENERATED by gen/gemm_w4_gen.py -- do not edit; `make gemm_w4_loop.inc` regenerates it.",
+           "// The hand-scheduled main loop of gemm_w4_kernel (gemm_bf16.hip): see the generator for the schedule.",
+           ""]
+    for NI in (8, 6):
+        g = Gen(NI)
+        lines = g.generate()
+        n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
+        out.append(f"// NI = {NI}: {len(lines)} lines, {n_mfma} MFMAs in the text (loop body {NI * 16})")
+        out.append(f"#define VGPT_W4_ASM_NI{NI} \\")
+        out.append(" \\\n".join('    "' + l + '\\n\\t"' for l in lines))
+        out.append("")
+    cl = [f'"v{i}"' for i in range(V_R, V_LAST + 1)] + [f'"a{i}"' for i in range(256)] + \
+         [f'"s{i}"' for i in range(S_FIRST, S_LAST + 1)] + ['"scc"', '"memory"']
+    out.append("#define VGPT_W4_CLOBBERS \\")
+    rows = [", ".join(cl[k:k + 16]) for k in range(0, len(cl), 16)]
+    out.append(", \\\n".join("    " + r for r in rows))
+    out.append("")
+    sys.stdout.write("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
