@@ -103,6 +103,13 @@ int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const void* extra, 
                       int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int epilogue, int a_transposed,
                       int w_transposed, void* stream);
 
+/* Kernel family of the big NT products behind vgpt_gemm_bf16 / vgpt_gemm_bf16_rope / vgpt_gated_mlp_act_fwd[_keep]:
+ * 0 (default) = the four-wave kernel with the hand-scheduled register-staged loop wherever it applies (K a multiple of 64
+ * with at least two k-tiles, 128 or more 256-row tiles), 1 = the eight-wave LDS-DMA kernels only.  Same operand contract and
+ * epilogues; results differ by the order of the fp32 additions inside a k-tile.  Process-wide, not thread-safe: a test and
+ * measurement switch, set before the launches it is meant for.  Returns the previous value; other values change nothing. */
+int vgpt_gemm_set_family(int family);
+
 /* Phi3MLP first half, fused: out[M,I] = act(A Wg^T) * (A Wu^T) where
  * W_gate_up (2I, K) = [Wg ; Wu] as stored by Phi3MLP.gate_up_proj.
  * K % 64 == 0, I % 64 == 0. */

@@ -34,6 +34,7 @@ SIGNATURES = {
     "vgpt_gemm_bf16": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
     "vgpt_gemm_bf16_rope": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_int, _P]),
     "vgpt_gemm_bf16_tr": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_int, c_int, _P]),
+    "vgpt_gemm_set_family": (c_int, [c_int]),
     "vgpt_gated_mlp_act_fwd": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
     "vgpt_gated_mlp_act_fwd_keep": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
     "vgpt_mask_pack_bool": (c_int, [_P, _P, _I64, _I64, _P]),

@@ -126,6 +126,7 @@ struct GemmArgs {
     // the plain GEMM followed by vgpt_silu_mul_fwd produces; null: inference (activation from the fp32 accumulators)
     bf16* gu_out = nullptr;
     int64_t ld_gu = 0;
+    uint32_t* dbg = nullptr;   // diagnostics builds of the four-wave kernel only
 };
 
 
@@ -777,7 +778,19 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
 // XOR-swizzled row images as above) with counted waits, one barrier per k-tile.  NT operands, K % 64 == 0, nk >= 2.
 // The loop is ONE asm statement; the C++ here computes the tile's addresses (the per-piece row offsets travel in the lanes
 // of one VGPR) and runs the epilogue straight from the accumulator registers.
-#include "gemm_w4_loop.inc"
+#ifndef VGPT_W4_INC
+#define VGPT_W4_INC "gemm_w4_loop.inc"
+#endif
+#include VGPT_W4_INC
+// diagnostics builds only (make gemm-w4-debug-N with bit 16): the loop's stamps leave the asm statement as outputs and go to
+// a buffer set through vgpt_gemm_w4_debug_buffer: per (workgroup, wave) {loop cycles, loop time in 10-ns ticks, cycles at the
+// barriers, k-tiles}
+#ifdef VGPT_W4_STAMPS
+#define VGPT_W4_OUTS [cyc] "=s"(st_cyc), [rt] "=s"(st_rt), [bar] "=s"(st_bar)
+uint32_t* g_w4_dbg = nullptr;
+#else
+#define VGPT_W4_OUTS
+#endif
 
 template <int I0, int N0, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -788,6 +801,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // accumulator quad IDX (registers a[4 IDX .. 4 IDX + 3]) of the asm loop
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
 template <int IDX>
 __device__ __forceinline__ f32x4 w4_acc() {
     float x0, x1, x2, x3;
@@ -829,26 +844,22 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     const int n_rows_w = (MODE == MODE_GATED) ? 2 * g.I : g.N;
 
     // ---- operands of the loop ----
+    // per piece and lane: byte offset of the 16 bytes this lane fetches, relative to the tile's first A row (oa) / to the W
+    // origin below (ow); rows clamped per lane into the matrix (rows past M / columns past N are computed and never stored)
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-    const uint32_t va = (uint32_t)(srow * (int)g.lda + schunk * 8) * 2u;
-    const uint32_t vw = (uint32_t)(srow * (int)g.ldw + schunk * 8) * 2u;
-    // lane p < 8: byte offset of the 8-row A piece p of this wave (rows clamped into the matrix: rows past M are never
-    // stored); lane 8 + p: of its W piece p (8 weight rows behind 8 consecutive n-slots)
-    uint32_t tab = 0;
-    {
-        const int pa = lane & 7;
-        const int ra = min((wave * 8 + pa) * 8, max(g.M - m0 - 8, 0));
-        const int pw = min(max(lane - 8, 0), NI - 1);
-        const int s8 = (wave * NI + pw) * 8;   // first n-slot of the piece inside the tile
-        int rw;
-        if constexpr (MODE == MODE_GATED) {
-            rw = ((s8 >> 4) & 1 ? g.I : 0) + min(n0 + (s8 >> 5) * 16 + (s8 & 15), g.I - 8);
-        } else if constexpr (ROPE) {
-            rw = min(rope_col_of_slot(n0 + s8, g.rope_cols, g.head_dim), n_rows_w - 8);
-        } else {
-            rw = min(s8, max(g.N - n0 - 8, 0));
-        }
-        tab = lane < 8 ? (uint32_t)(ra * (int)g.lda) * 2u : (uint32_t)(rw * (int)g.ldw) * 2u;
+    uint32_t oa[8], ow[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int r = min((wave * 8 + p) * 8 + srow, g.M - 1 - m0);
+        oa[p] = (uint32_t)(r * (int)g.lda + schunk * 8) * 2u;
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int sl = (wave * NI + min(p, NI - 1)) * 8 + srow;   // n-slot inside the tile
+        int wr;
+        if constexpr (ROPE) wr = min(rope_col_of_slot(n0 + sl, g.rope_cols, g.head_dim), n_rows_w - 1);
+        else wr = min(w_row_of_slot<MODE>(n0, sl, g.I), n_rows_w - 1) - (MODE == MODE_GATED ? 0 : n0);
+        ow[p] = (uint32_t)(wr * (int)g.ldw + schunk * 8) * 2u;
     }
     const bf16* a_org = g.A + (int64_t)m0 * g.lda;
     const bf16* w_org = (MODE == MODE_GATED || ROPE) ? g.W : g.W + (int64_t)n0 * g.ldw;
@@ -870,22 +881,45 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     const uint32_t wrW = (uint32_t)(2 * A_BYTES + wave * NI * 1024 + lane * 16);
     const int nk = __builtin_amdgcn_readfirstlane(g.K / BK);
 
+    [[maybe_unused]] uint32_t st_cyc = 0, st_rt = 0, st_bar = 0;
     if constexpr (NI == 8) {
         asm volatile(VGPT_W4_ASM_NI8
-                     :
-                     : [srdA] "s"(srdA), [srdW] "s"(srdW), [tab] "v"(tab), [va] "v"(va), [vw] "v"(vw), [rdA] "v"(rdA),
-                       [rdW] "v"(rdW), [wrA] "v"(wrA), [wrW] "v"(wrW), [nk] "s"(nk)
+                     : VGPT_W4_OUTS
+                     : [srdA] "s"(srdA), [srdW] "s"(srdW), [rdA] "v"(rdA), [rdW] "v"(rdW), [wrA] "v"(wrA), [wrW] "v"(wrW), [nk] "s"(nk),
+                       [oa0] "v"(oa[0]), [oa1] "v"(oa[1]), [oa2] "v"(oa[2]), [oa3] "v"(oa[3]), [oa4] "v"(oa[4]), [oa5] "v"(oa[5]),
+                       [oa6] "v"(oa[6]), [oa7] "v"(oa[7]), [ow0] "v"(ow[0]), [ow1] "v"(ow[1]), [ow2] "v"(ow[2]), [ow3] "v"(ow[3]),
+                       [ow4] "v"(ow[4]), [ow5] "v"(ow[5]), [ow6] "v"(ow[6]), [ow7] "v"(ow[7])
                      : VGPT_W4_CLOBBERS);
     } else {
         asm volatile(VGPT_W4_ASM_NI6
-                     :
-                     : [srdA] "s"(srdA), [srdW] "s"(srdW), [tab] "v"(tab), [va] "v"(va), [vw] "v"(vw), [rdA] "v"(rdA),
-                       [rdW] "v"(rdW), [wrA] "v"(wrA), [wrW] "v"(wrW), [nk] "s"(nk)
+                     : VGPT_W4_OUTS
+                     : [srdA] "s"(srdA), [srdW] "s"(srdW), [rdA] "v"(rdA), [rdW] "v"(rdW), [wrA] "v"(wrA), [wrW] "v"(wrW), [nk] "s"(nk),
+                       [oa0] "v"(oa[0]), [oa1] "v"(oa[1]), [oa2] "v"(oa[2]), [oa3] "v"(oa[3]), [oa4] "v"(oa[4]), [oa5] "v"(oa[5]),
+                       [oa6] "v"(oa[6]), [oa7] "v"(oa[7]), [ow0] "v"(ow[0]), [ow1] "v"(ow[1]), [ow2] "v"(ow[2]), [ow3] "v"(ow[3]),
+                       [ow4] "v"(ow[4]), [ow5] "v"(ow[5])
                      : VGPT_W4_CLOBBERS);
     }
 
-    // ---- epilogue: lane holds m = lane & 15, n = (lane >> 4) * 4 + reg of each 16 x 16 sub-tile (i: n, j: m) ----
+#ifdef VGPT_W4_STAMPS
+    if (g.dbg && lane == 0) {
+        uint32_t* d = g.dbg + (blockIdx.x * 4 + wave) * 4;
+        d[0] = st_cyc; d[1] = st_rt; d[2] = st_bar; d[3] = (uint32_t)nk;
+    }
+#endif
+    // ---- epilogue: lane holds m = lane & 15, n = (lane >> 4) * 4 + reg of each 16 x 16 sub-tile (i: n, j: m).  Branch-free:
+    //      outputs (and the residual) go through buffer descriptors anchored at the tile's origin, and a lane whose row or
+    //      column lies outside the matrix gets an offset past the descriptor's range -- its loads return zeros, its stores are
+    //      dropped -- so every row is one basic block (the residual quads of row j + 1 are requested before row j is stored) ----
     const int em = lane & 15, en = (lane >> 4) * 4;
+    constexpr uint32_t OOB = 0x80000000u;
+    auto make_rs = [](const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); };
+    auto pack4 = [](const f32x4& v) {
+        bf16x4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = f2bf(v[t]);
+        return __builtin_bit_cast(u32x2_t, o);
+    };
+    const int nl0 = wn * (NI * 16) + en;                      // this lane's first slot inside the tile
     if constexpr (ROPE) {
         // as gemm_bf16_kernel: product rounded to bf16, rotated in fp32 with the partner column from lane ^ 32, the cos / sin
         // rows of the tile staged through the (now free) LDS
@@ -906,99 +940,117 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        const auto rsC = make_rs(g.C + (int64_t)m0 * g.ldc);
         const bool upper = (lane & 32) != 0;
         static_for<0, MI>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const int ml = wm * 128 + j * 16 + em;
-            const int m = m0 + ml;
-            const bool m_ok = m < g.M;
+            const bool m_ok = m0 + ml < g.M;
+            const int mr = m_ok ? ml : 0;
             static_for<0, NI>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                const int gs = n0 + wn * (NI * 16) + i * 16 + en;
-                if (gs >= g.N) return;          // N % 16 == 0: uniform over a lane and its partner
+                const int gs = n0 + nl0 + i * 16;
                 const int n = rope_col_of_slot(gs, g.rope_cols, g.head_dim);
-                const f32x4 v = w4_acc<i * 8 + j>();
-                bf16x4 o;
-                if (gs < g.rope_cols) {
+                f32x4 v = w4_acc<i * 8 + j>();
+                if (gs < g.rope_cols) {                       // wave-uniform: rope_cols is a multiple of 16
                     const int d = (n % g.head_dim) - (upper ? half : 0);
-                    const int mr = m_ok ? ml : 0;
                     f32x4 cs, sn;
                     if (staged) {
                         cs = *reinterpret_cast<const f32x4*>(smem + (mr * half + d) * 4);
                         sn = *reinterpret_cast<const f32x4*>(smem + tab_bytes + (mr * half + d) * 4);
                     } else {
-                        const int64_t mg = m_ok ? m : 0;
-                        cs = *reinterpret_cast<const f32x4*>(g.rope_cos + mg * half + d);
-                        sn = *reinterpret_cast<const f32x4*>(g.rope_sin + mg * half + d);
+                        cs = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)(m0 + mr) * half + d);
+                        sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)(m0 + mr) * half + d);
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const float own = bf2f(f2bf(v[t]));
                         auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
                         const float other = __uint_as_float(upper ? sw2[0] : sw2[1]);
-                        o[t] = f2bf(upper ? own * cs[t] + other * sn[t] : own * cs[t] - other * sn[t]);
+                        v[t] = upper ? own * cs[t] + other * sn[t] : own * cs[t] - other * sn[t];
                     }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) o[t] = f2bf(v[t]);
                 }
-                if (m_ok) store_out4(g.C + (int64_t)m * g.ldc + n, o);
+                const uint32_t off = (m_ok && gs < g.N) ? (uint32_t)(ml * (int)g.ldc + n) * 2u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(pack4(v), rsC, off, 0, 0);
             });
         });
     } else if constexpr (MODE == MODE_PLAIN) {
-        static_for<0, MI>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const int m = m0 + wm * 128 + j * 16 + em;
-            if (m >= g.M) return;
-            static_for<0, NI>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const int n = n0 + wn * (NI * 16) + i * 16 + en;
-                if (n >= g.N) return;
-                f32x4 v = w4_acc<i * 8 + j>();
-                if (g.epi == VGPT_EPI_RESID) {
-                    bf16x4 r = *reinterpret_cast<const bf16x4*>(g.extra + (int64_t)m * g.ldr + n);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] += bf2f(r[t]);
-                } else if (g.epi == VGPT_EPI_BIAS) {
-                    bf16x4 r = *reinterpret_cast<const bf16x4*>(g.extra + n);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] += bf2f(r[t]);
+        auto plain_store = [&](auto epic) {
+            constexpr int EPI = decltype(epic)::value;
+            const auto rsC = make_rs(g.C + (int64_t)m0 * g.ldc + n0);
+            const bf16* rbase = EPI == VGPT_EPI_RESID ? g.extra + (int64_t)m0 * g.ldr + n0 : (EPI == VGPT_EPI_BIAS ? g.extra + n0 : g.C);
+            const auto rsR = make_rs(rbase);
+            u32x2_t r[2][NI];
+            auto request = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (EPI != VGPT_EPI_NONE && j < MI) {
+                    const int ml = wm * 128 + j * 16 + em;
+                    const bool row_ok = m0 + ml < g.M;
+                    static_for<0, NI>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        const int nl = nl0 + i * 16;
+                        const bool ok = row_ok && n0 + nl < g.N;
+                        const uint32_t off = EPI == VGPT_EPI_RESID ? (uint32_t)(ml * (int)g.ldr + nl) * 2u : (uint32_t)nl * 2u;
+                        r[j & 1][i] = __builtin_amdgcn_raw_buffer_load_b64(rsR, ok ? off : OOB, 0, 0);
+                    });
                 }
-                bf16x4 o;
+            };
+            request(std::integral_constant<int, 0>{});
+            static_for<0, MI>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                request(std::integral_constant<int, j + 1>{});
+                const int ml = wm * 128 + j * 16 + em;
+                const bool row_ok = m0 + ml < g.M;
+                static_for<0, NI>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const int nl = nl0 + i * 16;
+                    const bool ok = row_ok && n0 + nl < g.N;
+                    f32x4 v = w4_acc<i * 8 + j>();
+                    if constexpr (EPI != VGPT_EPI_NONE) {
+                        const bf16x4 rb = __builtin_bit_cast(bf16x4, r[j & 1][i]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = f2bf(v[t]);
-                store_out4(g.C + (int64_t)m * g.ldc + n, o);
+                        for (int t = 0; t < 4; ++t) v[t] += bf2f(rb[t]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(pack4(v), rsC, ok ? (uint32_t)(ml * (int)g.ldc + nl) * 2u : OOB, 0, 0);
+                });
             });
-        });
+        };
+        if (g.epi == VGPT_EPI_RESID) plain_store(std::integral_constant<int, VGPT_EPI_RESID>{});
+        else if (g.epi == VGPT_EPI_BIAS) plain_store(std::integral_constant<int, VGPT_EPI_BIAS>{});
+        else plain_store(std::integral_constant<int, VGPT_EPI_NONE>{});
     } else {
         auto gated_store = [&](auto actc, auto keepc) {
             constexpr int ACT = decltype(actc)::value;
             constexpr bool KEEP = decltype(keepc)::value;
+            const auto rsC = make_rs(g.C + (int64_t)m0 * g.ldc + n0);
+            const auto rsG = make_rs(KEEP ? g.gu_out + (int64_t)m0 * g.ld_gu + n0 : g.C);
+            const int ol0 = wn * (NI / 2) * 16 + en;          // this lane's first OUTPUT column inside the tile
             static_for<0, MI>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                const int m = m0 + wm * 128 + j * 16 + em;
-                if (m >= g.M) return;
+                const int ml = wm * 128 + j * 16 + em;
+                const bool row_ok = m0 + ml < g.M;
                 static_for<0, NI / 2>([&](auto pc) {
                     constexpr int p = decltype(pc)::value;
-                    const int n = n0 + (wn * (NI / 2) + p) * 16 + en;  // output column
-                    if (n >= g.I) return;
+                    const int nl = ol0 + p * 16;
+                    const bool ok = row_ok && n0 + nl < g.I;
                     const f32x4 gate = w4_acc<(2 * p) * 8 + j>(), up = w4_acc<(2 * p + 1) * 8 + j>();
-                    bf16x4 o;
+                    f32x4 o;
                     if constexpr (KEEP) {
                         bf16x4 gb, ub;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             gb[t] = f2bf(gate[t]);
                             ub[t] = f2bf(up[t]);
-                            o[t] = f2bf(act_apply(bf2f(gb[t]), ACT) * bf2f(ub[t]));
+                            o[t] = act_apply(bf2f(gb[t]), ACT) * bf2f(ub[t]);
                         }
-                        store_out4(g.gu_out + (int64_t)m * g.ld_gu + n, gb);
-                        store_out4(g.gu_out + (int64_t)m * g.ld_gu + g.I + n, ub);
+                        const uint32_t og = ok ? (uint32_t)(ml * (int)g.ld_gu + nl) * 2u : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, gb), rsG, og, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ub), rsG, og, g.I * 2, 0);
                     } else {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) o[t] = f2bf(act_apply(gate[t], ACT) * up[t]);
+                        for (int t = 0; t < 4; ++t) o[t] = act_apply(gate[t], ACT) * up[t];
                     }
-                    store_out4(g.C + (int64_t)m * g.ldc + n, o);
+                    __builtin_amdgcn_raw_buffer_store_b64(pack4(o), rsC, ok ? (uint32_t)(ml * (int)g.ldc + nl) * 2u : OOB, 0, 0);
                 });
             });
         };
@@ -1116,15 +1168,10 @@ BigPlan plan_big(int64_t M, int64_t n_out, int bn_out, int64_t nk) {
     return {M, whole};
 }
 
-// The four-wave kernel (gemm_w4_kernel).  VGPT_GEMM_W4=0 keeps the eight-wave kernels for same-box A/B runs.
-bool w4_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("VGPT_GEMM_W4");
-        v = e ? (atoi(e) != 0) : 1;
-    }
-    return v != 0;
-}
+// Which kernel family big NT products take: 0 = the four-wave kernel wherever w4_ok() (default), 1 = the eight-wave LDS-DMA
+// kernels only (parity tests run both; same-box A/B).  Set through vgpt_gemm_set_family.
+int g_family = 0;
+bool w4_enabled() { return g_family == 0; }
 
 template <int MODE, int NI>
 int launch_w4_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
@@ -1139,6 +1186,9 @@ int launch_w4_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
         attr_set = true;
     }
     constexpr int BN = NI * 32;
+#ifdef VGPT_W4_STAMPS
+    g.dbg = g_w4_dbg;
+#endif
     g.tiles_m = (int)cdiv(g.M, 256);
     g.tiles_n = (int)cdiv(n_out, MODE == MODE_GATED ? BN / 2 : BN);
     hipLaunchKernelGGL((gemm_w4_kernel<MODE, NI>), dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, s, g);
@@ -1155,6 +1205,7 @@ bool w4_ok(const GemmArgs& g, int64_t n_out) {
     if (MODE == MODE_GATED && g.I < 8) return false;
     if ((256 + 8) * g.lda * 2 + (int64_t)g.K * 2 >= (1ll << 31)) return false;
     if ((rows_w + 8) * g.ldw * 2 + (int64_t)g.K * 2 >= (1ll << 31)) return false;
+    if (g.ldc >= (1 << 21) || g.ldr >= (1 << 21) || g.ld_gu >= (1 << 21)) return false;   // 256 rows x ld x 2 bytes below the descriptors' range
     return true;
 }
 
@@ -1244,6 +1295,16 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 
 }  // namespace
+
+#ifdef VGPT_W4_STAMPS
+VGPT_EXPORT int vgpt_gemm_w4_debug_buffer(void* p) { g_w4_dbg = (uint32_t*)p; return 0; }
+#endif
+
+VGPT_EXPORT int vgpt_gemm_set_family(int family) {
+    const int prev = g_family;
+    if (family == 0 || family == 1) g_family = family;
+    return prev;
+}
 
 VGPT_EXPORT int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void* extra, int64_t M,
                                int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,

@@ -26,11 +26,14 @@ V_W = (168, 200)  # W fragments, set 0 / 1: up to 8 x 4 each
 V_RDA = (232, 233)  # LDS read address, A, k-step 0 / 1
 V_RDW = (234, 235)
 V_WRA, V_WRW = 236, 237
-V_VA, V_VW = 238, 239
-V_LAST = 239
-S_PA, S_PW = 40, 48  # per-piece byte offsets (A: 8, W: up to 8)
-S_KLOAD, S_KLAST, S_CNT, S_TMP = 56, 57, 58, 59
-S_FIRST, S_LAST = 40, 59
+V_OA, V_OW = 240, 248   # per-piece, per-lane source byte offsets (A: 8, W: up to 8): row clamped per lane, chunk swizzled
+V_LAST = 255
+S_KLOAD, S_KLAST, S_CNT = 56, 57, 58
+S_FIRST, S_LAST = 56, 71
+# diagnostics (python gemm_w4_gen.py --debug N; results are garbage unless N == 16): 1 = no global fetches in the loop,
+# 2 = no LDS writes, 4 = no fragment reads, 8 = no barrier, 16 = s_memtime / s_memrealtime stamps around the loop and around
+# every barrier (outputs %[cyc], %[rt], %[bar]: loop cycles, loop time in 10-ns ticks, cycles spent at the barriers)
+DEBUG = 0
 BUF_XOR = 0x8000
 
 
@@ -87,25 +90,29 @@ class Gen:
     def piece_regs(self, p):
         return V_R + 4 * p
 
-    def piece_soff(self, p):
-        return (S_PA + p) if p < self.PA else (S_PW + p - self.PA)
+    def load_piece(self, p, in_loop=True):
+        if in_loop and (DEBUG & 1):
+            return
+        srd, vo = ("%[srdA]", V_OA + p) if p < self.PA else ("%[srdW]", V_OW + p - self.PA)
+        self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, v{vo}, {srd}, s{S_KLOAD} offen")
 
-    def load_piece(self, p):
-        srd, vo = ("%[srdA]", V_VA) if p < self.PA else ("%[srdW]", V_VW)
-        self.emit(f"s_add_u32 s{S_TMP}, s{self.piece_soff(p)}, s{S_KLOAD}")
-        self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, v{vo}, {srd}, s{S_TMP} offen")
-
-    def write_piece(self, p):
+    def write_piece(self, p, in_loop=True):
+        if in_loop and (DEBUG & 2):
+            return
         addr, q = (V_WRA, p) if p < self.PA else (V_WRW, p - self.PA)
         self.emit(f"ds_write_b128 v{addr}, {vr(self.piece_regs(p))} offset:{q * 1024}")
         self.issue(("wr", p))
 
     # -- fragments --
-    def read_A(self, s, j):
+    def read_A(self, s, j, in_loop=True):
+        if in_loop and (DEBUG & 4):
+            self.issue(("A", s, j)); self.done = len(self.lgkm); return
         self.emit(f"ds_read_b128 {vr(V_A[s] + 4 * j)}, v{V_RDA[s]} offset:{j * 2048}")
         self.issue(("A", s, j))
 
-    def read_W(self, s, i):
+    def read_W(self, s, i, in_loop=True):
+        if in_loop and (DEBUG & 4):
+            self.issue(("W", s, i)); self.done = len(self.lgkm); return
         self.emit(f"ds_read_b128 {vr(V_W[s] + 4 * i)}, v{V_RDW[s]} offset:{i * 2048}")
         self.issue(("W", s, i))
 
@@ -138,7 +145,8 @@ class Gen:
                 for k in range(pc_per[i]):
                     p = pieces[pi]; pi += 1
                     def wr(p=p):
-                        self.emit(f"s_waitcnt vmcnt({self.P - 1})")
+                        if not (DEBUG & 1):
+                            self.emit(f"s_waitcnt vmcnt({self.P - 1})")
                         self.write_piece(p)
                     side.append((slot_w[k] if k < 2 else 7, wr))
                     side.append((slot_l[k] if k < 2 else 7, (lambda p=p: self.load_piece(p))))
@@ -161,7 +169,16 @@ class Gen:
         # k-step 0: set 0; reads set 1 of this tile; writes the second half of tile t + 1, refetches it for tile t + 2
         self.kstep(0, second, it)
         self.drain()
-        self.emit("s_barrier")
+        if DEBUG & 16:
+            self.emit("s_memtime s[60:61]")
+            self.emit("s_waitcnt lgkmcnt(0)")
+        if not (DEBUG & 8):
+            self.emit("s_barrier")
+        if DEBUG & 16:
+            self.emit("s_memtime s[62:63]")
+            self.emit("s_waitcnt lgkmcnt(0)")
+            self.emit("s_sub_u32 s62, s62, s60")
+            self.emit("s_add_u32 s64, s64, s62")
         self.emit(f"v_xor_b32 v{V_WRA}, 0x{BUF_XOR:x}, v{V_WRA}")
         self.emit(f"v_xor_b32 v{V_WRW}, 0x{BUF_XOR:x}, v{V_WRW}")
         self.emit(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
@@ -181,48 +198,52 @@ class Gen:
         e(f"v_xor_b32 v{V_RDW[1]}, 64, %[rdW]")
         e(f"v_mov_b32 v{V_WRA}, %[wrA]")
         e(f"v_mov_b32 v{V_WRW}, %[wrW]")
-        e(f"v_mov_b32 v{V_VA}, %[va]")
-        e(f"v_mov_b32 v{V_VW}, %[vw]")
         for p in range(PA):
-            e(f"v_readlane_b32 s{S_PA + p}, %[tab], {p}")
+            e(f"v_mov_b32 v{V_OA + p}, %[oa{p}]")
         for p in range(PW):
-            e(f"v_readlane_b32 s{S_PW + p}, %[tab], {8 + p}")
+            e(f"v_mov_b32 v{V_OW + p}, %[ow{p}]")
         e(f"s_mov_b32 s{S_KLOAD}, 0")
         e(f"s_sub_u32 s{S_KLAST}, %[nk], 1")
         e(f"s_lshl_b32 s{S_KLAST}, s{S_KLAST}, 7")
         e(f"s_mov_b32 s{S_CNT}, %[nk]")
-        e("s_nop 4")                                       # v_readlane (VALU writes SGPR) -> SALU / VMEM readers
         first, second = self.first, self.second
         order = first + second
         for p in order:                                    # tile 0
-            self.load_piece(p)
+            self.load_piece(p, False)
         for a in range(0, NI * 32, 1):                     # accumulators = 0 while the fetches fly
             e(f"v_accvgpr_write_b32 a{a}, 0")
         e("s_waitcnt vmcnt(0)")
         for p in order:
-            self.write_piece(p)
+            self.write_piece(p, False)
         e(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
         e(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
         for p in order:                                    # tile 1 (fetch order = the loop's consumption order)
-            self.load_piece(p)
+            self.load_piece(p, False)
         e(f"v_xor_b32 v{V_WRA}, 0x{BUF_XOR:x}, v{V_WRA}")
         e(f"v_xor_b32 v{V_WRW}, 0x{BUF_XOR:x}, v{V_WRW}")
         e(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
         e(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
         for p in first:                                    # "k-step 1 of tile -1": first half of tile 1 -> buffer 1, refetch for tile 2
             e(f"s_waitcnt vmcnt({P - 1})")
-            self.write_piece(p)
-            self.load_piece(p)
+            self.write_piece(p, False)
+            self.load_piece(p, False)
         self.drain()
         e("s_barrier")
         for j in range(8):
-            self.read_A(0, j)
+            self.read_A(0, j, False)
+            self.read_A(1, j, False)                       # (set 1 too: a diagnostics build that skips the reads still has data)
         for i in range(NI):
-            self.read_W(0, i)
+            self.read_W(0, i, False)
+            self.read_W(1, i, False)
         # the read addresses of set 0 now point at the buffer of tile 1 (they are toggled at the end of every k-step 1 ... see kstep)
         e(f"v_xor_b32 v{V_RDA[0]}, 0x{BUF_XOR:x}, v{V_RDA[0]}")
         e(f"v_xor_b32 v{V_RDW[0]}, 0x{BUF_XOR:x}, v{V_RDW[0]}")
         self.drain()
+        if DEBUG & 16:
+            e("s_mov_b32 s64, 0")
+            e("s_memtime s[66:67]")
+            e("s_memrealtime s[68:69]")
+            e("s_waitcnt lgkmcnt(0)")
         # ---- loop: the body is generated three times on the scoreboard; the text of the last two must agree ----
         texts = []
         for it in range(3):
@@ -237,6 +258,13 @@ class Gen:
         e(f"s_cbranch_scc1 1b")
         # ---- drain ----
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        if DEBUG & 16:
+            e("s_memtime s[60:61]")
+            e("s_memrealtime s[62:63]")
+            e("s_waitcnt lgkmcnt(0)")
+            e("s_sub_u32 %[cyc], s60, s66")
+            e("s_sub_u32 %[rt], s62, s68")
+            e("s_mov_b32 %[bar], s64")
         e("s_nop 15")
         e("s_nop 15")
         return self.lines
@@ -247,7 +275,11 @@ def c_string(lines):
 
 
 def main():
-    out = ["// GENERATED by gen/gemm_w4_gen.py -- do not edit; `make gemm_w4_loop.inc` regenerates it.",
+    global DEBUG
+    if "--debug" in sys.argv:
+        DEBUG = int(sys.argv[sys.argv.index("--debug") + 1])
+    out = [f"// DIAGNOSTICS BUILD, debug = {DEBUG}" if DEBUG else "",
+           "// GENERATED by gen/gemm_w4_gen.py -- do not edit; `make gemm_w4_loop.inc` regenerates it.",
            "// The hand-scheduled main loop of gemm_w4_kernel (gemm_bf16.hip): see the generator for the schedule.",
            ""]
     for NI in (8, 6):
