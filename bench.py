@@ -105,12 +105,12 @@ def pmc_records(kind):
     """Counter evidence of one kernel kind from the committed rocprofv3 --pmc passes of THIS command (separate runs, as
     MI355X_MICROARCH.md prescribes; scripts/pmc_traffic.py / pmc_mfma.py): beyond-L2 bytes per launch and matrix-pipe busy
     fraction, each with the file it came from.  Not measured in this run -- `source` says so."""
-    pat = {"gate_up": ("gemm_bf16_kernel<1", "<256"), "qkv_rope": ("gemm_bf16_kernel<2", "<256"),
-           "o_proj": ("gemm_bf16_kernel<0", "<256"), "down_proj": ("gemm_bf16_kernel<0", "<256"),
+    pat = {"gate_up": ("gemm_w4_kernel<1", ""), "qkv_rope": ("gemm_bf16_kernel<2", "<256"),
+           "o_proj": ("gemm_w4_kernel<0", ""), "down_proj": ("gemm_w4_kernel<0", ""),
            "attn_fwd": ("attn_fwd_kernel<96", "")}[kind]
     out = {}
-    for key, field, stems in (("traffic_bytes_per_launch", "traffic_bytes_per_launch", ("r03_pmc_traffic", "r02_pmc_traffic")),
-                              ("mfma_busy", "mfma_busy_frac", ("r03_pmc_mfma", "r02_pmc_mfma"))):
+    for key, field, stems in (("traffic_bytes_per_launch", "traffic_bytes_per_launch", ("r04_pmc_traffic",)),
+                              ("mfma_busy", "mfma_busy_frac", ("r04_pmc_mfma",))):
         for stem in stems:
             path = os.path.join(ROOT, "profiles", stem + ".json")
             if not os.path.exists(path):
@@ -434,6 +434,9 @@ def main():
     ap.add_argument("--no-stage1", action="store_true",
                     help="skip the short stage-1 data-parallel training measurement appended to the default line")
     ap.add_argument("--stage1-steps", type=int, default=10, help="timed steps of the stage-1 leg of the default line (2 warm-up)")
+    ap.add_argument("--gemm-family", type=int, choices=[0, 1], default=0,
+                    help="0 = default kernels (four-wave hand-scheduled GEMM where it applies), 1 = eight-wave GEMM kernels only "
+                         "(same-box A/B; include/vgpt.h vgpt_gemm_set_family)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the box calibration launches around the timed region")
     ap.add_argument("--attn-precision", choices=["bf16", "fp8"], default="bf16",
                     help="infer / pipeline workloads: operands of the sampler steps' attention (fp8 = the cfg-5 option; "
@@ -481,6 +484,7 @@ def main():
     E = importlib.import_module("video-gpt_amd.engine")
     S = importlib.import_module("video-gpt_amd.scheduler")
     ops = importlib.import_module("video-gpt_amd.ops")
+    importlib.import_module("video-gpt_amd._lib").load().vgpt_gemm_set_family(args.gemm_family)
 
     if args.workload == "stage1":
         return bench_stage1(args, rank, world, device, M, P, D, ops)
@@ -595,14 +599,14 @@ def main():
                     return ops.attention_qkv_range(eng.qkv, eng.pm, nq_, nk_, hd_, 0, eng.ctx, segments=eng.seg_all,
                                                    item_rows=eng.attn_item_rows)
                 return ops.attention_qkv(eng.qkv, eng.pm, nq_, nk_, hd_, out=eng.ctx)
-            kinds = (("gate_up", "gemm_bf16_kernel<MODE_GATED> (gate_up_proj + act(gate) * up epilogue)", 2 * rows * H * 2 * I,
+            kinds = (("gate_up", "gemm_w4_kernel<MODE_GATED, 8> (four-wave hand-scheduled loop, 256 x 256 tiles; gate_up_proj + act(gate) * up epilogue)", 2 * rows * H * 2 * I,
                       lambda l, li: ops.gated_mlp_act(eng.nrm, l.mlp.gate_up_proj.weight, l.mlp.act, out=eng.act)),
-                     ("qkv_rope", "gemm_bf16_kernel<MODE_ROPE> (qkv_proj + RoPE epilogue)", 2 * rows * H * 3 * H,
+                     ("qkv_rope", "gemm_bf16_kernel<MODE_ROPE, 256 x 288> (eight-wave LDS-DMA loop; qkv_proj + RoPE epilogue)", 2 * rows * H * 3 * H,
                       lambda l, li: ops.linear_qkv_rope(eng.nrm, l.self_attn.qkv_proj.weight, rope_[0], rope_[1], nq_, nk_, hd_,
                                                         out=qkv_out(li))),
-                     ("down_proj", "gemm_bf16_kernel<MODE_PLAIN> (down_proj + residual)", 2 * rows * I * H,
+                     ("down_proj", "gemm_w4_kernel<MODE_PLAIN, 6> (four-wave hand-scheduled loop, 256 x 192 tiles; down_proj + residual)", 2 * rows * I * H,
                       lambda l, li: ops.linear(eng.act, l.mlp.down_proj.weight, residual=eng.hid, out=scratch)),
-                     ("o_proj", "gemm_bf16_kernel<MODE_PLAIN> (o_proj + residual)", 2 * rows * H * H,
+                     ("o_proj", "gemm_w4_kernel<MODE_PLAIN, 6> (four-wave hand-scheduled loop, 256 x 192 tiles; o_proj + residual)", 2 * rows * H * H,
                       lambda l, li: ops.linear(eng.ctx, l.self_attn.o_proj.weight, residual=eng.hid, out=scratch)),
                      ("attn_fwd", "attn_fwd_kernel<96> (block-masked flash attention, planned launch)", flops_attn // nl, attn_call))
             # (1) every kind on its own, back to back over the 32 layers: one event pair per kind
@@ -727,7 +731,7 @@ def main():
         n_launch = len(gem) * nl
         achieved = alg / t_gemm / 1e12
         traf = [k.get("traffic_bytes_per_launch") for k in gem]
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (the hand-written instantiations of a decoder layer: "
+        roof = {"bound": "mfma", "kernel": "gemm_w4_kernel / gemm_bf16_kernel (the hand-written GEMMs of a decoder layer: "
                                            + ", ".join(k["name"] for k in gem) + f"; {n_launch} launches per step)",
                 "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4),

@@ -33,3 +33,13 @@ def vg():
 @pytest.fixture(scope="session")
 def ops(vg):
     return importlib.import_module("video-gpt_amd.ops")
+
+
+@pytest.fixture(params=[0, 1], ids=["gemm-four-wave", "gemm-eight-wave"])
+def gemm_family(request):
+    """Both GEMM kernel families under a model-level test (include/vgpt.h: vgpt_gemm_set_family): 0 = the four-wave kernel with
+    the hand-scheduled loop wherever it applies (the default), 1 = the eight-wave LDS-DMA kernels only."""
+    lib = importlib.import_module("video-gpt_amd._lib").load()
+    prev = lib.vgpt_gemm_set_family(request.param)
+    yield request.param
+    lib.vgpt_gemm_set_family(prev)

@@ -65,7 +65,7 @@ def _run(eng, use_graph):
     return out
 
 
-def test_sampler_graph_equals_eager_and_layouts_agree(mods, cfg2):
+def test_sampler_graph_equals_eager_and_layouts_agree(mods, cfg2, gemm_family):
     assert cfg2[2]["input_ids"].shape == (2, 3096)
     ref = _run(_engine(mods, cfg2, reuse_condition_prefix=True), use_graph=False)
     e_graph = _engine(mods, cfg2, reuse_condition_prefix=True)
@@ -132,7 +132,7 @@ def test_attention_plan_equals_aligned_kernel_on_engine_layout(mods, cfg2):
 
 
 @pytest.mark.parametrize("M,N,K", [(4128, 9216, 3072), (4128, 3072, 8192), (7740, 3072, 3072)])
-def test_gemm_layout_invariance(mods, M, N, K):
+def test_gemm_layout_invariance(mods, M, N, K, gemm_family):
     ops, T = mods["ops"], mods["ops_train"]
     g = torch.Generator("cpu").manual_seed(3)
     x = torch.randn(M, K, generator=g).to(DEV, BF)

@@ -36,7 +36,7 @@ def full_params():
     return {k: v.to(BF).float() for k, v in R.make_params(FULL1, seed=11).items()}
 
 
-def test_cfg2_decoder_layer_full_width(full_params):
+def test_cfg2_decoder_layer_full_width(full_params, gemm_family):
     """OmniGen/transformer.py:128-214 with one Phi3 decoder layer at full width over the real cfg-2 batch."""
     cfg, p = FULL1, full_params
     batch = R.collate_inference(4, 8, 256, use_cfg=True, pad_id=cfg.pad_token_id)
@@ -56,7 +56,7 @@ def test_cfg2_decoder_layer_full_width(full_params):
     assert float(err_rows[valid].max()) < 6e-2
 
 
-def test_cfg2_one_sampler_step_full_width_default_path(full_params):
+def test_cfg2_one_sampler_step_full_width_default_path(full_params, gemm_family):
     """One Euler step (x1 prediction, CFG 1.6) of the cfg-2 clip through LVMScheduler's default product path -- packed
     batch, cached condition prefix, hoisted special rows, fused RoPE epilogue, per-clip adaLN table, hipGraph -- vs the
     oracle's LVM.frame_block_forward_with_cfg + scheduler step."""
@@ -81,7 +81,7 @@ def test_cfg2_one_sampler_step_full_width_default_path(full_params):
     assert SC.rel_l2(torch.cat(out), torch.cat(ref)) < 2e-2
 
 
-def test_cfg3_stage1_step_full_width(full_params):
+def test_cfg3_stage1_step_full_width(full_params, gemm_family):
     """Stage-1 batch of cfg-3 (bs 2 x F=8 frames at 256^2 = 2 x 3870 tokens): per-frame loss and gradients of one
     full-width decoder layer vs autograd on the oracle (LVM/train_helper/loss.py:128-243 + LVMTraining.forward)."""
     cfg, p = FULL1, full_params

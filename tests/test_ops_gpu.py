@@ -76,8 +76,10 @@ def test_rope(ops, hd, nh, nkv):
                                             # 128-tile kernel with m tail; 256x192 / 256x256 tiles (qkv of cfg-2: 4096 x 9216)
                                             # (N = 9216 at 4096 / 2048 rows: the 256x288-tile kernel, two / one full rounds)
                                             (4096, 192, 96, 32, 32), (4100, 64, 96, 32, 32), (5160, 128, 96, 32, 32),
-                                            (2048, 256, 96, 32, 32)])
-def test_qkv_gemm_with_fused_rope(ops, M, K, hd, nh, nkv):
+                                            (2048, 256, 96, 32, 32), (4100, 320, 96, 32, 32), (4096, 128, 64, 32, 16)])
+def test_qkv_gemm_with_fused_rope(ops, M, K, hd, nh, nkv, gemm_family):
+    if gemm_family == 1 and M < 2048:
+        pytest.skip("small grids take the same kernel in both families")
     """vgpt_gemm_bf16_rope (qkv_proj + apply_rotary_pos_emb, sdpa_transform.py:39,52-53) vs the oracle's Linear (rounded
     to bf16) + apply_rope, and vs the two-kernel path (GEMM, then vgpt_rope_qk_inplace) it replaces."""
     N = (nh + 2 * nkv) * hd
@@ -114,7 +116,9 @@ def test_qkv_gemm_with_fused_rope(ops, M, K, hd, nh, nkv):
                                    # ... and to the 256x288-tile kernel (N = 9216 = 32 tiles: 4096 / 2048 rows are whole rounds)
                                    (4096, 3072, 192), (4000, 3000, 128), (4096, 9216, 64), (2048, 9216, 320)])
 @pytest.mark.parametrize("epi", ["none", "resid", "bias"])
-def test_gemm(ops, M, N, K, epi):
+def test_gemm(ops, M, N, K, epi, gemm_family):
+    if gemm_family == 1 and M * N < 128 * 256 * 256:
+        pytest.skip("small grids take the same kernel in both families")
     if epi != "none" and M > 1000 and N != 3000:
         pytest.skip("covered by the 'none' case")
     a = bf(torch.randn(M, K, generator=g(5)))
@@ -154,13 +158,49 @@ def test_gemm_rejects_bad_k(ops):
 @pytest.mark.parametrize("M,I,K,act", [(300, 512, 192, "silu"), (70, 64, 64, "gelu_pytorch_tanh"),
                                        (129, 8192, 3072, "silu"), (33, 144, 128, "gelu"),
                                        (2100, 8192, 256, "silu"), (5160, 4112, 64, "silu")])
-def test_gated_mlp(ops, M, I, K, act):
+def test_gated_mlp(ops, M, I, K, act, gemm_family):
+    if gemm_family == 1 and M * I < 64 * 256 * 256:
+        pytest.skip("small grids take the same kernel in both families")
     x = bf(torch.randn(M, K, generator=g(9)))
     w = bf(torch.randn(2 * I, K, generator=g(10)) * 0.05)
     gate, up = (x.double() @ w.double().t()).chunk(2, dim=-1)
     ref = up * R._ACT[act](gate)
     y = ops.gated_mlp_act(x.to(DEV, BF), w.to(DEV, BF), ops.act_code(act))
     assert rel_l2(y, ref) < 4e-3
+
+
+def test_gemm_families_agree_bit_for_bit(ops):
+    """The four-wave kernel (hand-scheduled loop, include/vgpt.h vgpt_gemm_set_family) adds a k-tile's products to an
+    accumulator in the same order as the eight-wave kernels, so the two families are the SAME function bit for bit: plain +
+    residual at the o_proj / down_proj shapes (192-wide tiles), the gated activation incl. the stored [gate | up] (256-wide),
+    ragged rows and columns."""
+    import importlib
+    lib = importlib.import_module("video-gpt_amd._lib").load()
+    def both(fn):
+        out = []
+        for fam in (0, 1):
+            prev = lib.vgpt_gemm_set_family(fam)
+            try:
+                out.append(fn())
+            finally:
+                lib.vgpt_gemm_set_family(prev)
+        return out
+    for (M, N, K) in ((4096, 3072, 3072), (4096, 3072, 8192), (4100, 3076, 320)):
+        a = bf(torch.randn(M, K, generator=g(71))).to(DEV, BF)
+        w = bf(torch.randn(N, K, generator=g(72)) * 0.05).to(DEV, BF)
+        r = bf(torch.randn(M, N, generator=g(73))).to(DEV, BF)
+        y4, y8 = both(lambda: ops.linear(a, w, residual=r))
+        assert torch.equal(y4, y8), (M, N, K)
+    M, I, K = 4100, 4112, 256
+    x = bf(torch.randn(M, K, generator=g(74))).to(DEV, BF)
+    w = bf(torch.randn(2 * I, K, generator=g(75)) * 0.05).to(DEV, BF)
+    def keep():
+        gu = torch.full((M, 2 * I), 7.0, dtype=BF, device=DEV)
+        return ops.gated_mlp_act(x, w, ops.ACT_SILU, gate_up_out=gu), gu
+    (a4, g4), (a8, g8) = both(keep)
+    assert torch.equal(g4, g8) and torch.equal(a4, a8)
+    p4, p8 = both(lambda: ops.gated_mlp_act(x, w, ops.ACT_SILU))
+    assert torch.equal(p4, p8)
 
 
 # ---------------------------------------------------------------------------------------------

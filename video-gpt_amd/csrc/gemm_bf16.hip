@@ -1209,17 +1209,34 @@ bool w4_ok(const GemmArgs& g, int64_t n_out) {
     return true;
 }
 
-// 256- or 192-wide tiles: rounds of 256 workgroups, a round of 192-wide tiles costs 3/4 of the k-loop (the loop is paced by
-// its MFMAs) plus the same fixed part
+// 256- or 192-wide tiles.  Cost of a round of 256 workgroups in units of one k-tile of a 256 x 256 round, fitted to in-step
+// kernel times of round 4 (o_proj 67 us and down_proj 152 us: one round of 192-wide tiles at 48 / 128 k-tiles; gate_up 292 us:
+// four rounds of 256-wide tiles at 48): a 256-wide k-tile 1.19 us, a 192-wide one 1.06 us (0.89 -- the loop is paced by the
+// clock the part holds under the operand stream, not by its MFMA count alone), and 16 us = 13.5 k-tiles per round for
+// dispatch, prologue and the epilogue's burst of stores.
+template <int MODE>
+void w4_costs(const GemmArgs& g, int64_t n_out, double& c256, double& c192) {
+    const int64_t nk = g.K / BK, tiles_m = cdiv(g.M, 256), cus = cu_count();
+    const int64_t t256 = tiles_m * cdiv(n_out, MODE == MODE_GATED ? 128 : 256), t192 = tiles_m * cdiv(n_out, MODE == MODE_GATED ? 96 : 192);
+    const double FIXED = 13.5;
+    c256 = (double)cdiv(t256, cus) * ((double)nk + FIXED);
+    c192 = (double)cdiv(t192, cus) * (0.89 * (double)nk + FIXED);
+}
+// the cheaper of the two in units of one 256-wide round
+template <int MODE>
+double w4_cost_rounds(const GemmArgs& g, int64_t n_out) {
+    double c256, c192;
+    w4_costs<MODE>(g, n_out, c256, c192);
+    return (c192 < c256 ? c192 : c256) / ((double)(g.K / BK) + 13.5);
+}
+
 template <int MODE>
 int launch_w4(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
-    const int64_t nk = g.K / BK, tiles_m = cdiv(g.M, 256);
-    const int64_t t256 = tiles_m * cdiv(n_out, MODE == MODE_GATED ? 128 : 256), t192 = tiles_m * cdiv(n_out, MODE == MODE_GATED ? 96 : 192);
-    const double FIXED = 7.0;
-    const double c256 = (double)cdiv(t256, cu_count()) * ((double)nk + FIXED), c192 = (double)cdiv(t192, cu_count()) * (0.75 * (double)nk + FIXED);
+    double c256, c192;
+    w4_costs<MODE>(g, n_out, c256, c192);
     static int forced = -1;
     if (forced < 0) {
-        const char* e = getenv("VGPT_GEMM_W4_NI");
+        const char* e = getenv("VGPT_GEMM_W4_NI");   // probes: force the tile width (8 = 256, 6 = 192)
         forced = e ? atoi(e) : 0;
     }
     const bool use192 = forced == 6 || (forced != 8 && c192 < c256);
@@ -1237,7 +1254,20 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     const bool use256 = f == 256 || f == 257 || f == 192 || f == 288 || f == 289 || f == 512 || (f != 128 && big_tiles >= 128);
     if (!use256) return launch_cfg<MODE, Cfg128, 0, ATR, WTR>(g, n_out, s, name);
     if constexpr (!ATR && !WTR) {
-        if (f == 0 && w4_enabled() && w4_ok<MODE>(g, n_out)) return launch_w4<MODE>(g, n_out, s, name);
+        if (f == 0 && w4_enabled() && w4_ok<MODE>(g, n_out)) {
+            // one exception, measured inside the sampler step on the same box (profiles/r04_*): qkv_proj of a 4096-row step
+            // (N = 9216 = 32 x 288) is two exact rounds of the eight-wave kernel's 256 x 288 tiles, 198 us, against three rounds
+            // of 256 x 192 four-wave tiles, 214 us (a 192-wide round costs 0.89 of a 256-wide one, not 0.75: see launch_w4)
+            bool keep288 = false;
+            if constexpr (MODE == MODE_PLAIN || MODE == MODE_ROPE) {
+                if (n_out % 288 == 0) {
+                    const int64_t t288 = tiles_m * (n_out / 288), cus = cu_count();
+                    const double r288 = (double)cdiv(t288, cus) * 1.30;
+                    keep288 = t288 % cus == 0 && r288 < w4_cost_rounds<MODE>(g, n_out);
+                }
+            }
+            if (!keep288) return launch_w4<MODE>(g, n_out, s, name);
+        }
     }
     if (f == 257) return launch_cfg<MODE, Cfg256, 0, ATR, WTR>(g, n_out, s, name);
     if constexpr ((MODE == MODE_PLAIN || MODE == MODE_ROPE) && !ATR && !WTR) {
