@@ -44,8 +44,14 @@ for name, M, N, K, kind in (("gate_up", 4096, 8192, 3072, "gated"), ("o_proj", 4
     us = s.elapsed_time(e) / n * 1e3
     rec = {"debug": tag, "shape": name, "us": round(us, 1)}
     if stamps:
-        d = dbg.cpu().view(-1, 4)
+        d = dbg.cpu().view(-1, 8)
         d = d[d[:, 3] > 0].double()
+        t0, t1, t2, t3 = d[:, 4], d[:, 5], d[:, 6], d[:, 7]
+        base = float(t0.min())
+        rec.update({"entry_spread_us": round(float(t0.max() - base) * 0.01, 2), "prologue_cpp_us": round(float((t1 - t0).median()) * 0.01, 2),
+                    "asm_us_median": round(float((t2 - t1).median()) * 0.01, 2), "epilogue_us_median": round(float((t3 - t2).median()) * 0.01, 2),
+                    "epilogue_us_max": round(float((t3 - t2).max()) * 0.01, 2),
+                    "kernel_span_us": round(float(t3.max() - base) * 0.01, 2)})
         nk = float(d[0, 3])
         cyc, rt, bar = d[:, 0], d[:, 1], d[:, 2]
         rec.update({"workgroup_waves": int(d.shape[0]), "cycles_per_ktile_median": round(float(cyc.median() / nk), 1),

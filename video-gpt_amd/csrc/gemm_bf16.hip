@@ -824,6 +824,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     const uint32_t lds_base =
         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
     if (lds_base != 0) __builtin_trap();   // the loop toggles its staging buffers by XOR on absolute LDS addresses
+#ifdef VGPT_W4_STAMPS
+    const uint32_t st_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- tile order: as gemm_bf16_kernel (XCD-aware remap, grouped along m) ----
     const int nwg = g.tiles_m * g.tiles_n;
@@ -882,6 +885,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     const int nk = __builtin_amdgcn_readfirstlane(g.K / BK);
 
     [[maybe_unused]] uint32_t st_cyc = 0, st_rt = 0, st_bar = 0;
+#ifdef VGPT_W4_STAMPS
+    const uint32_t st_t1 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
     if constexpr (NI == 8) {
         asm volatile(VGPT_W4_ASM_NI8
                      : VGPT_W4_OUTS
@@ -901,9 +907,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     }
 
 #ifdef VGPT_W4_STAMPS
+    const uint32_t st_t2 = (uint32_t)__builtin_amdgcn_s_memrealtime();
     if (g.dbg && lane == 0) {
-        uint32_t* d = g.dbg + (blockIdx.x * 4 + wave) * 4;
+        uint32_t* d = g.dbg + (blockIdx.x * 4 + wave) * 8;
         d[0] = st_cyc; d[1] = st_rt; d[2] = st_bar; d[3] = (uint32_t)nk;
+        d[4] = st_t0; d[5] = st_t1; d[6] = st_t2;
     }
 #endif
     // ---- epilogue: lane holds m = lane & 15, n = (lane >> 4) * 4 + reg of each 16 x 16 sub-tile (i: n, j: m).  Branch-free:
@@ -1067,6 +1075,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
             else gated_store(std::integral_constant<int, VGPT_ACT_GELU_TANH>{}, KF{});
         }
     }
+#ifdef VGPT_W4_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the epilogue's stores have left the CU
+    if (g.dbg && lane == 0) g.dbg[(blockIdx.x * 4 + wave) * 8 + 7] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // Persistent walk: OFF unless VGPT_GEMM_PERSIST=1.  Measured in round 3 on one box (bench.py, same process order): sampler
