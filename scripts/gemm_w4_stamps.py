@@ -7,7 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if "--child" not in sys.argv:
     libs = sys.argv[1:] or ["16", "17", "18", "20", "24", "31"]
     for n in libs:
-        env = dict(os.environ, VGPT_LIB=os.path.join(ROOT, "video-gpt_amd", f"libvgpt_hip_w4d{n}.so"))
+        env = dict(os.environ)
+        if n != "main":
+            env["VGPT_LIB"] = os.path.join(ROOT, "video-gpt_amd", f"libvgpt_hip_w4d{n}.so")
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", n], env=env, capture_output=True, text=True, timeout=300)
         sys.stdout.write(r.stdout); sys.stdout.flush()
         if r.returncode:
@@ -18,14 +20,19 @@ sys.path.insert(0, ROOT)
 importlib.import_module("video-gpt_amd")
 ops = importlib.import_module("video-gpt_amd.ops")
 lib = importlib.import_module("video-gpt_amd._lib").load()
-tag = int(sys.argv[sys.argv.index("--child") + 1])
+name_ = sys.argv[sys.argv.index("--child") + 1]
+tag = int("".join(c for c in name_ if c.isdigit()) or 0) if name_ != "main" else 0
+tag = tag if name_ == "main" or name_[0].isdigit() else 0
+import re as _re
+tag = int(_re.match(r"\d+", name_).group(0)) if _re.match(r"\d+", name_) else 0
 dev = "cuda:0"; BF = torch.bfloat16
 stamps = bool(tag & 16)
 dbg = torch.zeros(1 << 18, dtype=torch.int32, device=dev)
 if stamps:
     lib.vgpt_gemm_w4_debug_buffer.argtypes = [__import__("ctypes").c_void_p]
     lib.vgpt_gemm_w4_debug_buffer(dbg.data_ptr())
-for name, M, N, K, kind in (("gate_up", 4096, 8192, 3072, "gated"), ("o_proj", 4096, 3072, 3072, "resid"), ("square", 8192, 8192, 8192, "plain")):
+for name, M, N, K, kind in (("gate_up", 4096, 8192, 3072, "gated"), ("o_proj", 4096, 3072, 3072, "resid"), ("down_proj", 4096, 3072, 8192, "resid"),
+                            ("square", 8192, 8192, 8192, "plain")):
     x = torch.randn(M, K, device=dev).to(BF)
     ws = [(torch.randn((2 * N if kind == "gated" else N), K, device=dev) * 0.05).to(BF) for _ in range(4)]
     res = torch.randn(M, N, device=dev).to(BF)
@@ -42,7 +49,7 @@ for name, M, N, K, kind in (("gate_up", 4096, 8192, 3072, "gated"), ("o_proj", 4
     for i in range(n): call(ws[i % 4])
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) / n * 1e3
-    rec = {"debug": tag, "shape": name, "us": round(us, 1)}
+    rec = {"lib": name_, "shape": name, "us": round(us, 1)}
     if stamps:
         d = dbg.cpu().view(-1, 8)
         d = d[d[:, 3] > 0].double()

@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     if constexpr (NI == 8) {
         asm volatile(VGPT_W4_ASM_NI8
                      : VGPT_W4_OUTS
-                     : [srdA] "s"(srdA), [srdW] "s"(srdW), [rdA] "v"(rdA), [rdW] "v"(rdW), [wrA] "v"(wrA), [wrW] "v"(wrW), [nk] "s"(nk),
+                     : [srdA] "s"(srdA), [srdW] "s"(srdW), [rdA] "v"(rdA), [rdW] "v"(rdW), [wrA] "v"(wrA), [wrW] "v"(wrW), [nk] "s"(nk), [wv] "s"(wave),
                        [oa0] "v"(oa[0]), [oa1] "v"(oa[1]), [oa2] "v"(oa[2]), [oa3] "v"(oa[3]), [oa4] "v"(oa[4]), [oa5] "v"(oa[5]),
                        [oa6] "v"(oa[6]), [oa7] "v"(oa[7]), [ow0] "v"(ow[0]), [ow1] "v"(ow[1]), [ow2] "v"(ow[2]), [ow3] "v"(ow[3]),
                        [ow4] "v"(ow[4]), [ow5] "v"(ow[5]), [ow6] "v"(ow[6]), [ow7] "v"(ow[7])
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     } else {
         asm volatile(VGPT_W4_ASM_NI6
                      : VGPT_W4_OUTS
-                     : [srdA] "s"(srdA), [srdW] "s"(srdW), [rdA] "v"(rdA), [rdW] "v"(rdW), [wrA] "v"(wrA), [wrW] "v"(wrW), [nk] "s"(nk),
+                     : [srdA] "s"(srdA), [srdW] "s"(srdW), [rdA] "v"(rdA), [rdW] "v"(rdW), [wrA] "v"(wrA), [wrW] "v"(wrW), [nk] "s"(nk), [wv] "s"(wave),
                        [oa0] "v"(oa[0]), [oa1] "v"(oa[1]), [oa2] "v"(oa[2]), [oa3] "v"(oa[3]), [oa4] "v"(oa[4]), [oa5] "v"(oa[5]),
                        [oa6] "v"(oa[6]), [oa7] "v"(oa[7]), [ow0] "v"(ow[0]), [ow1] "v"(ow[1]), [ow2] "v"(ow[2]), [ow3] "v"(ow[3]),
                        [ow4] "v"(ow[4]), [ow5] "v"(ow[5])
@@ -988,10 +988,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
             const auto rsC = make_rs(g.C + (int64_t)m0 * g.ldc + n0);
             const bf16* rbase = EPI == VGPT_EPI_RESID ? g.extra + (int64_t)m0 * g.ldr + n0 : (EPI == VGPT_EPI_BIAS ? g.extra + n0 : g.C);
             const auto rsR = make_rs(rbase);
-            u32x2_t r[2][NI];
-            auto request = [&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (EPI != VGPT_EPI_NONE && j < MI) {
+            // every residual quad of the wave tile is requested up front (MI * NI * 2 registers: the loop's registers are
+            // dead by now): with the quads of one row in flight at a time the epilogue was bound by the round trip of a
+            // load -- 13.4 us for the 96 KiB of a 256 x 192 tile (in-kernel stamps, profiles/r04_w4_stamps_v2.log)
+            u32x2_t r[MI][NI];
+            if constexpr (EPI != VGPT_EPI_NONE) {
+                static_for<0, MI>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
                     const int ml = wm * 128 + j * 16 + em;
                     const bool row_ok = m0 + ml < g.M;
                     static_for<0, NI>([&](auto ic) {
@@ -999,14 +1002,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                         const int nl = nl0 + i * 16;
                         const bool ok = row_ok && n0 + nl < g.N;
                         const uint32_t off = EPI == VGPT_EPI_RESID ? (uint32_t)(ml * (int)g.ldr + nl) * 2u : (uint32_t)nl * 2u;
-                        r[j & 1][i] = __builtin_amdgcn_raw_buffer_load_b64(rsR, ok ? off : OOB, 0, 0);
+                        r[j][i] = __builtin_amdgcn_raw_buffer_load_b64(rsR, ok ? off : OOB, 0, 0);
                     });
-                }
-            };
-            request(std::integral_constant<int, 0>{});
+                });
+            }
             static_for<0, MI>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                request(std::integral_constant<int, j + 1>{});
                 const int ml = wm * 128 + j * 16 + em;
                 const bool row_ok = m0 + ml < g.M;
                 static_for<0, NI>([&](auto ic) {
@@ -1015,7 +1016,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                     const bool ok = row_ok && n0 + nl < g.N;
                     f32x4 v = w4_acc<i * 8 + j>();
                     if constexpr (EPI != VGPT_EPI_NONE) {
-                        const bf16x4 rb = __builtin_bit_cast(bf16x4, r[j & 1][i]);
+                        const bf16x4 rb = __builtin_bit_cast(bf16x4, r[j][i]);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) v[t] += bf2f(rb[t]);
                     }

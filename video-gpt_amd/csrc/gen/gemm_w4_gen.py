@@ -34,6 +34,13 @@ S_FIRST, S_LAST = 56, 71
 # 2 = no LDS writes, 4 = no fragment reads, 8 = no barrier, 16 = s_memtime / s_memrealtime stamps around the loop and around
 # every barrier (outputs %[cyc], %[rt], %[bar]: loop cycles, loop time in 10-ns ticks, cycles spent at the barriers)
 DEBUG = 0
+# schedule options under test (python gemm_w4_gen.py --split / --stagger N):
+#   SPLIT: a piece goes to LDS as two ds_write_b64 in two MFMA gaps instead of one ds_write_b128 (13 issue cycles: more than
+#          the 8 a gap leaves); STAGGER: waves 2, 3 idle N x 16 cycles behind every barrier, so that the two waves that share
+#          a half of the LDS store path no longer issue their writes in the same cycle
+SPLIT = False
+STAGGER = 0
+TAIL = 1      # trailing steps of a k-step that carry MFMAs only (--tail N): the LDS queue drains under them, in front of the barrier
 BUF_XOR = 0x8000
 
 
@@ -103,6 +110,13 @@ class Gen:
         self.emit(f"ds_write_b128 v{addr}, {vr(self.piece_regs(p))} offset:{q * 1024}")
         self.issue(("wr", p))
 
+    def write_half(self, p, h, in_loop=True):
+        if in_loop and (DEBUG & 2):
+            return
+        addr, q = (V_WRA, p) if p < self.PA else (V_WRW, p - self.PA)
+        self.emit(f"ds_write_b64 v{addr}, {vr(self.piece_regs(p) + 2 * h, 2)} offset:{q * 1024 + 8 * h}")
+        self.issue(("wr", p, h))
+
     # -- fragments --
     def read_A(self, s, j, in_loop=True):
         if in_loop and (DEBUG & 4):
@@ -127,7 +141,7 @@ class Gen:
         NI = self.NI
         o = s ^ 1
         reads = [("A", j) for j in range(8)] + [("W", i) for i in range(NI)]
-        nsteps = NI - 1                                    # steps that carry side work
+        nsteps = NI - TAIL                                 # steps that carry side work
         def spread(n):                                     # n items over nsteps steps, front-loaded
             base, extra = divmod(n, nsteps)
             return [base + (1 if k < extra else 0) for k in range(nsteps)]
@@ -136,7 +150,7 @@ class Gen:
         for i in range(NI):
             side = []                                      # (slot after MFMA j, callable)
             if i < nsteps:
-                slots_r = [0, 1, 2][:rd_per[i]] if rd_per[i] <= 3 else list(range(rd_per[i]))
+                slots_r = list(range(rd_per[i]))
                 for k in range(rd_per[i]):
                     kind, x = reads[ri]; ri += 1
                     side.append((slots_r[k], (lambda kind=kind, x=x: self.read_A(o, x) if kind == "A" else self.read_W(o, x))))
@@ -147,9 +161,22 @@ class Gen:
                     def wr(p=p):
                         if not (DEBUG & 1):
                             self.emit(f"s_waitcnt vmcnt({self.P - 1})")
-                        self.write_piece(p)
-                    side.append((slot_w[k] if k < 2 else 7, wr))
-                    side.append((slot_l[k] if k < 2 else 7, (lambda p=p: self.load_piece(p))))
+                        if SPLIT:
+                            self.write_half(p, 0)
+                        else:
+                            self.write_piece(p)
+                    if rd_per[i] > 3 or pc_per[i] > 2:   # crowded step (--tail > 1): reads first, then pieces two gaps apart
+                        s0 = min(rd_per[i] + 2 * k, 7)
+                        side.append((s0, wr))
+                        side.append((min(s0 + 1, 7), (lambda p=p: self.load_piece(p))))
+                    elif SPLIT:   # reads in gaps 0..2; piece 0: halves in gaps 3, 4, fetch in 5; piece 1: 5 (after the fetch), 6, fetch in 7
+                        s0 = (3, 5)[k] if k < 2 else 7
+                        side.append((s0, wr))
+                        side.append((min(s0 + 1, 7), (lambda p=p: self.write_half(p, 1))))
+                        side.append((min(s0 + 2, 7), (lambda p=p: self.load_piece(p))))
+                    else:
+                        side.append((slot_w[k] if k < 2 else 7, wr))
+                        side.append((slot_l[k] if k < 2 else 7, (lambda p=p: self.load_piece(p))))
             if i == NI - 1:
                 # address toggles (VALU, no memory operation): the read addresses of the set just requested from
                 def tog():
@@ -174,6 +201,12 @@ class Gen:
             self.emit("s_waitcnt lgkmcnt(0)")
         if not (DEBUG & 8):
             self.emit("s_barrier")
+        if STAGGER:
+            self.emit("s_bitcmp1_b32 %[wv], 1")
+            self.emit("s_cbranch_scc0 2f")
+            for _ in range(STAGGER):
+                self.emit("s_nop 15")
+            self.emit("2:")
         if DEBUG & 16:
             self.emit("s_memtime s[62:63]")
             self.emit("s_waitcnt lgkmcnt(0)")
@@ -275,9 +308,15 @@ def c_string(lines):
 
 
 def main():
-    global DEBUG
+    global DEBUG, SPLIT, STAGGER
     if "--debug" in sys.argv:
         DEBUG = int(sys.argv[sys.argv.index("--debug") + 1])
+    SPLIT = "--split" in sys.argv
+    global TAIL
+    if "--tail" in sys.argv:
+        TAIL = int(sys.argv[sys.argv.index("--tail") + 1])
+    if "--stagger" in sys.argv:
+        STAGGER = int(sys.argv[sys.argv.index("--stagger") + 1])
     out = [f"// DIAGNOSTICS BUILD, debug = {DEBUG}" if DEBUG else "",
            "// GENERATED by gen/gemm_w4_gen.py -- do not edit; `make gemm_w4_loop.inc` regenerates it.",
            "// The hand-scheduled main loop of gemm_w4_kernel (gemm_bf16.hip): see the generator for the schedule.",
