@@ -110,6 +110,35 @@ int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const void* extra, 
  * measurement switch, set before the launches it is meant for.  Returns the previous value; other values change nothing. */
 int vgpt_gemm_set_family(int family);
 
+/* RMSNorm folded into the GEMMs around it (a decoder layer's two Phi3RMSNorm calls, OmniGen/transformer.py:196-214 through
+ * transformers' Phi3DecoderLayer: hidden = residual + attn(input_layernorm(hidden)); hidden = residual +
+ * mlp(post_attention_layernorm(hidden))).  The PRODUCER of a residual stream (o_proj / down_proj + residual) also writes, per
+ * output row, partial sums of the squares of its bf16-rounded outputs; the CONSUMER (qkv_proj + RoPE, gate_up + activation)
+ * reads the raw residual stream as its A operand, a weight with the norm's gain folded in, and multiplies its fp32
+ * accumulators by rsqrt(mean of squares + eps) per row before anything else:
+ *      norm(x) W^T = rstd(x) . (x (W . diag(gain))^T)
+ * -- two launches and one activation round trip less per norm.  Differences from the separate kernel: the gain meets the weight
+ * (one bf16 rounding of gain * W) instead of the normalised activation (two roundings), and rstd multiplies an fp32 sum; the
+ * model-level tolerances (tests/golden/tolerance_calibration.json) hold unchanged.  Deterministic (no atomics).
+ *   vgpt_gemm_norm_partials(M, N, K): partial sums per row vgpt_gemm_bf16_resid_ssq writes for this shape, 0 if the shape is not
+ *       one it takes (then the caller keeps vgpt_rmsnorm_fwd);
+ *   vgpt_gemm_bf16_resid_ssq: C = A W^T + resid (as vgpt_gemm_bf16 with VGPT_EPI_RESID, dense row strides), ssq_out
+ *       (n_partials, M) fp32: ssq_out[p * M + m] = sum of C[m, columns of partial p]^2 on the rounded values;
+ *   vgpt_rms_ssq: ssq_out (M) = row sums of squares of x (M, H) -- one "partial", for a stream no GEMM here produced;
+ *   vgpt_fold_norm_gain: W_out (N, K) = bf16(W[n][k] * gain[k]);
+ *   vgpt_gemm_bf16_rope_prenorm / vgpt_gated_mlp_act_fwd_prenorm: vgpt_gemm_bf16_rope / vgpt_gated_mlp_act_fwd on
+ *       A = the raw stream, W = the folded weight, rows scaled by rsqrt(sum_p ssq[p * M + m] / K + eps). */
+int vgpt_gemm_norm_partials(int64_t M, int64_t N, int64_t K);
+int vgpt_gemm_bf16_resid_ssq(const void* A, const void* W, void* C, const void* resid, float* ssq_out, int64_t M, int64_t N,
+                             int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, void* stream);
+int vgpt_rms_ssq(const void* x, float* ssq_out, int64_t rows, int64_t H, int64_t ldx, void* stream);
+int vgpt_fold_norm_gain(const void* W, const void* gain, void* W_out, int64_t N, int64_t K, void* stream);
+int vgpt_gemm_bf16_rope_prenorm(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t, const float* ssq,
+                                int n_partials, float eps, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                                int64_t ldc, int n_rot_heads, int head_dim, void* stream);
+int vgpt_gated_mlp_act_fwd_prenorm(const void* A, const void* W_gate_up, void* out, const float* ssq, int n_partials, float eps,
+                                   int64_t M, int64_t I, int64_t K, int64_t lda, int64_t ldw, int64_t ldo, int act, void* stream);
+
 /* Phi3MLP first half, fused: out[M,I] = act(A Wg^T) * (A Wu^T) where
  * W_gate_up (2I, K) = [Wg ; Wu] as stored by Phi3MLP.gate_up_proj.
  * K % 64 == 0, I % 64 == 0. */

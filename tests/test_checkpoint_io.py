@@ -56,6 +56,28 @@ def test_state_dict_keys_match_reference_names():
     assert "input_final_layer.weight" in m.state_dict()
 
 
+def test_deepcopy_and_pickle_leave_the_sampler_engines_behind():
+    """LVMScheduler keeps the last clips' engines on the model (GBs of buffers, a hipGraph, a reference back to the model):
+    copy.deepcopy(model) -- how the reference makes its EMA (LVM/train/train_x1_stage1_noiseinput.py:229) -- and pickling must
+    not try to copy them."""
+    import copy
+    import pickle
+    cfg = M.Phi3Config(vocab_size=16, hidden_size=64, intermediate_size=64, num_hidden_layers=1, num_attention_heads=1)
+    m = M.LVM(cfg, pos_embed_max_size=8)
+
+    class Unpicklable:
+        def __reduce__(self):
+            raise RuntimeError("an engine must not be copied")
+    m.__dict__["_vgpt_engine_cache"] = {"key": Unpicklable()}
+    ema = copy.deepcopy(m)
+    assert "_vgpt_engine_cache" not in ema.__dict__ and "_vgpt_engine_cache" in m.__dict__
+    assert all(torch.equal(a, b) for a, b in zip(ema.state_dict().values(), m.state_dict().values()))
+    again = pickle.loads(pickle.dumps(m))
+    assert "_vgpt_engine_cache" not in again.__dict__
+    m.release_engines()
+    assert "_vgpt_engine_cache" not in m.__dict__
+
+
 def test_vae_from_pretrained_local_directory(tmp_path):
     cfg = VR.TINY_VAE8
     p = VR.make_vae_params(cfg, seed=7)

@@ -81,6 +81,35 @@ def test_cfg2_one_sampler_step_full_width_default_path(full_params, gemm_family)
     assert SC.rel_l2(torch.cat(out), torch.cat(ref)) < 2e-2
 
 
+def test_cfg2_sampler_steps_with_folded_rmsnorms_equal_the_separate_kernels(full_params):
+    """The per-step forward with the decoder layer's two RMSNorms folded into the GEMMs around them (engine.py `fuse`:
+    o_proj / down_proj leave the next norm's partial sums of squares behind, qkv_proj + RoPE and gate_up read the raw stream and
+    a gain-folded weight) against the same steps with the separate RMSNorm kernel: the two differ only by where bf16 roundings
+    sit.  Full width, real cfg-2 batch; the oracle comparison of the default (folded) path is the test above."""
+    cfg, p = FULL1, full_params
+    P = importlib.import_module("video-gpt_amd.processor")
+    LY = importlib.import_module("video-gpt_amd.layout")
+    S = importlib.import_module("video-gpt_amd.scheduler")
+    C, G, hw, bl = 4, 8, (32, 32), 258
+    _, batch, z, cond = SC.build_case(cfg, C=C, G=G, hw=hw)
+    lay = LY.TokenLayout.from_plans([(P.plan_inference([C, G])[0], bl, 0), (P.plan_inference([0, G])[0], bl, C * bl)],
+                                    (C + G) * bl)
+    model = SC.build_product_model(cfg, p, DEV)
+    kw = SC.model_kwargs(batch, cond, DEV)
+    kw["attention_mask"] = lay
+    # one step: the two paths differ by single roundings; three steps: by what any two equivalent bf16 paths differ after three
+    # Euler steps (tests/test_fullsize_gpu.py: packed / unpacked / prefix-reuse layouts agree to 9e-3 there)
+    for steps, bound in ((1, 6e-3), (3, 1.5e-2)):
+        outs = {}
+        for fuse in (None, False):
+            sched = S.LVMScheduler(num_steps=steps, time_shifting_factor=1)
+            sched.fuse_norms = fuse
+            outs[fuse] = torch.cat(sched([t.to(DEV, BF) for t in z], model.frame_block_forward_with_cfg, kw, prediction_type="x1"))
+            assert (sched.last_engine.fuse is not None) == (fuse is None)
+        assert SC.rel_l2(outs[None], outs[False].float().cpu()) < bound, steps
+        assert not torch.equal(outs[None], outs[False])                    # (they ARE different roundings)
+
+
 def test_cfg3_stage1_step_full_width(full_params, gemm_family):
     """Stage-1 batch of cfg-3 (bs 2 x F=8 frames at 256^2 = 2 x 3870 tokens): per-frame loss and gradients of one
     full-width decoder layer vs autograd on the oracle (LVM/train_helper/loss.py:128-243 + LVMTraining.forward)."""

@@ -203,6 +203,94 @@ def test_gemm_families_agree_bit_for_bit(ops):
     assert torch.equal(p4, p8)
 
 
+# ---- RMSNorm folded into the GEMMs around it (include/vgpt.h: vgpt_gemm_bf16_resid_ssq -> *_prenorm) ----------------------
+
+def _hf_rmsnorm(x, w, eps):
+    """Phi3RMSNorm.forward with its two bf16 roundings, on fp32 copies of bf16 values."""
+    rstd = torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)
+    return bf(bf(x * rstd) * w)
+
+
+def test_fold_norm_gain_and_row_statistics(ops):
+    g_ = g(81)
+    W = bf(torch.randn(520, 384, generator=g_) * 0.1).to(DEV, BF)
+    gain = bf(1.0 + 0.2 * torch.randn(384, generator=g_)).to(DEV, BF)
+    folded = ops.fold_norm_gain(W, gain)
+    assert torch.equal(folded, (W.float() * gain.float()[None, :]).to(BF))
+    x = bf(torch.randn(777, 384, generator=g_)).to(DEV, BF)
+    ss = ops.rms_ssq(x)
+    assert ss.shape == (1, 777)
+    assert torch.allclose(ss[0].cpu().double(), x.cpu().double().pow(2).sum(-1), rtol=1e-5)
+
+
+def test_linear_resid_ssq_is_the_residual_gemm_plus_its_rows_sums_of_squares(ops):
+    """The producer side: same output bit for bit as linear(..., residual=), partial sums of squares that add up to the row
+    sums of the ROUNDED output, in place on the residual stream, over ragged N (columns past N excluded)."""
+    for (M, N, K) in ((4096, 2048, 256), (4000, 3076, 128)):
+        parts = ops.norm_partials(M, N, K)
+        assert parts in (2 * -(-N // 192), 2 * -(-N // 256))            # two wave columns per 192- or 256-wide tile column
+        a = bf(torch.randn(M, K, generator=g(82))).to(DEV, BF)
+        w = bf(torch.randn(N, K, generator=g(83)) * 0.1).to(DEV, BF)
+        r = bf(torch.randn(M, N, generator=g(84))).to(DEV, BF)
+        ref = ops.linear(a, w, residual=r)
+        ssq = torch.full((parts, M), float("nan"), dtype=torch.float32, device=DEV)
+        hid = r.clone()
+        out = ops.linear_resid_ssq(a, w, hid, ssq, out=hid)          # in place
+        assert out.data_ptr() == hid.data_ptr() and torch.equal(hid, ref)
+        tot = ssq.double().sum(0).cpu()
+        assert torch.allclose(tot, ref.cpu().double().pow(2).sum(-1), rtol=2e-6)
+        again = torch.empty_like(ssq)
+        ops.linear_resid_ssq(a, w, r, again, out=torch.empty_like(r))
+        assert torch.equal(again, ssq)                                 # deterministic (no atomics)
+    assert ops.norm_partials(300, 512, 256) == 0                       # small grids keep the separate norm
+    with pytest.raises(Exception):
+        ops.linear_resid_ssq(a, w, r, torch.empty(3, M, dtype=torch.float32, device=DEV), out=torch.empty_like(r))
+
+
+@pytest.mark.parametrize("parts", [1, 5])
+def test_prenorm_consumers_equal_norm_then_gemm(ops, parts, gemm_family):
+    """The consumer side on both kernel families: qkv_proj + RoPE and gate_up + activation on the RAW stream with the gain
+    folded into the weight and the rows scaled by rstd, against (a) the reference sequence in fp64 on Phi3RMSNorm's own rounded
+    output, (b) the unfused kernels (rmsnorm, then GEMM) -- the two differ by where the bf16 roundings sit, well inside the
+    single-op tolerance.  The statistics arrive as `parts` partial sums per row."""
+    M, H, hd, nq, nkv, I, eps = 4096, 512, 96, 8, 8, 2048, 1e-5
+    g_ = g(85)
+    x = bf(torch.randn(M, H, generator=g_) * torch.rand(M, 1, generator=g_).mul(3).add(0.2))     # rows of very different norms
+    gain = bf(1.0 + 0.3 * torch.randn(H, generator=g_))
+    wq = bf(torch.randn((nq + 2 * nkv) * hd, H, generator=g_) * 0.05)
+    wgu = bf(torch.randn(2 * I, H, generator=g_) * 0.05)
+    xd, gd, wqd, wgud = x.to(DEV, BF), gain.to(DEV, BF), wq.to(DEV, BF), wgu.to(DEV, BF)
+    full = x.double().pow(2).sum(-1)
+    split = torch.rand(parts, M, generator=g_).double() + 0.1
+    ssq = (split / split.sum(0, keepdim=True) * full[None, :]).float().to(DEV)                    # parts rows that add up to the row sums
+    pos = torch.randint(0, 3100, (1, M), generator=g_)
+    cos, sin = ops.rope_table(pos.to(DEV), ops.rope_inv_freq(hd, 10000.0, DEV))
+    nrm = ops.rmsnorm(xd, gd, eps)
+    assert rel_l2(nrm, _hf_rmsnorm(x, gain, eps)) < 4e-3
+    # qkv + RoPE
+    fused = ops.linear_qkv_rope_prenorm(xd, ops.fold_norm_gain(wqd, gd), cos, sin, ssq, parts, eps, nq, nkv, hd,
+                                        out=torch.empty(M, wq.shape[0], dtype=BF, device=DEV))
+    two = ops.linear_qkv_rope(nrm, wqd, cos, sin, nq, nkv, hd)
+    assert rel_l2(fused, two.float().cpu()) < 4e-3
+    nrm64 = _hf_rmsnorm(x, gain, eps).double()
+    qkv = bf((nrm64 @ wq.double().t()).float()).float()[None]
+    rc, rs = R.rope_cos_sin(pos, hd, 10000.0, BF)
+    q = qkv[..., : nq * hd].view(1, M, nq, hd).transpose(1, 2)
+    k = qkv[..., nq * hd:(nq + nkv) * hd].view(1, M, nkv, hd).transpose(1, 2)
+    rq, rk = R.apply_rope(q, k, rc.float(), rs.float())
+    out = fused.cpu().float()[None]
+    assert rel_l2(out[..., : nq * hd], rq.transpose(1, 2).reshape(1, M, -1)) < 6e-3
+    assert rel_l2(out[..., nq * hd:(nq + nkv) * hd], rk.transpose(1, 2).reshape(1, M, -1)) < 6e-3
+    assert rel_l2(out[..., (nq + nkv) * hd:], qkv[..., (nq + nkv) * hd:]) < 4e-3
+    # gate_up + activation
+    fused = ops.gated_mlp_act_prenorm(xd, ops.fold_norm_gain(wgud, gd), ssq, parts, eps, ops.ACT_SILU,
+                                      out=torch.empty(M, I, dtype=BF, device=DEV))
+    two = ops.gated_mlp_act(nrm, wgud, ops.ACT_SILU)
+    gate, up = (nrm64 @ wgu.double().t()).chunk(2, dim=-1)
+    ref = up * R._ACT["silu"](gate)
+    assert rel_l2(fused, ref) < 5e-3 and rel_l2(two, ref) < 5e-3 and rel_l2(fused, two.float().cpu()) < 5e-3
+
+
 # ---------------------------------------------------------------------------------------------
 
 def _np_bits(mask: np.ndarray) -> np.ndarray:

@@ -127,6 +127,16 @@ struct GemmArgs {
     bf16* gu_out = nullptr;
     int64_t ld_gu = 0;
     uint32_t* dbg = nullptr;   // diagnostics builds of the four-wave kernel only
+    // RMSNorm folded into the GEMMs around it (vgpt_gemm_bf16_resid_ssq -> vgpt_gemm_bf16_rope_prenorm / vgpt_gated_mlp_act_fwd_prenorm):
+    //   producer (MODE_PLAIN + residual, four-wave kernel): ssq_out[p * M + m] = sum over the columns of partial p of the squares
+    //   of the bf16-rounded outputs of row m, p = tile column * 2 + wave column (deterministic: no atomics);
+    //   consumer (MODE_ROPE / MODE_GATED): the accumulators of row m are multiplied by rsqrt(sum_p nrm_ssq[p * M + m] * nrm_inv_h
+    //   + nrm_eps) before anything else -- the norm's gain is folded into W by the caller (vgpt_fold_norm_gain)
+    float* ssq_out = nullptr;
+    const float* nrm_ssq = nullptr;
+    int nrm_parts = 0;
+    int64_t nrm_ld = 0;        // rows of the whole matrix: stride between two partials (a row-split launch keeps it)
+    float nrm_eps = 0.f, nrm_inv_h = 0.f;
 };
 
 
@@ -320,6 +330,19 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
 
     f32x4 acc[NI][MI];
     f32x16 acc2[2][4];   // diagnostics flag 32 only
+    // folded RMSNorm (consumer side): 1 / rms of this tile's rows, in LDS behind the staging buffers
+    float* rs_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES);
+    auto load_rstd = [&](int m_first) {
+        if constexpr (MODE != MODE_PLAIN) {
+            if (g.nrm_ssq != nullptr && tid < BM) {
+                const int m = m_first + tid;
+                float ss = 0.f;
+                if (m < g.M)
+                    for (int p_ = 0; p_ < g.nrm_parts; ++p_) ss += g.nrm_ssq[(int64_t)p_ * g.nrm_ld + m];
+                rs_lds[tid] = m < g.M ? rsqrtf(ss * g.nrm_inv_h + g.nrm_eps) : 0.f;
+            }
+        }
+    };
     if constexpr ((kDebug & 32) != 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -350,6 +373,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     bool prefetched = false;
     const int kbeg = 0, kend = nk;
     for (;;) {
+    load_rstd(m0);   // read in the epilogue, behind the k-loop's barriers
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -641,6 +665,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                 if (gs >= g.N) continue;
                 const int n = rope_col_of_slot(gs, g.rope_cols, g.head_dim);
                 f32x4 v = acc[i][j];
+                if (g.nrm_ssq != nullptr) {
+                    const float rs = rs_lds[ml];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] *= rs;
+                }
                 bf16x4 o;
                 if (gs < g.rope_cols) {
                     const int d = (n % g.head_dim) - (upper ? half : 0);
@@ -738,7 +767,12 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                 for (int p = 0; p < NI / 2; ++p) {
                     const int n = n0e + (wn * (NI / 2) + p) * 16 + en;  // output column
                     if (n >= g.I) continue;
-                    const f32x4 gate = acc[2 * p][j], up = acc[2 * p + 1][j];
+                    f32x4 gate = acc[2 * p][j], up = acc[2 * p + 1][j];
+                    if (g.nrm_ssq != nullptr) {
+                        const float rs = rs_lds[wm * (MI * 16) + j * 16 + em];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { gate[t] *= rs; up[t] *= rs; }
+                    }
                     bf16x4 o;
                     if (g.gu_out) {
                         bf16x4 gb, ub;
@@ -884,6 +918,18 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     const uint32_t wrW = (uint32_t)(2 * A_BYTES + wave * NI * 1024 + lane * 16);
     const int nk = __builtin_amdgcn_readfirstlane(g.K / BK);
 
+    // folded RMSNorm, consumer side: 1 / rms of this tile's 256 rows into LDS behind the staging buffers (thread t: row t);
+    // the loop's barriers order it before the epilogue's reads
+    float* rs_lds = reinterpret_cast<float*>(smem + 4 * A_BYTES);
+    if constexpr (MODE != MODE_PLAIN) {
+        if (g.nrm_ssq != nullptr) {
+            const int m = m0 + tid;
+            float ss = 0.f;
+            if (m < g.M)
+                for (int p_ = 0; p_ < g.nrm_parts; ++p_) ss += g.nrm_ssq[(int64_t)p_ * g.nrm_ld + m];
+            rs_lds[tid] = m < g.M ? rsqrtf(ss * g.nrm_inv_h + g.nrm_eps) : 0.f;
+        }
+    }
     [[maybe_unused]] uint32_t st_cyc = 0, st_rt = 0, st_bar = 0;
 #ifdef VGPT_W4_STAMPS
     const uint32_t st_t1 = (uint32_t)__builtin_amdgcn_s_memrealtime();
@@ -960,6 +1006,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                 const int gs = n0 + nl0 + i * 16;
                 const int n = rope_col_of_slot(gs, g.rope_cols, g.head_dim);
                 f32x4 v = w4_acc<i * 8 + j>();
+                if (g.nrm_ssq != nullptr) {
+                    const float rs = rs_lds[ml];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] *= rs;
+                }
                 if (gs < g.rope_cols) {                       // wave-uniform: rope_cols is a multiple of 16
                     const int d = (n % g.head_dim) - (upper ? half : 0);
                     f32x4 cs, sn;
@@ -1010,6 +1061,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                 constexpr int j = decltype(jc)::value;
                 const int ml = wm * 128 + j * 16 + em;
                 const bool row_ok = m0 + ml < g.M;
+                float ssq = 0.f;
                 static_for<0, NI>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     const int nl = nl0 + i * 16;
@@ -1020,8 +1072,24 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) v[t] += bf2f(rb[t]);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b64(pack4(v), rsC, ok ? (uint32_t)(ml * (int)g.ldc + nl) * 2u : OOB, 0, 0);
+                    const u32x2_t ob = pack4(v);
+                    if constexpr (EPI == VGPT_EPI_RESID) {
+                        // sum of squares of the ROUNDED outputs (what the next RMSNorm reads), columns past N excluded
+                        const bf16x4 o4 = __builtin_bit_cast(bf16x4, ob);
+                        float q = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) q += bf2f(o4[t]) * bf2f(o4[t]);
+                        ssq += (n0 + nl < g.N) ? q : 0.f;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(ob, rsC, ok ? (uint32_t)(ml * (int)g.ldc + nl) * 2u : OOB, 0, 0);
                 });
+                if constexpr (EPI == VGPT_EPI_RESID) {
+                    if (g.ssq_out != nullptr) {      // the four lane groups of a row (lane >> 4), fixed order; lanes 0..15 store
+                        ssq += __shfl_xor(ssq, 16, 64);
+                        ssq += __shfl_xor(ssq, 32, 64);
+                        if (lane < 16 && row_ok) g.ssq_out[(int64_t)(tn * 2 + wn) * g.nrm_ld + m0 + ml] = ssq;
+                    }
+                }
             });
         };
         if (g.epi == VGPT_EPI_RESID) plain_store(std::integral_constant<int, VGPT_EPI_RESID>{});
@@ -1038,11 +1106,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                 constexpr int j = decltype(jc)::value;
                 const int ml = wm * 128 + j * 16 + em;
                 const bool row_ok = m0 + ml < g.M;
+                const float rs = g.nrm_ssq != nullptr ? rs_lds[ml] : 1.0f;
                 static_for<0, NI / 2>([&](auto pc) {
                     constexpr int p = decltype(pc)::value;
                     const int nl = ol0 + p * 16;
                     const bool ok = row_ok && n0 + nl < g.I;
-                    const f32x4 gate = w4_acc<(2 * p) * 8 + j>(), up = w4_acc<(2 * p + 1) * 8 + j>();
+                    f32x4 gate = w4_acc<(2 * p) * 8 + j>(), up = w4_acc<(2 * p + 1) * 8 + j>();
+                    if (g.nrm_ssq != nullptr) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { gate[t] *= rs; up[t] *= rs; }
+                    }
                     f32x4 o;
                     if constexpr (KEEP) {
                         bf16x4 gb, ub;
@@ -1113,7 +1186,7 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + C::BM * 4);
         if (e != hipSuccess) {
             vgpt_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return VGPT_ERR_HIP;
@@ -1125,12 +1198,12 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     // persistent walk (kernel: PERSIST): one round of the chip's workgroup slots, each workgroup taking tiles
     // blockIdx.x, + gridDim.x, ...; the slot count is a multiple of 8 (XCD remap).  Off by default (persist_enabled()).
     int grid = g.tiles_m * g.tiles_n;
-    if ((PIPE == 0 || PIPE == 1) && MODE != MODE_ROPE && persist_enabled()) {
+    if ((PIPE == 0 || PIPE == 1) && MODE != MODE_ROPE && persist_enabled() && g.nrm_ssq == nullptr) {
         const int slots = cu_count() * (C::LDS_BYTES > 80 * 1024 ? 1 : 2);
         if (slots % 8 == 0 && grid > slots) grid = slots;
     }
     hipLaunchKernelGGL((gemm_bf16_kernel<MODE, C, PIPE, ATR, WTR>), dim3(grid), dim3(C::THREADS),
-                       C::LDS_BYTES, s, g);
+                       C::LDS_BYTES + C::BM * 4, s, g);
     VGPT_CHECK_LAUNCH(name);
     return VGPT_OK;
 }
@@ -1188,7 +1261,7 @@ bool w4_enabled() { return g_family == 0; }
 
 template <int MODE, int NI>
 int launch_w4_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
-    constexpr int LDS = 128 * 1024;
+    constexpr int LDS = 128 * 1024 + 1024;   // staging buffers + the 256 rstd values of the folded RMSNorm
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_kernel<MODE, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1325,6 +1398,7 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     g2.C = g.C + m1 * g.ldc;
     if (g.epi == VGPT_EPI_RESID) g2.extra = g.extra + m1 * g.ldr;
     if (g.gu_out) g2.gu_out = g.gu_out + m1 * g.ld_gu;
+    if (g.nrm_ssq) g2.nrm_ssq = g.nrm_ssq + m1;
     if (MODE == MODE_ROPE) {
         g2.rope_cos = g.rope_cos + m1 * (g.head_dim / 2);
         g2.rope_sin = g.rope_sin + m1 * (g.head_dim / 2);
@@ -1347,6 +1421,39 @@ VGPT_EXPORT int vgpt_gemm_set_family(int family) {
     const int prev = g_family;
     if (family == 0 || family == 1) g_family = family;
     return prev;
+}
+
+/* ---- RMSNorm folded into the GEMMs around it ---- */
+// number of partial sums per row vgpt_gemm_bf16_resid_ssq writes for this shape (0: the shape is not one the four-wave kernel
+// takes, the caller keeps the separate RMSNorm)
+VGPT_EXPORT int vgpt_gemm_norm_partials(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0 || M >= (1 << 30) || N >= (1 << 30) || K >= (1 << 30)) return 0;
+    GemmArgs g;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.lda = K; g.ldw = K; g.ldc = N; g.ldr = N; g.I = 0;
+    if (g_family != 0 || forced_tile() != 0 || cdiv(M, 256) * cdiv(N, 256) < 128 || !w4_ok<MODE_PLAIN>(g, N)) return 0;
+    double c256, c192;
+    w4_costs<MODE_PLAIN>(g, N, c256, c192);
+    return 2 * (int)cdiv(N, c192 < c256 ? 192 : 256);
+}
+
+VGPT_EXPORT int vgpt_gemm_bf16_resid_ssq(const void* A, const void* W, void* C, const void* resid, float* ssq_out, int64_t M,
+                                         int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, void* stream) {
+    VGPT_REQUIRE(A && W && C && resid && ssq_out, VGPT_ERR_INVALID, "vgpt_gemm_bf16_resid_ssq: null pointer");
+    VGPT_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 &&
+                     aligned16(A) && aligned16(W) && ((uintptr_t)C & 7) == 0 && ((uintptr_t)resid & 7) == 0,
+                 VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_resid_ssq: shape / alignment as vgpt_gemm_bf16");
+    VGPT_REQUIRE(vgpt_gemm_norm_partials(M, N, K) > 0 && lda == K && ldw == K && ldc == N && ldr == N, VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_resid_ssq: not a shape of the four-wave kernel (vgpt_gemm_norm_partials), or strided operands");
+    GemmArgs g;
+    g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = (bf16*)C; g.extra = (const bf16*)resid;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+    g.epi = VGPT_EPI_RESID; g.act = VGPT_ACT_NONE; g.I = 0;
+    g.tiles_m = g.tiles_n = 0;
+    g.rope_cos = g.rope_sin = nullptr; g.rope_cols = g.head_dim = 0;
+    g.ssq_out = ssq_out; g.nrm_ld = M;
+    return launch_w4<MODE_PLAIN>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_resid_ssq");
 }
 
 VGPT_EXPORT int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void* extra, int64_t M,
@@ -1414,7 +1521,8 @@ VGPT_EXPORT int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const v
 }
 
 static int gated_mlp_impl(const void* A, const void* W_gate_up, void* out, void* gate_up_out, int64_t M, int64_t I, int64_t K,
-                          int64_t lda, int64_t ldw, int64_t ldo, int64_t ld_gu, int act, void* stream);
+                          int64_t lda, int64_t ldw, int64_t ldo, int64_t ld_gu, int act, void* stream,
+                          const float* nrm_ssq = nullptr, int nrm_parts = 0, float nrm_eps = 0.f);
 
 VGPT_EXPORT int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, void* out, int64_t M,
                                        int64_t I, int64_t K, int64_t lda, int64_t ldw, int64_t ldo,
@@ -1430,8 +1538,16 @@ VGPT_EXPORT int vgpt_gated_mlp_act_fwd_keep(const void* A, const void* W_gate_up
     return gated_mlp_impl(A, W_gate_up, out, gate_up_out, M, I, K, lda, ldw, ldo, ld_gu, act, stream);
 }
 
+VGPT_EXPORT int vgpt_gated_mlp_act_fwd_prenorm(const void* A, const void* W_gate_up, void* out, const float* ssq, int n_partials,
+                                               float eps, int64_t M, int64_t I, int64_t K, int64_t lda, int64_t ldw, int64_t ldo,
+                                               int act, void* stream) {
+    VGPT_REQUIRE(ssq && n_partials > 0 && eps >= 0.f, VGPT_ERR_INVALID, "vgpt_gated_mlp_act_fwd_prenorm: needs the rows' partial sums of squares");
+    return gated_mlp_impl(A, W_gate_up, out, nullptr, M, I, K, lda, ldw, ldo, 0, act, stream, ssq, n_partials, eps);
+}
+
 static int gated_mlp_impl(const void* A, const void* W_gate_up, void* out, void* gate_up_out, int64_t M, int64_t I, int64_t K,
-                          int64_t lda, int64_t ldw, int64_t ldo, int64_t ld_gu, int act, void* stream) {
+                          int64_t lda, int64_t ldw, int64_t ldo, int64_t ld_gu, int act, void* stream,
+                          const float* nrm_ssq, int nrm_parts, float nrm_eps) {
     VGPT_REQUIRE(A && W_gate_up && out, VGPT_ERR_INVALID, "vgpt_gated_mlp_act_fwd: null pointer");
     VGPT_REQUIRE(M >= 0 && I > 0 && K > 0, VGPT_ERR_INVALID, "vgpt_gated_mlp_act_fwd: bad shape");
     VGPT_REQUIRE(act >= VGPT_ACT_SILU && act <= VGPT_ACT_GELU_TANH, VGPT_ERR_INVALID,
@@ -1454,12 +1570,13 @@ static int gated_mlp_impl(const void* A, const void* W_gate_up, void* out, void*
     g.tiles_m = g.tiles_n = 0;
     g.rope_cos = g.rope_sin = nullptr; g.rope_cols = g.head_dim = 0;
     g.gu_out = (bf16*)gate_up_out; g.ld_gu = ld_gu;
+    g.nrm_ssq = nrm_ssq; g.nrm_parts = nrm_parts; g.nrm_eps = nrm_eps; g.nrm_inv_h = 1.0f / (float)K; g.nrm_ld = M;
     return launch<MODE_GATED>(g, I, (hipStream_t)stream, "vgpt_gated_mlp_act_fwd");
 }
 
-VGPT_EXPORT int vgpt_gemm_bf16_rope(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t,
-                                    int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
-                                    int n_rot_heads, int head_dim, void* stream) {
+static int gemm_rope_impl(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t, int64_t M, int64_t N,
+                         int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int n_rot_heads, int head_dim, void* stream,
+                         const float* nrm_ssq, int nrm_parts, float nrm_eps) {
     VGPT_REQUIRE(M >= 0 && N > 0 && K > 0 && n_rot_heads > 0 && head_dim > 0, VGPT_ERR_INVALID,
                  "vgpt_gemm_bf16_rope: bad shape");
     VGPT_REQUIRE(M == 0 || (A && W && C && cos_t && sin_t), VGPT_ERR_INVALID, "vgpt_gemm_bf16_rope: null pointer");
@@ -1480,6 +1597,20 @@ VGPT_EXPORT int vgpt_gemm_bf16_rope(const void* A, const void* W, void* C, const
     g.epi = VGPT_EPI_NONE; g.act = VGPT_ACT_NONE; g.I = 0;
     g.tiles_m = g.tiles_n = 0;
     g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_cols = n_rot_heads * head_dim; g.head_dim = head_dim;
+    g.nrm_ssq = nrm_ssq; g.nrm_parts = nrm_parts; g.nrm_eps = nrm_eps; g.nrm_inv_h = 1.0f / (float)K; g.nrm_ld = M;
     return launch<MODE_ROPE>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_rope");
+}
+
+VGPT_EXPORT int vgpt_gemm_bf16_rope(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t,
+                                    int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
+                                    int n_rot_heads, int head_dim, void* stream) {
+    return gemm_rope_impl(A, W, C, cos_t, sin_t, M, N, K, lda, ldw, ldc, n_rot_heads, head_dim, stream, nullptr, 0, 0.f);
+}
+
+VGPT_EXPORT int vgpt_gemm_bf16_rope_prenorm(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t,
+                                            const float* ssq, int n_partials, float eps, int64_t M, int64_t N, int64_t K,
+                                            int64_t lda, int64_t ldw, int64_t ldc, int n_rot_heads, int head_dim, void* stream) {
+    VGPT_REQUIRE(ssq && n_partials > 0 && eps >= 0.f, VGPT_ERR_INVALID, "vgpt_gemm_bf16_rope_prenorm: needs the rows' partial sums of squares");
+    return gemm_rope_impl(A, W, C, cos_t, sin_t, M, N, K, lda, ldw, ldc, n_rot_heads, head_dim, stream, ssq, n_partials, eps);
 }
 

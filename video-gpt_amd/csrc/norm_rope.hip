@@ -207,3 +207,66 @@ VGPT_EXPORT int vgpt_rope_qk_inplace(void* qkv, const float* cos_t, const float*
     VGPT_CHECK_LAUNCH("vgpt_rope_qk_inplace");
     return VGPT_OK;
 }
+
+// ---- RMSNorm folded into the GEMMs around it (gemm_bf16.hip: vgpt_gemm_bf16_resid_ssq -> *_prenorm) ----
+// Row sums of squares of a bf16 matrix: the statistics of the FIRST norm of a step, whose input no GEMM of ours produced
+// (one wave per row, fp32; a single "partial" in the layout the *_prenorm entries read).
+__global__ __launch_bounds__(256) void rms_ssq_kernel(const bf16* __restrict__ x, float* __restrict__ out, int64_t rows, int H,
+                                                      int64_t ldx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t wave_stride = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += wave_stride) {
+        const bf16* xr = x + row * ldx;
+        float ss = 0.f;
+        for (int off = lane * 8; off < H; off += 512) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = bf2f(v[j]);
+                ss += f * f;
+            }
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) out[row] = ss;
+    }
+}
+
+VGPT_EXPORT int vgpt_rms_ssq(const void* x, float* ssq_out, int64_t rows, int64_t H, int64_t ldx, void* stream) {
+    VGPT_REQUIRE(rows >= 0 && H > 0 && H % 8 == 0 && ldx >= H && ldx % 8 == 0, VGPT_ERR_INVALID,
+                 "vgpt_rms_ssq: H and ldx must be multiples of 8, ldx >= H");
+    VGPT_REQUIRE(rows == 0 || (x && ssq_out), VGPT_ERR_INVALID, "vgpt_rms_ssq: null pointer");
+    VGPT_REQUIRE(((uintptr_t)x & 15) == 0, VGPT_ERR_UNSUPPORTED, "vgpt_rms_ssq: rows must be 16-byte aligned");
+    if (rows == 0) return VGPT_OK;
+    const int blocks = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+    hipLaunchKernelGGL(rms_ssq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ssq_out, rows, (int)H, ldx);
+    VGPT_CHECK_LAUNCH("vgpt_rms_ssq");
+    return VGPT_OK;
+}
+
+// W'[n][k] = bf16(W[n][k] * g[k]): a norm's gain folded into the weight of the Linear behind it (once per checkpoint)
+__global__ __launch_bounds__(256) void fold_gain_kernel(const bf16* __restrict__ w, const bf16* __restrict__ g, bf16* __restrict__ out,
+                                                        int64_t n_vec, int K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_vec) return;
+    const int k = (int)((i * 8) % K);
+    const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + i * 8);
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + k);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * bf2f(gv[j]));
+    *reinterpret_cast<bf16x8*>(out + i * 8) = o;
+}
+
+VGPT_EXPORT int vgpt_fold_norm_gain(const void* W, const void* gain, void* W_out, int64_t N, int64_t K, void* stream) {
+    VGPT_REQUIRE(N >= 0 && K > 0 && K % 8 == 0, VGPT_ERR_INVALID, "vgpt_fold_norm_gain: K must be a multiple of 8");
+    VGPT_REQUIRE(N == 0 || (W && gain && W_out), VGPT_ERR_INVALID, "vgpt_fold_norm_gain: null pointer");
+    VGPT_REQUIRE((((uintptr_t)W | (uintptr_t)gain | (uintptr_t)W_out) & 15) == 0, VGPT_ERR_UNSUPPORTED,
+                 "vgpt_fold_norm_gain: operands must be 16-byte aligned");
+    if (N == 0) return VGPT_OK;
+    const int64_t n_vec = N * K / 8;
+    hipLaunchKernelGGL(fold_gain_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)W,
+                       (const bf16*)gain, (bf16*)W_out, n_vec, (int)K);
+    VGPT_CHECK_LAUNCH("vgpt_fold_norm_gain");
+    return VGPT_OK;
+}

@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import weakref
+
 import torch
 
 from . import ops
@@ -73,13 +75,36 @@ def pack_left_padded(input_ids, position_ids, attention_mask, pads: List[int]):
     return ids.contiguous(), pos.contiguous(), mask, offsets
 
 
+_FOLDED = weakref.WeakKeyDictionary()   # model -> (key, qkv weights, gate_up weights) with the RMSNorm gains folded in
+
+
+def folded_weights(model):
+    """Per decoder layer: qkv_proj.weight * input_layernorm.weight and gate_up_proj.weight * post_attention_layernorm.weight
+    (per input column, rounded to bf16 once: ops.fold_norm_gain) for the per-step forward with folded RMSNorms.  Derived
+    copies (5 GB at Phi-3-mini size), built once per model and rebuilt when a parameter involved was written or replaced."""
+    layers = model.llm.layers
+    ps = [p_ for l in layers for p_ in (l.self_attn.qkv_proj.weight, l.input_layernorm.weight, l.mlp.gate_up_proj.weight,
+                                        l.post_attention_layernorm.weight)]
+    key = tuple((p_.data_ptr(), p_._version) for p_ in ps)
+    hit = _FOLDED.get(model)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    wq = [ops.fold_norm_gain(l.self_attn.qkv_proj.weight, l.input_layernorm.weight) for l in layers]
+    wgu = [ops.fold_norm_gain(l.mlp.gate_up_proj.weight, l.post_attention_layernorm.weight) for l in layers]
+    _FOLDED[model] = (key, wq, wgu)
+    return wq, wgu
+
+
 class StaticDenoiser:
     def __init__(self, model, input_ids, position_ids, attention_mask, input_img_latents, input_image_sizes,
                  denoise_image_sizes, time_emb_inx, n_frames: int, latent_hw, use_img_cfg: bool, img_cfg_scale: float,
                  prediction_type: str = "v", sigma: Optional[torch.Tensor] = None, pack_padding: bool = True,
                  reuse_condition_prefix: bool = False, hoist_special_rows: bool = True,
-                 attention_precision: str = "bf16"):
+                 attention_precision: str = "bf16", fuse_norms: Optional[bool] = None):
         model._check_ready()
+        # fuse_norms: the two RMSNorms of a decoder layer folded into the GEMMs around them in the per-step forward (ops:
+        # linear_resid_ssq -> *_prenorm; include/vgpt.h).  None = on wherever the step's shapes allow it, VGPT_FUSE_NORMS=0
+        # switches it off (same-box A/B); the per-clip passes and the generic model path keep the separate kernel.
         if attention_precision not in ("bf16", "fp8"):
             raise VgptError(f"StaticDenoiser: attention_precision must be 'bf16' or 'fp8' (got {attention_precision!r})")
         # "fp8": the per-step attention of the sampler runs on MX-fp8 operands (csrc/attn_fp8.hip; the cfg-5 option of
@@ -254,6 +279,16 @@ class StaticDenoiser:
             self.qkv = e(B, L, (nq + 2 * nk) * hd)
             self.ctx = e(B, L, nq * hd)
             self.act = e(B, L, I)
+        self.fuse = None
+        if fuse_norms is None:
+            fuse_norms = os.environ.get("VGPT_FUSE_NORMS", "1") != "0"
+        if fuse_norms:
+            Ms = self.Ma if S else B * L
+            pa, pb = ops.norm_partials(Ms, H, nq * hd), ops.norm_partials(Ms, H, I)
+            if pa > 0 and pb > 0:
+                f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+                wq, wgu = folded_weights(model)
+                self.fuse = {"pa": pa, "pb": pb, "ssq0": f32(1, Ms), "ssq_a": f32(pa, Ms), "ssq_b": f32(pb, Ms), "wq": wq, "wgu": wgu}
         self.temb_sin = e(n_frames, 256)
         self.tt_h = e(n_frames, H)
         self.te_h = e(n_frames, H)
@@ -498,13 +533,27 @@ class StaticDenoiser:
         ops.patch_embed(self.z_model, m.x_embedder.proj.weight, m.x_embedder.proj.bias, pos, x_rows, seq2d,
                         m.pos_embed_max_size)
         nq, nk, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        fz = self.fuse
+        if fz is not None:
+            # the statistics of the first norm: the embedded rows are no GEMM's output.  From here on every residual stream is
+            # written by linear_resid_ssq, which leaves the next norm's partial sums of squares behind
+            ops.rms_ssq(self.hid, out=fz["ssq0"])
+            ssq_in, parts_in = fz["ssq0"], 1
+
+        def qkv_proj(li_, layer, out):
+            at = layer.self_attn
+            if fz is None:
+                return ops.linear_qkv_rope(self.nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=out)
+            return ops.linear_qkv_rope_prenorm(self.hid, fz["wq"][li_], rope[0], rope[1], ssq_in, parts_in,
+                                               layer.input_layernorm.variance_epsilon, nq, nk, hd, out=out)
         for li_, layer in enumerate(m.llm.layers):
             at, mlp = layer.self_attn, layer.mlp
-            ops.rmsnorm(self.hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=self.nrm)
+            if fz is None:
+                ops.rmsnorm(self.hid, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, out=self.nrm)
             if S:
                 full = self.qkv_full[li_]
                 live = full[S:]                                  # this step's q/k/v rows, behind the cached prefix
-                ops.linear_qkv_rope(self.nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=live)
+                qkv_proj(li_, layer, live)
                 if self.attn_fp8:
                     # the prefix rows were quantised once by prefill(); a step re-quantises from the first row it writes
                     ops.attention_qkv_fp8(full.view(1, self.L, -1), self.pm, nq, nk, hd, out=self.ctx, q_start=S,
@@ -513,7 +562,7 @@ class StaticDenoiser:
                     ops.attention_qkv_range(full.view(1, self.L, -1), self.pm, nq, nk, hd, S, self.ctx, segments=self.seg_live,
                                             item_rows=self.attn_item_rows)
             else:
-                ops.linear_qkv_rope(self.nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=self.qkv)
+                qkv_proj(li_, layer, self.qkv)
                 if self.attn_fp8:
                     ops.attention_qkv_fp8(self.qkv, self.pm, nq, nk, hd, out=self.ctx, segments=self.seg_all)
                 elif self.seg_all is not None:
@@ -521,6 +570,13 @@ class StaticDenoiser:
                                             item_rows=self.attn_item_rows)
                 else:
                     ops.attention_qkv(self.qkv, self.pm, nq, nk, hd, out=self.ctx)
+            if fz is not None:
+                ops.linear_resid_ssq(self.ctx, at.o_proj.weight, self.hid, fz["ssq_a"], out=self.hid)
+                ops.gated_mlp_act_prenorm(self.hid, fz["wgu"][li_], fz["ssq_a"], fz["pa"],
+                                          layer.post_attention_layernorm.variance_epsilon, mlp.act, out=self.act)
+                ops.linear_resid_ssq(self.act, mlp.down_proj.weight, self.hid, fz["ssq_b"], out=self.hid)
+                ssq_in, parts_in = fz["ssq_b"], fz["pb"]
+                continue
             ops.linear(self.ctx, at.o_proj.weight, residual=self.hid, out=self.hid)
             ops.rmsnorm(self.hid, layer.post_attention_layernorm.weight,
                         layer.post_attention_layernorm.variance_epsilon, out=self.nrm)

@@ -480,6 +480,14 @@ class LVM(nn.Module):
         per-clip buffers each at 256^2 / 12 frames; scheduler.LVMScheduler.cache_engines)."""
         self.__dict__.pop("_vgpt_engine_cache", None)
 
+    def __getstate__(self):
+        # copy.deepcopy(model) (how the reference makes its EMA: train_x1_stage1_noiseinput.py:229), pickling and torch.save(model)
+        # go through here: the cached sampler engines -- GBs of per-clip buffers, a hipGraph, a reference back to this model --
+        # are not part of the module's state
+        state = self.__dict__.copy()
+        state.pop("_vgpt_engine_cache", None)
+        return state
+
     def _check_ready(self):
         w = self.llm.norm.weight
         if not w.is_cuda or w.dtype != BF16:

@@ -36,6 +36,7 @@ class LVMScheduler:
         self.reuse_condition_prefix = True   # compute the step-invariant condition rows once per clip (engine.py)
         self.hoist_special_rows = True       # ... and the <|diffusion|> / time rows of all steps in one pass (needs a TokenLayout mask)
         self.attention_precision = "bf16"    # "fp8": MX-fp8 attention in the sampler steps of the fast path (cfg-5 option)
+        self.fuse_norms = None               # None: RMSNorms folded into the GEMMs wherever the step's shapes allow (engine.py); False: never
         # keep the engine of a clip on the model and re-use it for the next clip of an identical sequence (the rounds of a
         # rollout once the window is full: LVM/pipeline.py:418-422 re-creates the same prompt every round): buffers, attention
         # plan and the captured graph survive, the per-clip pass is redone on the new condition latents
@@ -89,7 +90,7 @@ class LVMScheduler:
                 len(z), tuple(z[0].shape), None if not lat else (len(lat), tuple(lat[0].shape)),
                 bool(model_kwargs["use_img_cfg"]), float(model_kwargs["img_cfg_scale"]), prediction_type, tb(self.sigma),
                 self.pack_padding, self.reuse_condition_prefix, self.hoist_special_rows, self.attention_precision,
-                str(z[0].device),
+                self.fuse_norms, str(z[0].device),
                 # the captured graph holds the parameters' device addresses: parameters moved or re-allocated since
                 # (model.to(...), a new state dict assigned tensor by tensor) must not meet a cached graph
                 tuple(p_.data_ptr() for p_ in self._owner_params))
@@ -102,7 +103,7 @@ class LVMScheduler:
                               prediction_type, sigma=self.sigma, pack_padding=self.pack_padding,
                               reuse_condition_prefix=self.reuse_condition_prefix,
                               hoist_special_rows=self.hoist_special_rows,
-                              attention_precision=self.attention_precision)
+                              attention_precision=self.attention_precision, fuse_norms=self.fuse_norms)
 
     def __call__(self, z, func, model_kwargs, use_kv_cache: bool = True, offload_kv_cache: bool = True,
                  prediction_type: str = "v", vae=None, noise_level=None):
