@@ -601,13 +601,14 @@ def main():
                 return ops.attention_qkv(eng.qkv, eng.pm, nq_, nk_, hd_, out=eng.ctx)
             fz = eng.fuse      # RMSNorms folded into the GEMMs (engine.py): the step runs the *_prenorm / *_resid_ssq entries
             if fz is not None:
-                ops.rms_ssq(eng.hid, out=fz["ssq0"])
-                f_gate = lambda l, li: ops.gated_mlp_act_prenorm(eng.hid, fz["wgu"][li], fz["ssq_a"], fz["pa"],
-                                                                 l.post_attention_layernorm.variance_epsilon, l.mlp.act, out=eng.act)
-                f_qkv = lambda l, li: ops.linear_qkv_rope_prenorm(eng.hid, fz["wq"][li], rope_[0], rope_[1], fz["ssq0"], 1,
-                                                                  l.input_layernorm.variance_epsilon, nq_, nk_, hd_, out=qkv_out(li))
-                f_down = lambda l, li: ops.linear_resid_ssq(eng.act, l.mlp.down_proj.weight, eng.hid, fz["ssq_b"], out=scratch)
-                f_o = lambda l, li: ops.linear_resid_ssq(eng.ctx, l.self_attn.o_proj.weight, eng.hid, fz["ssq_a"], out=scratch)
+                ops.rms_rstd(eng.hid, 1e-5, out=fz["rstd_in"])
+                ops.rms_rstd(eng.hid, 1e-5, out=fz["rstd_post"])
+                rs2 = torch.empty_like(fz["rstd_in"])
+                f_gate = lambda l, li: ops.gated_mlp_act_prenorm(eng.hid, fz["wgu"][li], fz["rstd_post"], l.mlp.act, out=eng.act)
+                f_qkv = lambda l, li: ops.linear_qkv_rope_prenorm(eng.hid, fz["wq"][li], rope_[0], rope_[1], fz["rstd_in"], nq_, nk_, hd_,
+                                                                  out=qkv_out(li))
+                f_down = lambda l, li: ops.linear_resid_rstd(eng.act, l.mlp.down_proj.weight, eng.hid, rs2, fz["ws"], 1e-5, out=scratch)
+                f_o = lambda l, li: ops.linear_resid_rstd(eng.ctx, l.self_attn.o_proj.weight, eng.hid, rs2, fz["ws"], 1e-5, out=scratch)
             else:
                 f_gate = lambda l, li: ops.gated_mlp_act(eng.nrm, l.mlp.gate_up_proj.weight, l.mlp.act, out=eng.act)
                 f_qkv = lambda l, li: ops.linear_qkv_rope(eng.nrm, l.self_attn.qkv_proj.weight, rope_[0], rope_[1], nq_, nk_, hd_,
@@ -620,9 +621,9 @@ def main():
                      ("qkv_rope", "gemm_bf16_kernel<MODE_ROPE, 256 x 288> (eight-wave LDS-DMA loop; qkv_proj + RoPE epilogue" + tag + ")",
                       2 * rows * H * 3 * H, f_qkv),
                      ("down_proj", "gemm_w4_kernel<MODE_PLAIN, 6> (four-wave hand-scheduled loop, 256 x 192 tiles; down_proj + residual"
-                      + (" + row sums of squares for the next norm" if fz is not None else "") + ")", 2 * rows * I * H, f_down),
+                      + (" + 1 / rms of the output rows for the next norm" if fz is not None else "") + ")", 2 * rows * I * H, f_down),
                      ("o_proj", "gemm_w4_kernel<MODE_PLAIN, 6> (four-wave hand-scheduled loop, 256 x 192 tiles; o_proj + residual"
-                      + (" + row sums of squares for the next norm" if fz is not None else "") + ")", 2 * rows * H * H, f_o),
+                      + (" + 1 / rms of the output rows for the next norm" if fz is not None else "") + ")", 2 * rows * H * H, f_o),
                      ("attn_fwd", "attn_fwd_kernel<96> (block-masked flash attention, planned launch)", flops_attn // nl, attn_call))
             # (1) every kind on its own, back to back over the 32 layers: one event pair per kind
             iso = {}
@@ -644,7 +645,7 @@ def main():
             #     kind's in-step average = its pairs' average - c.
             pairs = {k[0]: [] for k in kinds}
             saved = {n: getattr(ops, n) for n in ("linear", "linear_qkv_rope", "gated_mlp_act", "attention_qkv_range", "attention_qkv",
-                                                  "linear_resid_ssq", "linear_qkv_rope_prenorm", "gated_mlp_act_prenorm")}
+                                                  "linear_resid_rstd", "linear_qkv_rope_prenorm", "gated_mlp_act_prenorm")}
 
             def wrap(fn, kind_of):
                 def f(*a_, **k_):
@@ -682,7 +683,7 @@ def main():
                 ops.linear = wrap(saved["linear"], lin_kind)
                 ops.linear_qkv_rope = wrap(saved["linear_qkv_rope"], lambda *a_, **k_: "qkv_rope")
                 ops.gated_mlp_act = wrap(saved["gated_mlp_act"], lambda *a_, **k_: "gate_up")
-                ops.linear_resid_ssq = wrap(saved["linear_resid_ssq"], lin_kind)
+                ops.linear_resid_rstd = wrap(saved["linear_resid_rstd"], lin_kind)
                 ops.linear_qkv_rope_prenorm = wrap(saved["linear_qkv_rope_prenorm"], lambda *a_, **k_: "qkv_rope")
                 ops.gated_mlp_act_prenorm = wrap(saved["gated_mlp_act_prenorm"], lambda *a_, **k_: "gate_up")
                 ops.attention_qkv_range = wrap(saved["attention_qkv_range"], lambda *a_, **k_: "attn_fwd")

@@ -112,32 +112,37 @@ int vgpt_gemm_set_family(int family);
 
 /* RMSNorm folded into the GEMMs around it (a decoder layer's two Phi3RMSNorm calls, OmniGen/transformer.py:196-214 through
  * transformers' Phi3DecoderLayer: hidden = residual + attn(input_layernorm(hidden)); hidden = residual +
- * mlp(post_attention_layernorm(hidden))).  The PRODUCER of a residual stream (o_proj / down_proj + residual) also writes, per
- * output row, partial sums of the squares of its bf16-rounded outputs; the CONSUMER (qkv_proj + RoPE, gate_up + activation)
- * reads the raw residual stream as its A operand, a weight with the norm's gain folded in, and multiplies its fp32
- * accumulators by rsqrt(mean of squares + eps) per row before anything else:
+ * mlp(post_attention_layernorm(hidden))).  The PRODUCER of a residual stream (o_proj / down_proj + residual) also leaves
+ * 1 / rms of every output row behind; the CONSUMER (qkv_proj + RoPE, gate_up + activation) reads the raw residual stream as its
+ * A operand and a weight with the norm's gain folded in, and multiplies its fp32 accumulators by the row's 1 / rms before
+ * anything else:
  *      norm(x) W^T = rstd(x) . (x (W . diag(gain))^T)
  * -- two launches and one activation round trip less per norm.  Differences from the separate kernel: the gain meets the weight
  * (one bf16 rounding of gain * W) instead of the normalised activation (two roundings), and rstd multiplies an fp32 sum; the
- * model-level tolerances (tests/golden/tolerance_calibration.json) hold unchanged.  Deterministic (no atomics).
- *   vgpt_gemm_norm_partials(M, N, K): partial sums per row vgpt_gemm_bf16_resid_ssq writes for this shape, 0 if the shape is not
- *       one it takes (then the caller keeps vgpt_rmsnorm_fwd);
- *   vgpt_gemm_bf16_resid_ssq: C = A W^T + resid (as vgpt_gemm_bf16 with VGPT_EPI_RESID, dense row strides), ssq_out
- *       (n_partials, M) fp32: ssq_out[p * M + m] = sum of C[m, columns of partial p]^2 on the rounded values;
- *   vgpt_rms_ssq: ssq_out (M) = row sums of squares of x (M, H) -- one "partial", for a stream no GEMM here produced;
+ * model-level tolerances (tests/golden/tolerance_calibration.json) hold unchanged.  Deterministic: every workgroup stores the
+ * sum of squares of ITS columns of a row, and the last workgroup to arrive at a 256-row block's counter adds the block's
+ * partial sums up in a fixed order (no floating-point atomics).
+ *   vgpt_gemm_norm_workspace_bytes(M, N, K): bytes of workspace vgpt_gemm_bf16_resid_rstd needs for this shape, 0 if the shape
+ *       is not one it takes (then the caller keeps vgpt_rmsnorm_fwd).  The workspace is 256-byte aligned, ZEROED ONCE by the
+ *       caller before its first use (it holds arrival counters that every launch leaves at zero again) and may be shared by
+ *       all such launches of one stream;
+ *   vgpt_gemm_bf16_resid_rstd: C = A W^T + resid (as vgpt_gemm_bf16 with VGPT_EPI_RESID; C may be resid), and
+ *       rstd_out[m] = rsqrt(mean_n C[m, n]^2 + eps) on the rounded values;
+ *   vgpt_rms_rstd: the same statistic of a matrix x (M, H) no GEMM here produced;
  *   vgpt_fold_norm_gain: W_out (N, K) = bf16(W[n][k] * gain[k]);
  *   vgpt_gemm_bf16_rope_prenorm / vgpt_gated_mlp_act_fwd_prenorm: vgpt_gemm_bf16_rope / vgpt_gated_mlp_act_fwd on
- *       A = the raw stream, W = the folded weight, rows scaled by rsqrt(sum_p ssq[p * M + m] / K + eps). */
-int vgpt_gemm_norm_partials(int64_t M, int64_t N, int64_t K);
-int vgpt_gemm_bf16_resid_ssq(const void* A, const void* W, void* C, const void* resid, float* ssq_out, int64_t M, int64_t N,
-                             int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, void* stream);
-int vgpt_rms_ssq(const void* x, float* ssq_out, int64_t rows, int64_t H, int64_t ldx, void* stream);
+ *       A = the raw stream, W = the folded weight, row m of the product scaled by rstd[m]. */
+int64_t vgpt_gemm_norm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int vgpt_gemm_bf16_resid_rstd(const void* A, const void* W, void* C, const void* resid, float* rstd_out, void* workspace,
+                              int64_t workspace_bytes, float eps, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                              int64_t ldc, int64_t ldr, void* stream);
+int vgpt_rms_rstd(const void* x, float* rstd_out, int64_t rows, int64_t H, int64_t ldx, float eps, void* stream);
 int vgpt_fold_norm_gain(const void* W, const void* gain, void* W_out, int64_t N, int64_t K, void* stream);
-int vgpt_gemm_bf16_rope_prenorm(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t, const float* ssq,
-                                int n_partials, float eps, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
-                                int64_t ldc, int n_rot_heads, int head_dim, void* stream);
-int vgpt_gated_mlp_act_fwd_prenorm(const void* A, const void* W_gate_up, void* out, const float* ssq, int n_partials, float eps,
-                                   int64_t M, int64_t I, int64_t K, int64_t lda, int64_t ldw, int64_t ldo, int act, void* stream);
+int vgpt_gemm_bf16_rope_prenorm(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t, const float* rstd,
+                                int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int n_rot_heads,
+                                int head_dim, void* stream);
+int vgpt_gated_mlp_act_fwd_prenorm(const void* A, const void* W_gate_up, void* out, const float* rstd, int64_t M, int64_t I,
+                                   int64_t K, int64_t lda, int64_t ldw, int64_t ldo, int act, void* stream);
 
 /* Phi3MLP first half, fused: out[M,I] = act(A Wg^T) * (A Wu^T) where
  * W_gate_up (2I, K) = [Wg ; Wu] as stored by Phi3MLP.gate_up_proj.

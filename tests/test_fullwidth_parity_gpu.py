@@ -97,16 +97,23 @@ def test_cfg2_sampler_steps_with_folded_rmsnorms_equal_the_separate_kernels(full
     model = SC.build_product_model(cfg, p, DEV)
     kw = SC.model_kwargs(batch, cond, DEV)
     kw["attention_mask"] = lay
-    # one step: the two paths differ by single roundings; three steps: by what any two equivalent bf16 paths differ after three
-    # Euler steps (tests/test_fullsize_gpu.py: packed / unpacked / prefix-reuse layouts agree to 9e-3 there)
-    for steps, bound in ((1, 6e-3), (3, 1.5e-2)):
+    # The two paths are different sequences of bf16 roundings of the same function (gain * W rounded once, against x * rstd and
+    # its product with the gain rounded per element), so they differ from each other by about what each differs from the fp32
+    # oracle by -- measured 9.5e-3 after one step, against 9e-3 for either path vs the oracle.  What must hold: the folded path
+    # is as close to the ORACLE as the separate kernels are (no systematic error), at one step and at three.
+    for steps in (1, 3):
         outs = {}
         for fuse in (None, False):
             sched = S.LVMScheduler(num_steps=steps, time_shifting_factor=1)
             sched.fuse_norms = fuse
             outs[fuse] = torch.cat(sched([t.to(DEV, BF) for t in z], model.frame_block_forward_with_cfg, kw, prediction_type="x1"))
             assert (sched.last_engine.fuse is not None) == (fuse is None)
-        assert SC.rel_l2(outs[None], outs[False].float().cpu()) < bound, steps
+        with torch.no_grad():
+            ref = torch.cat(SC.oracle_sample(cfg, p, batch, z, cond, steps, "x1"))
+        e_fused, e_sep = SC.rel_l2(outs[None], ref), SC.rel_l2(outs[False], ref)
+        assert e_fused < 2e-2 and e_sep < 2e-2, (steps, e_fused, e_sep)
+        assert e_fused < 1.15 * e_sep + 5e-4, (steps, e_fused, e_sep)
+        assert SC.rel_l2(outs[None], outs[False].float().cpu()) < 1.5e-2, steps
         assert not torch.equal(outs[None], outs[False])                    # (they ARE different roundings)
 
 

@@ -218,41 +218,46 @@ def test_fold_norm_gain_and_row_statistics(ops):
     folded = ops.fold_norm_gain(W, gain)
     assert torch.equal(folded, (W.float() * gain.float()[None, :]).to(BF))
     x = bf(torch.randn(777, 384, generator=g_)).to(DEV, BF)
-    ss = ops.rms_ssq(x)
-    assert ss.shape == (1, 777)
-    assert torch.allclose(ss[0].cpu().double(), x.cpu().double().pow(2).sum(-1), rtol=1e-5)
+    rs = ops.rms_rstd(x, 1e-5)
+    assert rs.shape == (777,)
+    assert torch.allclose(rs.cpu().double(), torch.rsqrt(x.cpu().double().pow(2).mean(-1) + 1e-5), rtol=1e-5)
 
 
-def test_linear_resid_ssq_is_the_residual_gemm_plus_its_rows_sums_of_squares(ops):
-    """The producer side: same output bit for bit as linear(..., residual=), partial sums of squares that add up to the row
-    sums of the ROUNDED output, in place on the residual stream, over ragged N (columns past N excluded)."""
+def test_linear_resid_rstd_is_the_residual_gemm_plus_its_rows_rstd(ops):
+    """The producer side: same output bit for bit as linear(..., residual=), 1 / rms of the ROUNDED output rows (the partial
+    sums of the tile columns added up by the last workgroup of every 256-row block), in place on the residual stream, ragged
+    M and N (columns past N excluded), the workspace's counters back at zero after every launch, deterministic."""
+    eps = 1e-5
     for (M, N, K) in ((4096, 2048, 256), (4000, 3076, 128)):
-        parts = ops.norm_partials(M, N, K)
-        assert parts in (2 * -(-N // 192), 2 * -(-N // 256))            # two wave columns per 192- or 256-wide tile column
+        nbytes = ops.norm_workspace_bytes(M, N, K)
+        assert nbytes > 0
+        ws = ops.norm_workspace(nbytes, DEV)
         a = bf(torch.randn(M, K, generator=g(82))).to(DEV, BF)
         w = bf(torch.randn(N, K, generator=g(83)) * 0.1).to(DEV, BF)
         r = bf(torch.randn(M, N, generator=g(84))).to(DEV, BF)
         ref = ops.linear(a, w, residual=r)
-        ssq = torch.full((parts, M), float("nan"), dtype=torch.float32, device=DEV)
+        want = torch.rsqrt(ref.cpu().double().pow(2).mean(-1) + eps)
+        rstd = torch.full((M,), float("nan"), dtype=torch.float32, device=DEV)
         hid = r.clone()
-        out = ops.linear_resid_ssq(a, w, hid, ssq, out=hid)          # in place
+        out = ops.linear_resid_rstd(a, w, hid, rstd, ws, eps, out=hid)          # in place
         assert out.data_ptr() == hid.data_ptr() and torch.equal(hid, ref)
-        tot = ssq.double().sum(0).cpu()
-        assert torch.allclose(tot, ref.cpu().double().pow(2).sum(-1), rtol=2e-6)
-        again = torch.empty_like(ssq)
-        ops.linear_resid_ssq(a, w, r, again, out=torch.empty_like(r))
-        assert torch.equal(again, ssq)                                 # deterministic (no atomics)
-    assert ops.norm_partials(300, 512, 256) == 0                       # small grids keep the separate norm
+        assert torch.allclose(rstd.cpu().double(), want, rtol=3e-6)
+        n_cnt = -(-M // 256)
+        assert int(ws[: n_cnt * 4].view(torch.int32).abs().sum()) == 0          # every counter is back at zero
+        for _ in range(3):                                                      # the same workspace again, fresh outputs
+            again = torch.full((M,), float("nan"), dtype=torch.float32, device=DEV)
+            ops.linear_resid_rstd(a, w, r, again, ws, eps, out=torch.empty_like(r))
+            assert torch.equal(again, rstd)                                     # deterministic (no float atomics)
+    assert ops.norm_workspace_bytes(300, 512, 256) == 0                         # small grids keep the separate norm
     with pytest.raises(Exception):
-        ops.linear_resid_ssq(a, w, r, torch.empty(3, M, dtype=torch.float32, device=DEV), out=torch.empty_like(r))
+        ops.linear_resid_rstd(a, w, r, rstd, ws[:256], eps, out=torch.empty_like(r))
 
 
-@pytest.mark.parametrize("parts", [1, 5])
-def test_prenorm_consumers_equal_norm_then_gemm(ops, parts, gemm_family):
+def test_prenorm_consumers_equal_norm_then_gemm(ops, gemm_family):
     """The consumer side on both kernel families: qkv_proj + RoPE and gate_up + activation on the RAW stream with the gain
-    folded into the weight and the rows scaled by rstd, against (a) the reference sequence in fp64 on Phi3RMSNorm's own rounded
-    output, (b) the unfused kernels (rmsnorm, then GEMM) -- the two differ by where the bf16 roundings sit, well inside the
-    single-op tolerance.  The statistics arrive as `parts` partial sums per row."""
+    folded into the weight and the rows scaled by 1 / rms, against (a) the reference sequence in fp64 on Phi3RMSNorm's own
+    rounded output, (b) the unfused kernels (rmsnorm, then GEMM) -- the two differ by where the bf16 roundings sit, well inside
+    the single-op tolerance."""
     M, H, hd, nq, nkv, I, eps = 4096, 512, 96, 8, 8, 2048, 1e-5
     g_ = g(85)
     x = bf(torch.randn(M, H, generator=g_) * torch.rand(M, 1, generator=g_).mul(3).add(0.2))     # rows of very different norms
@@ -260,15 +265,13 @@ def test_prenorm_consumers_equal_norm_then_gemm(ops, parts, gemm_family):
     wq = bf(torch.randn((nq + 2 * nkv) * hd, H, generator=g_) * 0.05)
     wgu = bf(torch.randn(2 * I, H, generator=g_) * 0.05)
     xd, gd, wqd, wgud = x.to(DEV, BF), gain.to(DEV, BF), wq.to(DEV, BF), wgu.to(DEV, BF)
-    full = x.double().pow(2).sum(-1)
-    split = torch.rand(parts, M, generator=g_).double() + 0.1
-    ssq = (split / split.sum(0, keepdim=True) * full[None, :]).float().to(DEV)                    # parts rows that add up to the row sums
+    rstd = ops.rms_rstd(xd, eps)
     pos = torch.randint(0, 3100, (1, M), generator=g_)
     cos, sin = ops.rope_table(pos.to(DEV), ops.rope_inv_freq(hd, 10000.0, DEV))
     nrm = ops.rmsnorm(xd, gd, eps)
     assert rel_l2(nrm, _hf_rmsnorm(x, gain, eps)) < 4e-3
     # qkv + RoPE
-    fused = ops.linear_qkv_rope_prenorm(xd, ops.fold_norm_gain(wqd, gd), cos, sin, ssq, parts, eps, nq, nkv, hd,
+    fused = ops.linear_qkv_rope_prenorm(xd, ops.fold_norm_gain(wqd, gd), cos, sin, rstd, nq, nkv, hd,
                                         out=torch.empty(M, wq.shape[0], dtype=BF, device=DEV))
     two = ops.linear_qkv_rope(nrm, wqd, cos, sin, nq, nkv, hd)
     assert rel_l2(fused, two.float().cpu()) < 4e-3
@@ -283,8 +286,7 @@ def test_prenorm_consumers_equal_norm_then_gemm(ops, parts, gemm_family):
     assert rel_l2(out[..., nq * hd:(nq + nkv) * hd], rk.transpose(1, 2).reshape(1, M, -1)) < 6e-3
     assert rel_l2(out[..., (nq + nkv) * hd:], qkv[..., (nq + nkv) * hd:]) < 4e-3
     # gate_up + activation
-    fused = ops.gated_mlp_act_prenorm(xd, ops.fold_norm_gain(wgud, gd), ssq, parts, eps, ops.ACT_SILU,
-                                      out=torch.empty(M, I, dtype=BF, device=DEV))
+    fused = ops.gated_mlp_act_prenorm(xd, ops.fold_norm_gain(wgud, gd), rstd, ops.ACT_SILU, out=torch.empty(M, I, dtype=BF, device=DEV))
     two = ops.gated_mlp_act(nrm, wgud, ops.ACT_SILU)
     gate, up = (nrm64 @ wgu.double().t()).chunk(2, dim=-1)
     ref = up * R._ACT["silu"](gate)

@@ -35,12 +35,12 @@ SIGNATURES = {
     "vgpt_gemm_bf16_rope": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_int, _P]),
     "vgpt_gemm_bf16_tr": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_int, c_int, _P]),
     "vgpt_gemm_set_family": (c_int, [c_int]),
-    "vgpt_gemm_norm_partials": (c_int, [_I64, _I64, _I64]),
-    "vgpt_gemm_bf16_resid_ssq": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
-    "vgpt_rms_ssq": (c_int, [_P, _P, _I64, _I64, _I64, _P]),
+    "vgpt_gemm_norm_workspace_bytes": (_I64, [_I64, _I64, _I64]),
+    "vgpt_gemm_bf16_resid_rstd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, c_float, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
+    "vgpt_rms_rstd": (c_int, [_P, _P, _I64, _I64, _I64, c_float, _P]),
     "vgpt_fold_norm_gain": (c_int, [_P, _P, _P, _I64, _I64, _P]),
-    "vgpt_gemm_bf16_rope_prenorm": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_float, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_int, _P]),
-    "vgpt_gated_mlp_act_fwd_prenorm": (c_int, [_P, _P, _P, _P, c_int, c_float, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
+    "vgpt_gemm_bf16_rope_prenorm": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_int, _P]),
+    "vgpt_gated_mlp_act_fwd_prenorm": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
     "vgpt_gated_mlp_act_fwd": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
     "vgpt_gated_mlp_act_fwd_keep": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P]),
     "vgpt_mask_pack_bool": (c_int, [_P, _P, _I64, _I64, _P]),

@@ -127,15 +127,19 @@ struct GemmArgs {
     bf16* gu_out = nullptr;
     int64_t ld_gu = 0;
     uint32_t* dbg = nullptr;   // diagnostics builds of the four-wave kernel only
-    // RMSNorm folded into the GEMMs around it (vgpt_gemm_bf16_resid_ssq -> vgpt_gemm_bf16_rope_prenorm / vgpt_gated_mlp_act_fwd_prenorm):
-    //   producer (MODE_PLAIN + residual, four-wave kernel): ssq_out[p * M + m] = sum over the columns of partial p of the squares
-    //   of the bf16-rounded outputs of row m, p = tile column * 2 + wave column (deterministic: no atomics);
-    //   consumer (MODE_ROPE / MODE_GATED): the accumulators of row m are multiplied by rsqrt(sum_p nrm_ssq[p * M + m] * nrm_inv_h
-    //   + nrm_eps) before anything else -- the norm's gain is folded into W by the caller (vgpt_fold_norm_gain)
-    float* ssq_out = nullptr;
-    const float* nrm_ssq = nullptr;
-    int nrm_parts = 0;
-    int64_t nrm_ld = 0;        // rows of the whole matrix: stride between two partials (a row-split launch keeps it)
+    // RMSNorm folded into the GEMMs around it (vgpt_gemm_bf16_resid_rstd -> vgpt_gemm_bf16_rope_prenorm /
+    // vgpt_gated_mlp_act_fwd_prenorm):
+    //   producer (MODE_PLAIN + residual, four-wave kernel): every workgroup stores, per output row, the sum over ITS columns of the
+    //   squares of the bf16-rounded outputs (ssq_out[p * M + m], p = tile column * 2 + wave column); the last workgroup to arrive
+    //   at a 256-row block's counter adds the block's partials up in index order (deterministic: no float atomics) and writes
+    //   rstd_out[m] = rsqrt(sum * nrm_inv_h + nrm_eps);
+    //   consumer (MODE_ROPE / MODE_GATED): the accumulators of row m are multiplied by nrm_rstd[m] before anything else -- the
+    //   norm's gain is folded into W by the caller (vgpt_fold_norm_gain)
+    float* ssq_out = nullptr;          // producer: partial sums (n_partials, M), inside the caller's workspace
+    int* ssq_cnt = nullptr;            // producer: one arrival counter per 256-row block (zero between launches)
+    float* rstd_out = nullptr;         // producer: 1 / rms of every output row, written by the last workgroup of its row block
+    const float* nrm_rstd = nullptr;   // consumer: 1 / rms of every row of A
+    int64_t nrm_ld = 0;                // producer: rows of the whole matrix = stride between two partials
     float nrm_eps = 0.f, nrm_inv_h = 0.f;
 };
 
@@ -334,13 +338,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
     float* rs_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES);
     auto load_rstd = [&](int m_first) {
         if constexpr (MODE != MODE_PLAIN) {
-            if (g.nrm_ssq != nullptr && tid < BM) {
-                const int m = m_first + tid;
-                float ss = 0.f;
-                if (m < g.M)
-                    for (int p_ = 0; p_ < g.nrm_parts; ++p_) ss += g.nrm_ssq[(int64_t)p_ * g.nrm_ld + m];
-                rs_lds[tid] = m < g.M ? rsqrtf(ss * g.nrm_inv_h + g.nrm_eps) : 0.f;
-            }
+            if (g.nrm_rstd != nullptr && tid < BM) rs_lds[tid] = m_first + tid < g.M ? g.nrm_rstd[m_first + tid] : 0.f;
         }
     };
     if constexpr ((kDebug & 32) != 0) {
@@ -665,7 +663,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                 if (gs >= g.N) continue;
                 const int n = rope_col_of_slot(gs, g.rope_cols, g.head_dim);
                 f32x4 v = acc[i][j];
-                if (g.nrm_ssq != nullptr) {
+                if (g.nrm_rstd != nullptr) {
                     const float rs = rs_lds[ml];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] *= rs;
@@ -768,7 +766,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
                     const int n = n0e + (wn * (NI / 2) + p) * 16 + en;  // output column
                     if (n >= g.I) continue;
                     f32x4 gate = acc[2 * p][j], up = acc[2 * p + 1][j];
-                    if (g.nrm_ssq != nullptr) {
+                    if (g.nrm_rstd != nullptr) {
                         const float rs = rs_lds[wm * (MI * 16) + j * 16 + em];
 #pragma unroll
                         for (int t = 0; t < 4; ++t) { gate[t] *= rs; up[t] *= rs; }
@@ -922,13 +920,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     // the loop's barriers order it before the epilogue's reads
     float* rs_lds = reinterpret_cast<float*>(smem + 4 * A_BYTES);
     if constexpr (MODE != MODE_PLAIN) {
-        if (g.nrm_ssq != nullptr) {
-            const int m = m0 + tid;
-            float ss = 0.f;
-            if (m < g.M)
-                for (int p_ = 0; p_ < g.nrm_parts; ++p_) ss += g.nrm_ssq[(int64_t)p_ * g.nrm_ld + m];
-            rs_lds[tid] = m < g.M ? rsqrtf(ss * g.nrm_inv_h + g.nrm_eps) : 0.f;
-        }
+        if (g.nrm_rstd != nullptr) rs_lds[tid] = m0 + tid < g.M ? g.nrm_rstd[m0 + tid] : 0.f;
     }
     [[maybe_unused]] uint32_t st_cyc = 0, st_rt = 0, st_bar = 0;
 #ifdef VGPT_W4_STAMPS
@@ -1006,7 +998,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                 const int gs = n0 + nl0 + i * 16;
                 const int n = rope_col_of_slot(gs, g.rope_cols, g.head_dim);
                 f32x4 v = w4_acc<i * 8 + j>();
-                if (g.nrm_ssq != nullptr) {
+                if (g.nrm_rstd != nullptr) {
                     const float rs = rs_lds[ml];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] *= rs;
@@ -1087,10 +1079,46 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                     if (g.ssq_out != nullptr) {      // the four lane groups of a row (lane >> 4), fixed order; lanes 0..15 store
                         ssq += __shfl_xor(ssq, 16, 64);
                         ssq += __shfl_xor(ssq, 32, 64);
-                        if (lane < 16 && row_ok) g.ssq_out[(int64_t)(tn * 2 + wn) * g.nrm_ld + m0 + ml] = ssq;
+                        // write-through (sc1): read by ANOTHER workgroup below, MI355X_MICROARCH.md inter-workgroup visibility
+                        if (lane < 16 && row_ok)
+                            __hip_atomic_store(g.ssq_out + (int64_t)(tn * 2 + wn) * g.nrm_ld + m0 + ml, ssq, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             });
+            if constexpr (EPI == VGPT_EPI_RESID) {
+                if (g.ssq_out != nullptr) {
+                    // The workgroup that arrives LAST at its 256-row block's counter adds up the block's partial sums -- every
+                    // one stored sc1 and drained (vmcnt(0) of every storing wave, then the barrier) before its workgroup's
+                    // arrival -- in a fixed order and writes the rows' 1 / rms: the consumers read one float per row.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    int* flag = reinterpret_cast<int*>(smem + 4 * A_BYTES);
+                    if (tid == 0) {
+                        const int old = __hip_atomic_fetch_add(g.ssq_cnt + tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *flag = old == g.tiles_n - 1;
+                        if (old == g.tiles_n - 1) __hip_atomic_store(g.ssq_cnt + tm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __syncthreads();
+                    if (*flag && m0 + tid < g.M) {
+                        const float* pp = g.ssq_out + m0 + tid;
+                        const int parts = g.tiles_n * 2;
+                        float ss = 0.f;
+                        int p_ = 0;
+                        for (; p_ + 8 <= parts; p_ += 8) {      // eight loads in flight, added in index order
+                            float v8[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                v8[u] = __hip_atomic_load(pp + (int64_t)(p_ + u) * g.nrm_ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) ss += v8[u];
+                        }
+                        for (; p_ < parts; ++p_)
+                            ss += __hip_atomic_load(pp + (int64_t)p_ * g.nrm_ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        g.rstd_out[m0 + tid] = rsqrtf(ss * g.nrm_inv_h + g.nrm_eps);
+                    }
+                }
+            }
         };
         if (g.epi == VGPT_EPI_RESID) plain_store(std::integral_constant<int, VGPT_EPI_RESID>{});
         else if (g.epi == VGPT_EPI_BIAS) plain_store(std::integral_constant<int, VGPT_EPI_BIAS>{});
@@ -1106,13 +1134,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                 constexpr int j = decltype(jc)::value;
                 const int ml = wm * 128 + j * 16 + em;
                 const bool row_ok = m0 + ml < g.M;
-                const float rs = g.nrm_ssq != nullptr ? rs_lds[ml] : 1.0f;
+                const float rs = g.nrm_rstd != nullptr ? rs_lds[ml] : 1.0f;
                 static_for<0, NI / 2>([&](auto pc) {
                     constexpr int p = decltype(pc)::value;
                     const int nl = ol0 + p * 16;
                     const bool ok = row_ok && n0 + nl < g.I;
                     f32x4 gate = w4_acc<(2 * p) * 8 + j>(), up = w4_acc<(2 * p + 1) * 8 + j>();
-                    if (g.nrm_ssq != nullptr) {
+                    if (g.nrm_rstd != nullptr) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) { gate[t] *= rs; up[t] *= rs; }
                     }
@@ -1198,7 +1226,7 @@ int launch_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     // persistent walk (kernel: PERSIST): one round of the chip's workgroup slots, each workgroup taking tiles
     // blockIdx.x, + gridDim.x, ...; the slot count is a multiple of 8 (XCD remap).  Off by default (persist_enabled()).
     int grid = g.tiles_m * g.tiles_n;
-    if ((PIPE == 0 || PIPE == 1) && MODE != MODE_ROPE && persist_enabled() && g.nrm_ssq == nullptr) {
+    if ((PIPE == 0 || PIPE == 1) && MODE != MODE_ROPE && persist_enabled() && g.nrm_rstd == nullptr) {
         const int slots = cu_count() * (C::LDS_BYTES > 80 * 1024 ? 1 : 2);
         if (slots % 8 == 0 && grid > slots) grid = slots;
     }
@@ -1398,7 +1426,7 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     g2.C = g.C + m1 * g.ldc;
     if (g.epi == VGPT_EPI_RESID) g2.extra = g.extra + m1 * g.ldr;
     if (g.gu_out) g2.gu_out = g.gu_out + m1 * g.ld_gu;
-    if (g.nrm_ssq) g2.nrm_ssq = g.nrm_ssq + m1;
+    if (g.nrm_rstd) g2.nrm_rstd = g.nrm_rstd + m1;
     if (MODE == MODE_ROPE) {
         g2.rope_cos = g.rope_cos + m1 * (g.head_dim / 2);
         g2.rope_sin = g.rope_sin + m1 * (g.head_dim / 2);
@@ -1424,9 +1452,9 @@ VGPT_EXPORT int vgpt_gemm_set_family(int family) {
 }
 
 /* ---- RMSNorm folded into the GEMMs around it ---- */
-// number of partial sums per row vgpt_gemm_bf16_resid_ssq writes for this shape (0: the shape is not one the four-wave kernel
-// takes, the caller keeps the separate RMSNorm)
-VGPT_EXPORT int vgpt_gemm_norm_partials(int64_t M, int64_t N, int64_t K) {
+namespace {
+// partial sums per row for this shape on the four-wave kernel; 0: not a shape it takes
+int norm_partials(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || M >= (1 << 30) || N >= (1 << 30) || K >= (1 << 30)) return 0;
     GemmArgs g;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -1436,15 +1464,28 @@ VGPT_EXPORT int vgpt_gemm_norm_partials(int64_t M, int64_t N, int64_t K) {
     w4_costs<MODE_PLAIN>(g, N, c256, c192);
     return 2 * (int)cdiv(N, c192 < c256 ? 192 : 256);
 }
+int64_t norm_cnt_bytes(int64_t M) { return (cdiv(M, 256) * 4 + 255) / 256 * 256; }
+}  // namespace
 
-VGPT_EXPORT int vgpt_gemm_bf16_resid_ssq(const void* A, const void* W, void* C, const void* resid, float* ssq_out, int64_t M,
-                                         int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, void* stream) {
-    VGPT_REQUIRE(A && W && C && resid && ssq_out, VGPT_ERR_INVALID, "vgpt_gemm_bf16_resid_ssq: null pointer");
+// bytes of workspace vgpt_gemm_bf16_resid_rstd needs for this shape; 0: the shape is not one the four-wave kernel takes (the
+// caller keeps the separate RMSNorm)
+VGPT_EXPORT int64_t vgpt_gemm_norm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    const int parts = norm_partials(M, N, K);
+    return parts == 0 ? 0 : norm_cnt_bytes(M) + (int64_t)parts * M * 4;
+}
+
+VGPT_EXPORT int vgpt_gemm_bf16_resid_rstd(const void* A, const void* W, void* C, const void* resid, float* rstd_out, void* workspace,
+                                          int64_t workspace_bytes, float eps, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                          int64_t ldw, int64_t ldc, int64_t ldr, void* stream) {
+    VGPT_REQUIRE(A && W && C && resid && rstd_out && workspace, VGPT_ERR_INVALID, "vgpt_gemm_bf16_resid_rstd: null pointer");
     VGPT_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 &&
-                     aligned16(A) && aligned16(W) && ((uintptr_t)C & 7) == 0 && ((uintptr_t)resid & 7) == 0,
-                 VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_resid_ssq: shape / alignment as vgpt_gemm_bf16");
-    VGPT_REQUIRE(vgpt_gemm_norm_partials(M, N, K) > 0 && lda == K && ldw == K && ldc == N && ldr == N, VGPT_ERR_UNSUPPORTED,
-                 "vgpt_gemm_bf16_resid_ssq: not a shape of the four-wave kernel (vgpt_gemm_norm_partials), or strided operands");
+                     aligned16(A) && aligned16(W) && ((uintptr_t)C & 7) == 0 && ((uintptr_t)resid & 7) == 0 && eps >= 0.f,
+                 VGPT_ERR_UNSUPPORTED, "vgpt_gemm_bf16_resid_rstd: shape / alignment as vgpt_gemm_bf16");
+    const int64_t need = vgpt_gemm_norm_workspace_bytes(M, N, K);
+    VGPT_REQUIRE(need > 0, VGPT_ERR_UNSUPPORTED,
+                 "vgpt_gemm_bf16_resid_rstd: not a shape of the four-wave kernel (vgpt_gemm_norm_workspace_bytes)");
+    VGPT_REQUIRE(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0, VGPT_ERR_INVALID,
+                 "vgpt_gemm_bf16_resid_rstd: workspace too small or not 256-byte aligned");
     GemmArgs g;
     g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = (bf16*)C; g.extra = (const bf16*)resid;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -1452,8 +1493,10 @@ VGPT_EXPORT int vgpt_gemm_bf16_resid_ssq(const void* A, const void* W, void* C, 
     g.epi = VGPT_EPI_RESID; g.act = VGPT_ACT_NONE; g.I = 0;
     g.tiles_m = g.tiles_n = 0;
     g.rope_cos = g.rope_sin = nullptr; g.rope_cols = g.head_dim = 0;
-    g.ssq_out = ssq_out; g.nrm_ld = M;
-    return launch_w4<MODE_PLAIN>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_resid_ssq");
+    g.ssq_cnt = (int*)workspace;
+    g.ssq_out = (float*)((char*)workspace + norm_cnt_bytes(M));
+    g.rstd_out = rstd_out; g.nrm_ld = M; g.nrm_eps = eps; g.nrm_inv_h = 1.0f / (float)N;
+    return launch_w4<MODE_PLAIN>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_resid_rstd");
 }
 
 VGPT_EXPORT int vgpt_gemm_bf16(const void* A, const void* W, void* C, const void* extra, int64_t M,
@@ -1522,7 +1565,7 @@ VGPT_EXPORT int vgpt_gemm_bf16_tr(const void* A, const void* W, void* C, const v
 
 static int gated_mlp_impl(const void* A, const void* W_gate_up, void* out, void* gate_up_out, int64_t M, int64_t I, int64_t K,
                           int64_t lda, int64_t ldw, int64_t ldo, int64_t ld_gu, int act, void* stream,
-                          const float* nrm_ssq = nullptr, int nrm_parts = 0, float nrm_eps = 0.f);
+                          const float* nrm_rstd = nullptr);
 
 VGPT_EXPORT int vgpt_gated_mlp_act_fwd(const void* A, const void* W_gate_up, void* out, int64_t M,
                                        int64_t I, int64_t K, int64_t lda, int64_t ldw, int64_t ldo,
@@ -1538,16 +1581,14 @@ VGPT_EXPORT int vgpt_gated_mlp_act_fwd_keep(const void* A, const void* W_gate_up
     return gated_mlp_impl(A, W_gate_up, out, gate_up_out, M, I, K, lda, ldw, ldo, ld_gu, act, stream);
 }
 
-VGPT_EXPORT int vgpt_gated_mlp_act_fwd_prenorm(const void* A, const void* W_gate_up, void* out, const float* ssq, int n_partials,
-                                               float eps, int64_t M, int64_t I, int64_t K, int64_t lda, int64_t ldw, int64_t ldo,
-                                               int act, void* stream) {
-    VGPT_REQUIRE(ssq && n_partials > 0 && eps >= 0.f, VGPT_ERR_INVALID, "vgpt_gated_mlp_act_fwd_prenorm: needs the rows' partial sums of squares");
-    return gated_mlp_impl(A, W_gate_up, out, nullptr, M, I, K, lda, ldw, ldo, 0, act, stream, ssq, n_partials, eps);
+VGPT_EXPORT int vgpt_gated_mlp_act_fwd_prenorm(const void* A, const void* W_gate_up, void* out, const float* rstd, int64_t M,
+                                               int64_t I, int64_t K, int64_t lda, int64_t ldw, int64_t ldo, int act, void* stream) {
+    VGPT_REQUIRE(rstd, VGPT_ERR_INVALID, "vgpt_gated_mlp_act_fwd_prenorm: needs the rows' 1 / rms");
+    return gated_mlp_impl(A, W_gate_up, out, nullptr, M, I, K, lda, ldw, ldo, 0, act, stream, rstd);
 }
 
 static int gated_mlp_impl(const void* A, const void* W_gate_up, void* out, void* gate_up_out, int64_t M, int64_t I, int64_t K,
-                          int64_t lda, int64_t ldw, int64_t ldo, int64_t ld_gu, int act, void* stream,
-                          const float* nrm_ssq, int nrm_parts, float nrm_eps) {
+                          int64_t lda, int64_t ldw, int64_t ldo, int64_t ld_gu, int act, void* stream, const float* nrm_rstd) {
     VGPT_REQUIRE(A && W_gate_up && out, VGPT_ERR_INVALID, "vgpt_gated_mlp_act_fwd: null pointer");
     VGPT_REQUIRE(M >= 0 && I > 0 && K > 0, VGPT_ERR_INVALID, "vgpt_gated_mlp_act_fwd: bad shape");
     VGPT_REQUIRE(act >= VGPT_ACT_SILU && act <= VGPT_ACT_GELU_TANH, VGPT_ERR_INVALID,
@@ -1570,13 +1611,13 @@ static int gated_mlp_impl(const void* A, const void* W_gate_up, void* out, void*
     g.tiles_m = g.tiles_n = 0;
     g.rope_cos = g.rope_sin = nullptr; g.rope_cols = g.head_dim = 0;
     g.gu_out = (bf16*)gate_up_out; g.ld_gu = ld_gu;
-    g.nrm_ssq = nrm_ssq; g.nrm_parts = nrm_parts; g.nrm_eps = nrm_eps; g.nrm_inv_h = 1.0f / (float)K; g.nrm_ld = M;
+    g.nrm_rstd = nrm_rstd;
     return launch<MODE_GATED>(g, I, (hipStream_t)stream, "vgpt_gated_mlp_act_fwd");
 }
 
 static int gemm_rope_impl(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t, int64_t M, int64_t N,
                          int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int n_rot_heads, int head_dim, void* stream,
-                         const float* nrm_ssq, int nrm_parts, float nrm_eps) {
+                         const float* nrm_rstd) {
     VGPT_REQUIRE(M >= 0 && N > 0 && K > 0 && n_rot_heads > 0 && head_dim > 0, VGPT_ERR_INVALID,
                  "vgpt_gemm_bf16_rope: bad shape");
     VGPT_REQUIRE(M == 0 || (A && W && C && cos_t && sin_t), VGPT_ERR_INVALID, "vgpt_gemm_bf16_rope: null pointer");
@@ -1597,20 +1638,20 @@ static int gemm_rope_impl(const void* A, const void* W, void* C, const float* co
     g.epi = VGPT_EPI_NONE; g.act = VGPT_ACT_NONE; g.I = 0;
     g.tiles_m = g.tiles_n = 0;
     g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_cols = n_rot_heads * head_dim; g.head_dim = head_dim;
-    g.nrm_ssq = nrm_ssq; g.nrm_parts = nrm_parts; g.nrm_eps = nrm_eps; g.nrm_inv_h = 1.0f / (float)K; g.nrm_ld = M;
+    g.nrm_rstd = nrm_rstd;
     return launch<MODE_ROPE>(g, N, (hipStream_t)stream, "vgpt_gemm_bf16_rope");
 }
 
 VGPT_EXPORT int vgpt_gemm_bf16_rope(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t,
                                     int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
                                     int n_rot_heads, int head_dim, void* stream) {
-    return gemm_rope_impl(A, W, C, cos_t, sin_t, M, N, K, lda, ldw, ldc, n_rot_heads, head_dim, stream, nullptr, 0, 0.f);
+    return gemm_rope_impl(A, W, C, cos_t, sin_t, M, N, K, lda, ldw, ldc, n_rot_heads, head_dim, stream, nullptr);
 }
 
 VGPT_EXPORT int vgpt_gemm_bf16_rope_prenorm(const void* A, const void* W, void* C, const float* cos_t, const float* sin_t,
-                                            const float* ssq, int n_partials, float eps, int64_t M, int64_t N, int64_t K,
-                                            int64_t lda, int64_t ldw, int64_t ldc, int n_rot_heads, int head_dim, void* stream) {
-    VGPT_REQUIRE(ssq && n_partials > 0 && eps >= 0.f, VGPT_ERR_INVALID, "vgpt_gemm_bf16_rope_prenorm: needs the rows' partial sums of squares");
-    return gemm_rope_impl(A, W, C, cos_t, sin_t, M, N, K, lda, ldw, ldc, n_rot_heads, head_dim, stream, ssq, n_partials, eps);
+                                            const float* rstd, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                                            int64_t ldc, int n_rot_heads, int head_dim, void* stream) {
+    VGPT_REQUIRE(rstd, VGPT_ERR_INVALID, "vgpt_gemm_bf16_rope_prenorm: needs the rows' 1 / rms");
+    return gemm_rope_impl(A, W, C, cos_t, sin_t, M, N, K, lda, ldw, ldc, n_rot_heads, head_dim, stream, rstd);
 }
 

@@ -209,10 +209,10 @@ VGPT_EXPORT int vgpt_rope_qk_inplace(void* qkv, const float* cos_t, const float*
 }
 
 // ---- RMSNorm folded into the GEMMs around it (gemm_bf16.hip: vgpt_gemm_bf16_resid_ssq -> *_prenorm) ----
-// Row sums of squares of a bf16 matrix: the statistics of the FIRST norm of a step, whose input no GEMM of ours produced
-// (one wave per row, fp32; a single "partial" in the layout the *_prenorm entries read).
-__global__ __launch_bounds__(256) void rms_ssq_kernel(const bf16* __restrict__ x, float* __restrict__ out, int64_t rows, int H,
-                                                      int64_t ldx) {
+// 1 / rms of the rows of a bf16 matrix: the statistics of the FIRST norm of a step, whose input no GEMM of ours produced
+// (one wave per row, fp32; what the *_prenorm entries read).
+__global__ __launch_bounds__(256) void rms_rstd_kernel(const bf16* __restrict__ x, float* __restrict__ out, int64_t rows, int H,
+                                                       int64_t ldx, float eps) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t wave_stride = (int64_t)gridDim.x * 4;
@@ -228,19 +228,19 @@ __global__ __launch_bounds__(256) void rms_ssq_kernel(const bf16* __restrict__ x
             }
         }
         ss = wave_sum(ss);
-        if (lane == 0) out[row] = ss;
+        if (lane == 0) out[row] = rsqrtf(ss / (float)H + eps);
     }
 }
 
-VGPT_EXPORT int vgpt_rms_ssq(const void* x, float* ssq_out, int64_t rows, int64_t H, int64_t ldx, void* stream) {
-    VGPT_REQUIRE(rows >= 0 && H > 0 && H % 8 == 0 && ldx >= H && ldx % 8 == 0, VGPT_ERR_INVALID,
-                 "vgpt_rms_ssq: H and ldx must be multiples of 8, ldx >= H");
-    VGPT_REQUIRE(rows == 0 || (x && ssq_out), VGPT_ERR_INVALID, "vgpt_rms_ssq: null pointer");
-    VGPT_REQUIRE(((uintptr_t)x & 15) == 0, VGPT_ERR_UNSUPPORTED, "vgpt_rms_ssq: rows must be 16-byte aligned");
+VGPT_EXPORT int vgpt_rms_rstd(const void* x, float* rstd_out, int64_t rows, int64_t H, int64_t ldx, float eps, void* stream) {
+    VGPT_REQUIRE(rows >= 0 && H > 0 && H % 8 == 0 && ldx >= H && ldx % 8 == 0 && eps >= 0.f, VGPT_ERR_INVALID,
+                 "vgpt_rms_rstd: H and ldx must be multiples of 8, ldx >= H");
+    VGPT_REQUIRE(rows == 0 || (x && rstd_out), VGPT_ERR_INVALID, "vgpt_rms_rstd: null pointer");
+    VGPT_REQUIRE(((uintptr_t)x & 15) == 0, VGPT_ERR_UNSUPPORTED, "vgpt_rms_rstd: rows must be 16-byte aligned");
     if (rows == 0) return VGPT_OK;
     const int blocks = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
-    hipLaunchKernelGGL(rms_ssq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ssq_out, rows, (int)H, ldx);
-    VGPT_CHECK_LAUNCH("vgpt_rms_ssq");
+    hipLaunchKernelGGL(rms_rstd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, rstd_out, rows, (int)H, ldx, eps);
+    VGPT_CHECK_LAUNCH("vgpt_rms_rstd");
     return VGPT_OK;
 }
 

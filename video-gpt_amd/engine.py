@@ -284,11 +284,13 @@ class StaticDenoiser:
             fuse_norms = os.environ.get("VGPT_FUSE_NORMS", "1") != "0"
         if fuse_norms:
             Ms = self.Ma if S else B * L
-            pa, pb = ops.norm_partials(Ms, H, nq * hd), ops.norm_partials(Ms, H, I)
-            if pa > 0 and pb > 0:
-                f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            wa, wb = ops.norm_workspace_bytes(Ms, H, nq * hd), ops.norm_workspace_bytes(Ms, H, I)
+            if wa > 0 and wb > 0:
                 wq, wgu = folded_weights(model)
-                self.fuse = {"pa": pa, "pb": pb, "ssq0": f32(1, Ms), "ssq_a": f32(pa, Ms), "ssq_b": f32(pb, Ms), "wq": wq, "wgu": wgu}
+                # rstd_in / rstd_post: 1 / rms of the stream in front of a layer's input / post-attention norm
+                self.fuse = {"rstd_in": torch.empty(Ms, dtype=torch.float32, device=dev),
+                             "rstd_post": torch.empty(Ms, dtype=torch.float32, device=dev),
+                             "ws": ops.norm_workspace(max(wa, wb), dev), "wq": wq, "wgu": wgu}
         self.temb_sin = e(n_frames, 256)
         self.tt_h = e(n_frames, H)
         self.te_h = e(n_frames, H)
@@ -537,15 +539,13 @@ class StaticDenoiser:
         if fz is not None:
             # the statistics of the first norm: the embedded rows are no GEMM's output.  From here on every residual stream is
             # written by linear_resid_ssq, which leaves the next norm's partial sums of squares behind
-            ops.rms_ssq(self.hid, out=fz["ssq0"])
-            ssq_in, parts_in = fz["ssq0"], 1
+            ops.rms_rstd(self.hid, m.llm.layers[0].input_layernorm.variance_epsilon, out=fz["rstd_in"])
 
         def qkv_proj(li_, layer, out):
             at = layer.self_attn
             if fz is None:
                 return ops.linear_qkv_rope(self.nrm, at.qkv_proj.weight, rope[0], rope[1], nq, nk, hd, out=out)
-            return ops.linear_qkv_rope_prenorm(self.hid, fz["wq"][li_], rope[0], rope[1], ssq_in, parts_in,
-                                               layer.input_layernorm.variance_epsilon, nq, nk, hd, out=out)
+            return ops.linear_qkv_rope_prenorm(self.hid, fz["wq"][li_], rope[0], rope[1], fz["rstd_in"], nq, nk, hd, out=out)
         for li_, layer in enumerate(m.llm.layers):
             at, mlp = layer.self_attn, layer.mlp
             if fz is None:
@@ -571,11 +571,13 @@ class StaticDenoiser:
                 else:
                     ops.attention_qkv(self.qkv, self.pm, nq, nk, hd, out=self.ctx)
             if fz is not None:
-                ops.linear_resid_ssq(self.ctx, at.o_proj.weight, self.hid, fz["ssq_a"], out=self.hid)
-                ops.gated_mlp_act_prenorm(self.hid, fz["wgu"][li_], fz["ssq_a"], fz["pa"],
-                                          layer.post_attention_layernorm.variance_epsilon, mlp.act, out=self.act)
-                ops.linear_resid_ssq(self.act, mlp.down_proj.weight, self.hid, fz["ssq_b"], out=self.hid)
-                ssq_in, parts_in = fz["ssq_b"], fz["pb"]
+                ops.linear_resid_rstd(self.ctx, at.o_proj.weight, self.hid, fz["rstd_post"], fz["ws"],
+                                      layer.post_attention_layernorm.variance_epsilon, out=self.hid)
+                ops.gated_mlp_act_prenorm(self.hid, fz["wgu"][li_], fz["rstd_post"], mlp.act, out=self.act)
+                # the statistic the NEXT layer's input norm reads (its eps; the last layer's goes unused: the final norm is a
+                # separate kernel)
+                nxt = m.llm.layers[min(li_ + 1, len(m.llm.layers) - 1)].input_layernorm.variance_epsilon
+                ops.linear_resid_rstd(self.act, mlp.down_proj.weight, self.hid, fz["rstd_in"], fz["ws"], nxt, out=self.hid)
                 continue
             ops.linear(self.ctx, at.o_proj.weight, residual=self.hid, out=self.hid)
             ops.rmsnorm(self.hid, layer.post_attention_layernorm.weight,

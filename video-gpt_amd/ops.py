@@ -130,40 +130,46 @@ def linear(x: torch.Tensor, weight: torch.Tensor, residual: Optional[torch.Tenso
     return out
 
 
-# ---- RMSNorm folded into the GEMMs around it (include/vgpt.h: vgpt_gemm_bf16_resid_ssq -> *_prenorm) ----
+# ---- RMSNorm folded into the GEMMs around it (include/vgpt.h: vgpt_gemm_bf16_resid_rstd -> *_prenorm) ----
 
-def norm_partials(M: int, N: int, K: int) -> int:
-    """Partial sums per row linear_resid_ssq writes for this shape; 0 = the shape keeps the separate RMSNorm."""
-    return int(_lib.load().vgpt_gemm_norm_partials(M, N, K))
+def norm_workspace_bytes(M: int, N: int, K: int) -> int:
+    """Workspace bytes of linear_resid_rstd for this shape; 0 = the shape keeps the separate RMSNorm."""
+    return int(_lib.load().vgpt_gemm_norm_workspace_bytes(M, N, K))
 
 
-def linear_resid_ssq(x: torch.Tensor, weight: torch.Tensor, residual: torch.Tensor, ssq: torch.Tensor, out: torch.Tensor):
-    """out = x @ weight.T + residual, and ssq (n_partials, M) fp32 = partial row sums of out^2 (on the rounded values) for the
-    RMSNorm that reads `out` next.  `out` may be `residual` (in place)."""
-    _chk(x, BF16, "linear_resid_ssq.x"); _chk(weight, BF16, "linear_resid_ssq.weight"); _chk(residual, BF16, "linear_resid_ssq.residual")
-    _chk(out, BF16, "linear_resid_ssq.out"); _chk(ssq, torch.float32, "linear_resid_ssq.ssq")
+def norm_workspace(nbytes: int, device) -> torch.Tensor:
+    """A zeroed, 256-byte aligned workspace (its arrival counters are left at zero by every launch)."""
+    return torch.zeros((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
+
+
+def linear_resid_rstd(x: torch.Tensor, weight: torch.Tensor, residual: torch.Tensor, rstd: torch.Tensor, workspace: torch.Tensor,
+                      eps: float, out: torch.Tensor):
+    """out = x @ weight.T + residual, and rstd (M,) fp32 = 1 / rms of the rows of `out` (on the rounded values) for the RMSNorm
+    that reads `out` next.  `out` may be `residual` (in place)."""
+    _chk(x, BF16, "linear_resid_rstd.x"); _chk(weight, BF16, "linear_resid_rstd.weight"); _chk(residual, BF16, "linear_resid_rstd.residual")
+    _chk(out, BF16, "linear_resid_rstd.out"); _chk(rstd, torch.float32, "linear_resid_rstd.rstd")
+    _chk(workspace, torch.uint8, "linear_resid_rstd.workspace")
     K, N = x.shape[-1], weight.shape[0]
     M = x.numel() // K
-    parts = norm_partials(M, N, K)
-    if weight.shape[1] != K or residual.numel() != M * N or out.numel() != M * N or parts == 0 or ssq.numel() != parts * M:
-        raise VgptError("linear_resid_ssq: shape mismatch (ssq must be (norm_partials(M, N, K), M))")
-    call("vgpt_gemm_bf16_resid_ssq", x.data_ptr(), weight.data_ptr(), out.data_ptr(), residual.data_ptr(), ssq.data_ptr(), M, N, K,
-         K, K, N, N, _stream())
+    if weight.shape[1] != K or residual.numel() != M * N or out.numel() != M * N or rstd.numel() != M:
+        raise VgptError("linear_resid_rstd: shape mismatch")
+    call("vgpt_gemm_bf16_resid_rstd", x.data_ptr(), weight.data_ptr(), out.data_ptr(), residual.data_ptr(), rstd.data_ptr(),
+         workspace.data_ptr(), workspace.numel(), float(eps), M, N, K, K, K, N, N, _stream())
     return out
 
 
-def rms_ssq(x: torch.Tensor, out: Optional[torch.Tensor] = None):
-    """Row sums of squares of x (..., H) as ONE partial (1, M) fp32."""
-    _chk(x, BF16, "rms_ssq.x")
+def rms_rstd(x: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None):
+    """1 / rms of the rows of x (..., H): (M,) fp32."""
+    _chk(x, BF16, "rms_rstd.x")
     H = x.shape[-1]
     M = x.numel() // H
     if out is None:
-        out = torch.empty(1, M, dtype=torch.float32, device=x.device)
+        out = torch.empty(M, dtype=torch.float32, device=x.device)
     else:
-        _chk(out, torch.float32, "rms_ssq.out")
-        if out.numel() < M:
-            raise VgptError("rms_ssq: out too small")
-    call("vgpt_rms_ssq", x.data_ptr(), out.data_ptr(), M, H, H, _stream())
+        _chk(out, torch.float32, "rms_rstd.out")
+        if out.numel() != M:
+            raise VgptError("rms_rstd: out size mismatch")
+    call("vgpt_rms_rstd", x.data_ptr(), out.data_ptr(), M, H, H, float(eps), _stream())
     return out
 
 
@@ -178,35 +184,34 @@ def fold_norm_gain(weight: torch.Tensor, gain: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def linear_qkv_rope_prenorm(x: torch.Tensor, weight_folded: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, ssq: torch.Tensor,
-                            n_partials: int, eps: float, n_q_heads: int, n_kv_heads: int, head_dim: int, out: torch.Tensor):
+def linear_qkv_rope_prenorm(x: torch.Tensor, weight_folded: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, rstd: torch.Tensor,
+                            n_q_heads: int, n_kv_heads: int, head_dim: int, out: torch.Tensor):
     """linear_qkv_rope(rmsnorm(x), W) with the norm folded in: x is the raw stream, weight_folded = fold_norm_gain(W, gain),
-    ssq (n_partials, M) the stream's partial row sums of squares."""
+    rstd (M,) the rows' 1 / rms."""
     _chk(x, BF16, "qkv_prenorm.x"); _chk(weight_folded, BF16, "qkv_prenorm.weight"); _chk(out, BF16, "qkv_prenorm.out")
-    _chk(cos, torch.float32, "qkv_prenorm.cos"); _chk(sin, torch.float32, "qkv_prenorm.sin"); _chk(ssq, torch.float32, "qkv_prenorm.ssq")
+    _chk(cos, torch.float32, "qkv_prenorm.cos"); _chk(sin, torch.float32, "qkv_prenorm.sin"); _chk(rstd, torch.float32, "qkv_prenorm.rstd")
     K, N = x.shape[-1], weight_folded.shape[0]
     M = x.numel() // K
     if weight_folded.shape[1] != K or N != (n_q_heads + 2 * n_kv_heads) * head_dim or out.numel() != M * N:
         raise VgptError("linear_qkv_rope_prenorm: shape mismatch")
-    if cos.numel() != M * (head_dim // 2) or sin.numel() != cos.numel() or ssq.numel() < n_partials * M:
+    if cos.numel() != M * (head_dim // 2) or sin.numel() != cos.numel() or rstd.numel() != M:
         raise VgptError("linear_qkv_rope_prenorm: table / statistics size mismatch")
     call("vgpt_gemm_bf16_rope_prenorm", x.data_ptr(), weight_folded.data_ptr(), out.data_ptr(), cos.data_ptr(), sin.data_ptr(),
-         ssq.data_ptr(), n_partials, float(eps), M, N, K, K, K, N, n_q_heads + n_kv_heads, head_dim, _stream())
+         rstd.data_ptr(), M, N, K, K, K, N, n_q_heads + n_kv_heads, head_dim, _stream())
     return out
 
 
-def gated_mlp_act_prenorm(x: torch.Tensor, w_gate_up_folded: torch.Tensor, ssq: torch.Tensor, n_partials: int, eps: float,
-                          act: int, out: torch.Tensor):
+def gated_mlp_act_prenorm(x: torch.Tensor, w_gate_up_folded: torch.Tensor, rstd: torch.Tensor, act: int, out: torch.Tensor):
     """gated_mlp_act(rmsnorm(x), W) with the norm folded in (see linear_qkv_rope_prenorm)."""
     _chk(x, BF16, "gated_prenorm.x"); _chk(w_gate_up_folded, BF16, "gated_prenorm.w"); _chk(out, BF16, "gated_prenorm.out")
-    _chk(ssq, torch.float32, "gated_prenorm.ssq")
+    _chk(rstd, torch.float32, "gated_prenorm.rstd")
     K = x.shape[-1]
     I = w_gate_up_folded.shape[0] // 2
     M = x.numel() // K
-    if w_gate_up_folded.shape[1] != K or out.numel() != M * I or ssq.numel() < n_partials * M:
+    if w_gate_up_folded.shape[1] != K or out.numel() != M * I or rstd.numel() != M:
         raise VgptError("gated_mlp_act_prenorm: shape mismatch")
-    call("vgpt_gated_mlp_act_fwd_prenorm", x.data_ptr(), w_gate_up_folded.data_ptr(), out.data_ptr(), ssq.data_ptr(), n_partials,
-         float(eps), M, I, K, K, K, I, act, _stream())
+    call("vgpt_gated_mlp_act_fwd_prenorm", x.data_ptr(), w_gate_up_folded.data_ptr(), out.data_ptr(), rstd.data_ptr(), M, I, K,
+         K, K, I, act, _stream())
     return out
 
 
