@@ -340,6 +340,8 @@ def build_reference_model(cfg, params, cls_name="LVM"):
     model = getattr(ns, cls_name)(hf_config(cfg), patch_size=cfg.patch_size, in_channels=cfg.in_channels,
                                   pe_interpolation=cfg.pe_interpolation, pos_embed_max_size=cfg.pos_embed_max_size)
     sd = {k: v for k, v in params.items()}
+    if "input_final_layer.weight" in sd:
+        model.init_input_final_layer()            # LVM/model.py:246-253: the optional head of input_output_return
     own = model.state_dict()
     extra = [k for k in own if k not in sd]
     # the only keys the oracle dict lacks are the rotary inv_freq buffers of the installed transformers module

@@ -233,15 +233,17 @@ def patch_multiple_resolutions(p, cfg: Phi3Cfg, pos_embed, latents: List[torch.T
 
 def frame_block_forward(p, cfg: Phi3Cfg, x: List[torch.Tensor], timestep: torch.Tensor, input_ids, input_img_latents,
                         input_image_sizes, attention_mask, position_ids, denoise_image_sizes, time_emb_inx,
-                        return_hidden: bool = False):
-    """LVM/model.py:399-501 at world_size 1 (also LVMTraining.forward :752-845, same body)."""
+                        return_hidden: bool = False, input_output_return: bool = False):
+    """LVM/model.py:399-501 at world_size 1 (also LVMTraining.forward :752-845, same body).  input_output_return
+    (LVM/model.py:488-497): also the `input_final_layer` head -- a plain Linear on the last hidden state -- on every condition
+    frame's rows, unpatchified."""
     pos_embed = p["pos_embed"]
     xs, _, shapes = patch_multiple_resolutions(p, cfg, pos_embed, x, False)
     dtype = xs[0].dtype
     time_token = timestep_embedder(p, "time_token", timestep, dtype)
     input_latents = []
     if input_img_latents is not None:
-        input_latents, _, _ = patch_multiple_resolutions(p, cfg, pos_embed, input_img_latents, True)
+        input_latents, _, input_shapes = patch_multiple_resolutions(p, cfg, pos_embed, input_img_latents, True)
     emb = F.embedding(input_ids, p["llm.embed_tokens.weight"]).clone()
     n = 0
     for b in input_image_sizes.keys():
@@ -267,6 +269,14 @@ def frame_block_forward(p, cfg: Phi3Cfg, x: List[torch.Tensor], timestep: torch.
             y = final_layer(p, out[b:b + 1, s:e], time_emb[k:k + 1])
             latents.append(unpatchify(y, shapes[k][0], shapes[k][1], cfg.patch_size, cfg.in_channels))
             k += 1
+    if input_output_return:
+        preds, k = [], 0
+        for b in input_image_sizes.keys():
+            for s, e in input_image_sizes[b]:
+                y = F.linear(out[b:b + 1, s:e], p["input_final_layer.weight"], p["input_final_layer.bias"])
+                preds.append(unpatchify(y, input_shapes[k][0], input_shapes[k][1], cfg.patch_size, cfg.in_channels))
+                k += 1
+        return latents, preds
     return (latents, out) if return_hidden else latents
 
 
@@ -516,13 +526,20 @@ def collate_stage1(F_list: List[int], N: int, pad_id: int = 2, sp: int = 1):
 # stage-1 loss   (LVM/train_helper/loss.py:128-243) with externally supplied noise / times
 # ------------------------------------------------------------------------------------------------
 
-def stage1_loss(p, cfg, x1: List[torch.Tensor], x0, t, clean_latents, x0_in, t_in, batch):
-    """xt = t x1 + (1-t) x0; clean inputs noised the same way with t_in in [0.9,1]; per-frame MSE (order=2)."""
+def stage1_loss(p, cfg, x1: List[torch.Tensor], x0, t, clean_latents, x0_in, t_in, batch, input_output_return: bool = False):
+    """xt = t x1 + (1-t) x0; clean inputs noised the same way with t_in in [0.9,1]; per-frame MSE (order=2).
+    input_output_return (loss.py:194-197,220-225): the model also predicts the CLEAN condition latents from the noised ones it
+    was given (input_final_layer head); their per-frame MSE terms are appended to the loss vector."""
     xt = [t[i] * x1[i] + (1 - t[i]) * x0[i] for i in range(len(x1))]
     cl = [t_in[i] * clean_latents[i] + (1 - t_in[i]) * x0_in[i] for i in range(len(clean_latents))]
     pred = frame_block_forward(p, cfg, xt, t, batch["input_ids"], cl, batch["input_image_sizes"],
                                batch["attention_mask"], batch["position_ids"], batch["denoise_image_sizes"],
-                               batch["time_emb_inx"])
+                               batch["time_emb_inx"], input_output_return=input_output_return)
+    if input_output_return:
+        pred, pred_in = pred
+        loss = torch.stack([((x1[i] - pred[i]) ** 2).mean() for i in range(len(x1))])
+        loss_in = torch.stack([((clean_latents[i] - pred_in[i]) ** 2).mean() for i in range(len(clean_latents))])
+        return torch.cat([loss, loss_in]), xt
     return torch.stack([((x1[i] - pred[i]) ** 2).mean() for i in range(len(x1))]), xt
 
 
@@ -564,3 +581,14 @@ def make_params(cfg: Phi3Cfg, seed: int = 0, dtype=torch.float32, pos_embed: boo
     if pos_embed:
         p["pos_embed"] = make_pos_embed(cfg).to(dtype)
     return p
+
+
+def add_input_final_layer(p: Dict[str, torch.Tensor], cfg: Phi3Cfg, seed: int = 77) -> Dict[str, torch.Tensor]:
+    """The optional `input_final_layer` head (LVM/model.py:246-253 creates it zero-initialised; seeded N(0, 0.02) here so
+    that its outputs and gradients say something)."""
+    g = torch.Generator("cpu").manual_seed(seed)
+    pp = cfg.patch_size * cfg.patch_size * cfg.in_channels
+    q = dict(p)
+    q["input_final_layer.weight"] = (torch.randn(pp, cfg.hidden_size, generator=g) * 0.02).to(torch.bfloat16).float()
+    q["input_final_layer.bias"] = (torch.randn(pp, generator=g) * 0.02).to(torch.bfloat16).float()
+    return q

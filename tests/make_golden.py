@@ -196,7 +196,7 @@ def lvm_glue_vectors():
     np.savez_compressed(os.path.join(OUT, "ref_lvm_glue_tiny.npz"), **out)
 
 
-def _run_reference_loss(model, ns, x1, clean, batch, seed, frame_blocks=None):
+def _run_reference_loss(model, ns, x1, clean, batch, seed, frame_blocks=None, input_output_return=False):
     """training_losses_x1_noise_input (LVM/train_helper/loss.py:128-243) on the reference LVMTraining; the noise / times
     it draws from torch's (and python's) global RNG are recovered by replaying the same draws after the same seed."""
     import random
@@ -216,11 +216,17 @@ def _run_reference_loss(model, ns, x1, clean, batch, seed, frame_blocks=None):
     def spy(xt, tt, **kw):
         seen["xt"], seen["t"], seen["inp"] = [a.clone() for a in xt], tt.clone(), [a.clone() for a in kw["input_img_latents"]]
         res = inner(xt, tt, **kw)
-        seen["pred"] = [a.detach().clone() for a in res]
+        if kw.get("input_output_return", False):
+            seen["pred"] = [a.detach().clone() for a in res[0]]
+            seen["pred_in"] = [a.detach().clone() for a in res[1]]
+        else:
+            seen["pred"] = [a.detach().clone() for a in res]
         return res
     model.forward = spy
     kw = {k: batch[k] for k in GC.BATCH_KEYS}
     kw.update(input_img_latents=[a.clone() for a in cl], return_past_key_values=False)
+    if input_output_return:
+        kw["input_output_return"] = True
     torch.manual_seed(seed); random.seed(seed)
     model.zero_grad()
     terms = ns.training_losses_x1_noise_input(model, [a.clone() for a in x1l], kw, frame_blocks=frame_blocks, device="cpu")
@@ -233,6 +239,8 @@ def _run_reference_loss(model, ns, x1, clean, batch, seed, frame_blocks=None):
         assert torch.equal(seen["inp"][i], ti[i] * cl[i] + (1 - ti[i]) * x0i[i])
     out = dict(x0=torch.cat(x0).numpy(), t=t.numpy(), x0_in=torch.cat(x0i).numpy(), t_in=ti.numpy(),
                xt=torch.cat(seen["xt"]).numpy(), pred=torch.cat(seen["pred"]).numpy(), loss=terms["loss"].detach().numpy())
+    if input_output_return:
+        out["pred_in"] = torch.cat(seen["pred_in"]).numpy()
     for name, prm in model.named_parameters():
         if prm.grad is not None:
             out["gnorm." + name] = np.asarray(float(prm.grad.double().norm()))
@@ -258,6 +266,32 @@ def loss_vectors():
     x1b, cleanb = torch.randn(nd, 4, 8, 8, generator=gen), torch.randn(nc, 4, 8, 8, generator=gen)
     out = _run_reference_loss(model, ns, x1b, cleanb, fb, 321, frame_blocks=fb["frame_blocks"])
     np.savez_compressed(os.path.join(OUT, "ref_loss_fbtrain_tiny.npz"), **out)
+
+
+def input_output_return_vectors():
+    """`input_output_return=True` (LVM/model.py:488-497, 832-841; loss branch LVM/train_helper/loss.py:194-197,220-225): the
+    reference's LVM.frame_block_forward on the tiny next-clip case and its LVMTraining + training_losses_x1_noise_input on the
+    stage-1 case, both with a seeded (non-zero) `input_final_layer` head -- outputs, the appended input-loss terms and every
+    parameter gradient of loss.mean()."""
+    from tests import smoke_case as SC
+    from tests import glue_cases as GC
+    cfg = R.TINY
+    p, batch, z, cond = SC.build_case(cfg)
+    p = R.add_input_final_layer(p, cfg)
+    model, ns = X.build_reference_model(cfg, p, "LVM")
+    okw = {k: batch[k] for k in GC.BATCH_KEYS}
+    out = {}
+    with torch.no_grad():
+        lat, pin = model.frame_block_forward([x.clone() for x in z], torch.full((len(z),), 0.3), input_img_latents=cond,
+                                             input_output_return=True, **okw)
+    out["fwd"] = torch.cat(lat).numpy(); out["fwd_in"] = torch.cat(pin).numpy()
+    p2, batch2, x1, x0, t, clean, x0i, ti = GC.stage1_case(cfg)
+    p2 = R.add_input_final_layer(p2, cfg)
+    model2, ns2 = X.build_reference_model(cfg, p2, "LVMTraining")
+    model2.train()
+    for k, v in _run_reference_loss(model2, ns2, x1, clean, batch2, 456, input_output_return=True).items():
+        out["loss." + k] = v
+    np.savez_compressed(os.path.join(OUT, "ref_input_output_return_tiny.npz"), **out)
 
 
 def pipeline_vectors():
@@ -349,6 +383,7 @@ if __name__ == "__main__":
     leaf_vectors()
     lvm_glue_vectors()
     loss_vectors()
+    input_output_return_vectors()
     pipeline_vectors()
     oracle_e2e_vectors()
     for f in sorted(os.listdir(OUT)):

@@ -250,6 +250,46 @@ def test_restatement_matches_reference_loss_and_gradients(name):
     assert checked == len([k for k in pr if k != "pos_embed"])
 
 
+def test_restatement_matches_reference_input_output_return():
+    """`input_output_return=True` (LVM/model.py:488-497, 832-841; loss.py:194-197,220-225), vectors produced by EXECUTING the
+    reference (tests/make_golden.py::input_output_return_vectors): the input_final_layer head's predictions, the loss vector
+    with the input terms appended, and every parameter gradient of loss.mean() -- the head's own included."""
+    from tests import smoke_case as SC
+    d = GC.load("ref_input_output_return_tiny.npz")
+    cfg = R.TINY
+    p, batch, z, cond = SC.build_case(cfg)
+    p = R.add_input_final_layer(p, cfg)
+    with torch.no_grad():
+        lat, pin = R.frame_block_forward(p, cfg, z, torch.full((len(z),), 0.3), batch["input_ids"], cond, batch["input_image_sizes"],
+                                         batch["attention_mask"], batch["position_ids"], batch["denoise_image_sizes"],
+                                         batch["time_emb_inx"], input_output_return=True)
+    assert float((torch.cat(lat) - T(d["fwd"])).abs().max()) <= GLUE_TOL
+    assert float((torch.cat(pin) - T(d["fwd_in"])).abs().max()) <= GLUE_TOL
+    assert float(T(d["fwd_in"]).abs().max()) > 1e-3                       # the seeded head says something
+    p2, batch2, x1, _, _, clean, _, _ = GC.stage1_case(cfg)
+    p2 = R.add_input_final_layer(p2, cfg)
+    pr = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in p2.items()}
+    loss, xt = R.stage1_loss(pr, cfg, list(x1.split(1)), list(T(d["loss.x0"]).split(1)), T(d["loss.t"]), list(clean.split(1)),
+                             list(T(d["loss.x0_in"]).split(1)), T(d["loss.t_in"]), batch2, input_output_return=True)
+    assert loss.shape == (x1.shape[0] + clean.shape[0],)
+    assert torch.equal(torch.cat(xt), T(d["loss.xt"]))
+    assert float((loss.detach() - T(d["loss.loss"])).abs().max()) <= GLUE_TOL
+    loss.mean().backward()
+    checked = 0
+    for key in d.files:
+        if not key.startswith("loss.grad."):
+            continue
+        name_ = key[len("loss.grad."):]
+        if "rotary_emb" in name_:
+            continue
+        gr = pr[name_].grad
+        ref_norm = float(d["loss.gnorm." + name_])
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-7, name_
+        assert np.abs(GC.sampled_grad(gr) - d[key]).max() <= 1e-5 * max(1.0, float(np.abs(d[key]).max())), name_
+        checked += 1
+    assert checked == len([k for k in pr if k != "pos_embed"]) and "input_final_layer.weight" in pr
+
+
 def test_oracle_round_composition_matches_reference_pipeline():
     """The reference's LVMPipeline.prompt_condition_frame_block_autoregressive_inference, executed (two chained rounds,
     tests/golden/ref_pipeline_tiny.npz), against the composition of oracle pieces the GPU pipeline tests use: condition

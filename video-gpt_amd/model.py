@@ -579,8 +579,12 @@ class LVM(nn.Module):
                             input_output_return=False, out=None):
         """LVM/model.py:399-501 at sequence-parallel size 1."""
         self._check_ready()
-        if padding_latent is not None or input_output_return:
-            raise VgptError("padding_latent / input_output_return are not used by the video path")
+        if padding_latent is not None and not (isinstance(padding_latent, (list, tuple)) and all(p_ is None for p_ in padding_latent)):
+            # LVM/model.py:292-309 appends `padding` tokens behind a frame's patch tokens; in THIS entry the frame's span then
+            # holds more than (h/p)(w/p) rows and the reference's own unpatchify (LVM/model.py:262) fails on the reshape.  A list
+            # of None (what patch_multiple_resolutions expands None to) is the only value the reference can run with.
+            raise VgptError("frame_block_forward: padding_latent entries other than None are not runnable in the reference "
+                            "either (unpatchify reshape, LVM/model.py:262)")
         assert input_ids is not None, "input_ids is None"
         seq, rows, shapes = self.assemble_sequence(x, timestep, input_ids, input_img_latents, input_image_sizes,
                                                    denoise_image_sizes, time_emb_inx)
@@ -594,9 +598,28 @@ class LVM(nn.Module):
             output = self.llm(inputs_embeds=seq, attention_mask=attention_mask, position_ids=position_ids,
                               past_key_values=past_key_values, offload_model=offload_model)
         latents = self.decode_frames(output.last_hidden_state, timestep, rows, shapes, out=out)
+        if input_output_return:
+            return latents, self.decode_input_frames(output.last_hidden_state, input_img_latents, input_image_sizes)
         if return_past_key_values:
             return latents, None
         return latents
+
+    def decode_input_frames(self, hidden, input_img_latents, input_image_sizes):
+        """LVM/model.py:488-497: the `input_final_layer` head (a plain Linear on the last hidden state, no modulation) on the
+        rows of every CONDITION frame, unpatchified -- what `input_output_return=True` adds to the outputs."""
+        head = self.input_final_layer        # AttributeError without init_input_final_layer(), as in the reference
+        B, L, H = hidden.shape
+        hidden2d = hidden.view(-1, H)
+        rows, lens = _index_rows(input_image_sizes, L, "span")
+        n = 0 if input_img_latents is None else len(input_img_latents)
+        if len(rows) != n:
+            raise AssertionError("input_image_sizes and input_img_latents disagree")
+        preds = []
+        for i in range(n):
+            h, w = input_img_latents[i].shape[-2:]
+            y = ops.linear_small(hidden2d[rows[i]:rows[i] + lens[i]], head.weight, head.bias)
+            preds.append(self.unpatchify(y[None], h, w).contiguous())
+        return preds
 
     @torch.no_grad()
     def frame_block_forward_with_cfg(self, x, timestep, input_ids, input_img_latents, input_image_sizes,
