@@ -431,6 +431,10 @@ int vgpt_lerp_frames(const float* x1, const float* x0, const float* t, void* out
 /* loss[f] = mean((x1[f]-pred[f])^2) (loss.py:209-218); dpred (optional, bf16) = d(mean_f loss)/dpred. */
 int vgpt_mse_frames(const void* pred, const float* x1, float* loss, void* dpred, int n_frames, int64_t elems,
                     void* stream);
+/* The same with the mean taken over n_mean >= n_frames terms: the frames' terms are part of a longer loss vector (the
+ * input-head terms of input_output_return, loss.py:220-225, appended before .mean()). */
+int vgpt_mse_frames_mean(const void* pred, const float* x1, float* loss, void* dpred, int n_frames, int n_mean, int64_t elems,
+                         void* stream);
 /* FinalLayer split for training: v = LN(x)(1+scale)+shift with xhat / rstd saved; and its backward (dmod fp32
  * (n_frames, 2H) accumulated with atomics — caller zeroes; dhidden rows written at dst_row[f] + t). */
 int vgpt_ln_mod_fwd(const void* hidden, const int32_t* src_row, const void* mod, void* v_out, float* xhat_out,

@@ -55,6 +55,8 @@ def build_product_model(cfg, params, device="cuda:0", cls_name="LVM"):
                       num_key_value_heads=cfg.num_key_value_heads, hidden_act=cfg.hidden_act,
                       rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, pad_token_id=cfg.pad_token_id)
     model = getattr(M, cls_name)(pc, pos_embed_max_size=cfg.pos_embed_max_size)
+    if "input_final_layer.weight" in params:
+        model.init_input_final_layer()        # the optional head of input_output_return (LVM/model.py:246-253)
     missing, unexpected = model.load_state_dict(params, strict=True), None
     return model.to(device, BF).eval()
 

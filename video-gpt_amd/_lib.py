@@ -102,6 +102,7 @@ SIGNATURES = {
     "vgpt_colsum": (c_int, [_P, c_int, _P, _I64, _I64, _I64, c_int, _P]),
     "vgpt_lerp_frames": (c_int, [_P, _P, _P, _P, c_int, _I64, _P]),
     "vgpt_mse_frames": (c_int, [_P, _P, _P, _P, c_int, _I64, _P]),
+    "vgpt_mse_frames_mean": (c_int, [_P, _P, _P, _P, c_int, c_int, _I64, _P]),
     "vgpt_ln_mod_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _I64, c_float, _P]),
     "vgpt_ln_mod_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I64, _P]),
     "vgpt_embed_bwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),

@@ -761,13 +761,19 @@ VGPT_EXPORT int vgpt_lerp_frames(const float* x1, const float* x0, const float* 
     LAUNCH_OK("vgpt_lerp_frames");
 }
 
-VGPT_EXPORT int vgpt_mse_frames(const void* pred, const float* x1, float* loss, void* dpred, int n_frames,
-                                int64_t elems, void* stream) {
-    VGPT_REQUIRE(pred && x1 && loss && n_frames >= 0 && elems > 0, VGPT_ERR_INVALID, "vgpt_mse_frames: bad argument");
+VGPT_EXPORT int vgpt_mse_frames_mean(const void* pred, const float* x1, float* loss, void* dpred, int n_frames, int n_mean,
+                                     int64_t elems, void* stream) {
+    VGPT_REQUIRE(pred && x1 && loss && n_frames >= 0 && n_mean >= n_frames && elems > 0, VGPT_ERR_INVALID,
+                 "vgpt_mse_frames_mean: bad argument");
     if (n_frames == 0) return VGPT_OK;
     hipLaunchKernelGGL(mse_frames_kernel, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, (const bf16*)pred, x1, loss,
-                       (bf16*)dpred, elems, n_frames);
-    LAUNCH_OK("vgpt_mse_frames");
+                       (bf16*)dpred, elems, n_mean);
+    LAUNCH_OK("vgpt_mse_frames_mean");
+}
+
+VGPT_EXPORT int vgpt_mse_frames(const void* pred, const float* x1, float* loss, void* dpred, int n_frames,
+                                int64_t elems, void* stream) {
+    return vgpt_mse_frames_mean(pred, x1, loss, dpred, n_frames, n_frames, elems, stream);
 }
 
 VGPT_EXPORT int vgpt_ln_mod_fwd(const void* hidden, const int32_t* src_row, const void* mod, void* v_out,

@@ -100,8 +100,6 @@ def training_losses_x1_noise_input(model, x1, model_kwargs=None, snr_type="unifo
                         "reference's scripts and not built")
     if model_kwargs is None:
         model_kwargs = {}
-    if model_kwargs.get("input_output_return", False):
-        raise VgptError("input_output_return (the input_final_layer head) is not built")
     if not isinstance(x1, (list, tuple)):
         x1 = list(x1.split(1))
     clean = list(model_kwargs.get("input_img_latents") or [])
@@ -110,6 +108,10 @@ def training_losses_x1_noise_input(model, x1, model_kwargs=None, snr_type="unifo
     batch = {k: model_kwargs[k] for k in ("input_ids", "attention_mask", "position_ids", "input_image_sizes",
                                           "denoise_image_sizes", "time_emb_inx")}
     cat = lambda xs: torch.cat(list(xs), dim=0) if len(xs) > 0 else None
+    ioret = bool(model_kwargs.get("input_output_return", False))      # loss.py:194-197,220-225: the input head's terms appended
     loss = trainer.step(batch, cat(x1), cat(x0), t, cat(clean), cat(x0_in) if clean else None, t_in,
-                        update=update and isinstance(model, Stage1Trainer), backward=isinstance(model, Stage1Trainer))
+                        update=update and isinstance(model, Stage1Trainer), backward=isinstance(model, Stage1Trainer),
+                        input_output_return=ioret)
+    if ioret:
+        return {"loss": loss, "input_loss": loss[len(x1):]}
     return {"loss": loss}

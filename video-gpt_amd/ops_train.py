@@ -146,10 +146,12 @@ def lerp_frames(x1, x0, t, out):
     return out
 
 
-def mse_frames(pred, x1, loss, dpred=None):
+def mse_frames(pred, x1, loss, dpred=None, n_mean=None):
+    """loss[f] = mean((x1[f] - pred[f])^2); dpred = d(mean over n_mean terms)/dpred (n_mean: the length of the whole loss
+    vector when these frames are only part of it; default: these frames alone)."""
     n = x1.shape[0]
-    call("vgpt_mse_frames", pred.data_ptr(), x1.data_ptr(), loss.data_ptr(), _ptr(dpred), n, x1.numel() // max(n, 1),
-         _stream())
+    call("vgpt_mse_frames_mean", pred.data_ptr(), x1.data_ptr(), loss.data_ptr(), _ptr(dpred), n, n if n_mean is None else n_mean,
+         x1.numel() // max(n, 1), _stream())
     return loss
 
 

@@ -190,13 +190,15 @@ class Stage1Trainer:
             keep[r0:r0 + ntok_x] = 0
         for r0 in t_rows:
             keep[r0] = 0
+        c_idx = torch.tensor([r0 + k for r0 in c_rows for k in range(ntok_x)], dtype=torch.int64, device=self.dev) if c_rows else None
         return dict(ids=ids.contiguous(), B=B, L=L, pm=ops.as_packed_mask(mask, self.dev), rope=self.model.llm.rope_tables(pos),
-                    x_rows=i32(x_rows), t_rows=i32(t_rows), c_rows=i32(c_rows) if c_rows else None,
+                    x_rows=i32(x_rows), t_rows=i32(t_rows), c_rows=i32(c_rows) if c_rows else None, c_idx=c_idx,
                     keep=keep.to(self.dev), ntok=ntok_x)
 
     # ------------------------------------------------------------------------------------------------
     def step(self, batch, x1: torch.Tensor, x0: torch.Tensor, t: torch.Tensor, clean: Optional[torch.Tensor],
-             x0_in: Optional[torch.Tensor], t_in: Optional[torch.Tensor], update: bool = True, backward: bool = True):
+             x0_in: Optional[torch.Tensor], t_in: Optional[torch.Tensor], update: bool = True, backward: bool = True,
+             input_output_return: bool = False):
         """One optimisation step.  x1/x0: (F, C, h, w) fp32 target latents / noise, t: (F,) fp32;
         clean/x0_in/t_in: the clean-frame latents and their noise (loss.py:166-192).  Returns the per-frame losses."""
         m, cfg = self.model, self.cfg
@@ -274,8 +276,26 @@ class Stage1Trainer:
         pred = y16.view(nf, h // p2, w // p2, p2, p2, C).permute(0, 5, 1, 3, 2, 4).reshape(nf, C, h, w).contiguous()
         loss = torch.empty(nf, dtype=F32, device=self.dev)
         dpred = self._buf("dpred", (nf, C, h, w))
-        T.mse_frames(pred, x1, loss, dpred)
-        self.last = dict(pred=pred, loss=loss, xt=xt)
+        head = None
+        if input_output_return:
+            # LVM/model.py:832-841 + loss.py:220-225: the input_final_layer head predicts the CLEAN condition latents from the
+            # last hidden state of their rows; its per-frame MSE terms are appended to the loss vector before .mean()
+            if cl is None:
+                raise VgptError("Stage1Trainer.step: input_output_return needs condition frames")
+            head = m.input_final_layer           # AttributeError without init_input_final_layer(), as in the reference
+            nfc = clean.shape[0]
+            vin = T.gather_rows(nrm, prep["c_rows"], ntok)                   # (nfc * ntok, H)
+            yin = ops.linear(vin, head.weight, bias=head.bias)
+            pred_in = yin.view(nfc, h // p2, w // p2, p2, p2, C).permute(0, 5, 1, 3, 2, 4).reshape(nfc, C, h, w).contiguous()
+            loss_in = torch.empty(nfc, dtype=F32, device=self.dev)
+            dpred_in = self._buf("dpred_in", (nfc, C, h, w))
+            T.mse_frames(pred_in, clean.to(self.dev, F32).contiguous(), loss_in, dpred_in, n_mean=nf + nfc)
+            T.mse_frames(pred, x1, loss, dpred, n_mean=nf + nfc)
+            loss = torch.cat([loss, loss_in])
+            self.last = dict(pred=pred, loss=loss, xt=xt, pred_in=pred_in)
+        else:
+            T.mse_frames(pred, x1, loss, dpred)
+            self.last = dict(pred=pred, loss=loss, xt=xt)
         if self.forward_only or not backward:
             if update:
                 raise VgptError("Stage1Trainer.step: an optimizer step needs the backward pass")
@@ -290,6 +310,11 @@ class Stage1Trainer:
         dnrm = self._buf("dnrm", (M, H)); dnrm.zero_()
         dmod = torch.zeros(nf, 2 * H, dtype=F32, device=self.dev)
         T.ln_mod_bwd(dv, xhat, rstd, mod, prep["x_rows"], dnrm, dmod, ntok)
+        if head is not None:
+            dyin = T.unpatchify_bwd(dpred_in)                                # (nfc * ntok, 16)
+            T.matmul(dyin, vin, out=g["input_final_layer.weight"], ta=True)
+            T.colsum(dyin, g["input_final_layer.bias"])
+            dnrm.index_copy_(0, prep["c_idx"], T.matmul(dyin, head.weight))  # condition rows: no other gradient reaches them here
         dh = self._buf("dh", (M, H)); dh_b = self._buf("dh_b", (M, H))
         T.rmsnorm_bwd(hbuf[nl], m.llm.norm.weight, dnrm, dh, g["llm.norm.weight"], m.llm.norm.variance_epsilon)
         # adaLN + t_embedder
