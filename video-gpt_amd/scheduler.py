@@ -61,6 +61,8 @@ class LVMScheduler:
         if any(k not in model_kwargs for k in need) or model_kwargs.get("offload_model"):
             return None
         self.last_engine_reused = False
+        from .train import wait_for_pending_update
+        wait_for_pending_update(owner)      # a trainer's overlapped AdamW update of these parameters may still be in flight
         self._owner_params = list(owner.parameters())
         key = self._engine_key(z, model_kwargs, prediction_type) if self.cache_engines else None
         cache = owner.__dict__.setdefault("_vgpt_engine_cache", {}) if key is not None else None

@@ -19,6 +19,7 @@ optimizer to DeepSpeed's bf16 AdamW (fp32 master weights).  Here:
 from __future__ import annotations
 
 import os
+import weakref
 
 from typing import Dict, List, Optional
 
@@ -31,6 +32,23 @@ from .engine import _rows, count_left_pads, pack_left_padded
 from .ops import BF16, VgptError
 
 F32 = torch.float32
+
+
+_TRAINER_OF = weakref.WeakKeyDictionary()   # model -> weakref to the trainer whose optimizer updates it on a stream of its own
+
+
+def wait_for_pending_update(model) -> None:
+    """Readers of `model`'s parameters outside Stage1Trainer.step() -- the sampler (validation clips through LVMPipeline),
+    state_dict() -- call this: with `overlap_optimizer` the last AdamW update may still be running on the trainer's own stream.
+    Makes the CURRENT stream wait for it; nothing to do otherwise."""
+    ref = _TRAINER_OF.get(model)
+    tr = ref() if ref is not None else None
+    if tr is not None:
+        tr.finish_optimizer()
+
+
+def _state_dict_barrier(module, prefix, keep_vars):
+    wait_for_pending_update(module)
 
 
 class Stage1Trainer:
@@ -76,6 +94,11 @@ class Stage1Trainer:
         # bucket and of every layer bucket, waited for where the next forward first reads those parameters
         self.overlap_optimizer = bool(overlap_optimizer) and self.dev.type == "cuda" and not forward_only
         self._opt_stream = torch.cuda.Stream(device=self.dev) if self.overlap_optimizer else None
+        if self.overlap_optimizer:
+            # parameters are read outside step() too: the sampler asks wait_for_pending_update(model), state_dict() through
+            # this hook
+            _TRAINER_OF[model] = weakref.ref(self)
+            model.register_state_dict_pre_hook(_state_dict_barrier)
         self._opt_events = None      # (small, [layer 0 .. nl-1]) of the update in flight
         self.step_count = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -398,6 +421,10 @@ class Stage1Trainer:
 
     # ------------------------------------------------------------------------------------------------
     def optimizer_step(self):
+        # an update still running on the optimizer's stream (overlap_optimizer) reads self.coef / self.sumsq and writes the
+        # master weights and moments this call is about to touch: wait for it (free in the normal flow, where the forward of
+        # the step that produced these gradients already waited for every layer's event)
+        self.finish_optimizer()
         lr = self.current_lr()
         self.last_lr = lr
         self.step_count += 1
