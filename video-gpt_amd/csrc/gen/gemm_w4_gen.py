@@ -29,7 +29,8 @@ V_WRA, V_WRW = 236, 237
 V_OA, V_OW = 240, 248   # per-piece, per-lane source byte offsets (A: 8, W: up to 8): row clamped per lane, chunk swizzled
 V_LAST = 255
 S_KLOAD, S_KLAST, S_CNT = 56, 57, 58
-S_FIRST, S_LAST = 56, 71
+S_FIRST, S_LAST = 36, 71
+S_PIECE, S_TMP, S_DELTA = 36, 59, 53   # NI = 9: s36..s52 piece offsets, s53..s55 buffer deltas
 # diagnostics (python gemm_w4_gen.py --debug N; results are garbage unless N == 16): 1 = no global fetches in the loop,
 # 2 = no LDS writes, 4 = no fragment reads, 8 = no barrier, 16 = s_memtime / s_memrealtime stamps around the loop and around
 # every barrier (outputs %[cyc], %[rt], %[bar]: loop cycles, loop time in 10-ns ticks, cycles spent at the barriers)
@@ -53,6 +54,23 @@ class Gen:
         self.NI = NI
         self.PA, self.PW = 8, NI          # pieces per wave and k-tile
         self.P = self.PA + self.PW
+        if NI <= 8:
+            # physical registers; the operands are copied in by the prologue
+            self.R, self.A, self.W = V_R, V_A, V_W
+            self.RDA, self.RDW = tuple(f"v{x}" for x in V_RDA), tuple(f"v{x}" for x in V_RDW)
+            self.WRA, self.WRW = f"v{V_WRA}", f"v{V_WRW}"
+            self.sgpr_pieces = False
+        else:
+            # NI = 9 (256 x 288 tiles): 288 accumulator registers -- sub-tile column 8 lives in VGPRs -- leave no room for
+            # copies: the LDS addresses are read-write operands used in place, the source offsets are one VGPR per operand
+            # plus one SGPR per piece (no per-lane row clamp: whole tiles only), the LDS buffers are toggled by adding +-D
+            self.R = 20
+            self.A = (88, 120)
+            self.W = (152, 188)
+            self.ACC8 = 224
+            self.RDA, self.RDW = ("%[rdA0]", "%[rdA1]"), ("%[rdW0]", "%[rdW1]")
+            self.WRA, self.WRW = "%[wrA]", "%[wrW]"
+            self.sgpr_pieces = True
         self.lines = []
         self.lgkm = []                    # tags of issued LGKM operations, program order
         self.done = 0                     # lgkm[:done] are known complete
@@ -95,45 +113,65 @@ class Gen:
 
     # -- pieces --
     def piece_regs(self, p):
-        return V_R + 4 * p
+        return self.R + 4 * p
 
     def load_piece(self, p, in_loop=True):
         if in_loop and (DEBUG & 1):
             return
+        if self.sgpr_pieces:
+            srd, vo = ("%[srdA]", "%[va]") if p < self.PA else ("%[srdW]", "%[vw]")
+            self.emit(f"s_add_u32 s{S_TMP}, s{S_PIECE + p}, s{S_KLOAD}")
+            self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, {vo}, {srd}, s{S_TMP} offen")
+            return
         srd, vo = ("%[srdA]", V_OA + p) if p < self.PA else ("%[srdW]", V_OW + p - self.PA)
         self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, v{vo}, {srd}, s{S_KLOAD} offen")
+
+    def toggle(self, regs, group):
+        """Move LDS address registers to the other staging buffer."""
+        if not self.sgpr_pieces:
+            for r_ in regs:
+                self.emit(f"v_xor_b32 {r_}, 0x{BUF_XOR:x}, {r_}")
+            return
+        sd = S_DELTA + group
+        for r_ in regs:
+            self.emit(f"v_add_u32 {r_}, s{sd}, {r_}")
+        self.emit(f"s_sub_u32 s{sd}, 0, s{sd}")
 
     def write_piece(self, p, in_loop=True):
         if in_loop and (DEBUG & 2):
             return
-        addr, q = (V_WRA, p) if p < self.PA else (V_WRW, p - self.PA)
-        self.emit(f"ds_write_b128 v{addr}, {vr(self.piece_regs(p))} offset:{q * 1024}")
+        addr, q = (self.WRA, p) if p < self.PA else (self.WRW, p - self.PA)
+        self.emit(f"ds_write_b128 {addr}, {vr(self.piece_regs(p))} offset:{q * 1024}")
         self.issue(("wr", p))
 
     def write_half(self, p, h, in_loop=True):
         if in_loop and (DEBUG & 2):
             return
-        addr, q = (V_WRA, p) if p < self.PA else (V_WRW, p - self.PA)
-        self.emit(f"ds_write_b64 v{addr}, {vr(self.piece_regs(p) + 2 * h, 2)} offset:{q * 1024 + 8 * h}")
+        addr, q = (self.WRA, p) if p < self.PA else (self.WRW, p - self.PA)
+        self.emit(f"ds_write_b64 {addr}, {vr(self.piece_regs(p) + 2 * h, 2)} offset:{q * 1024 + 8 * h}")
         self.issue(("wr", p, h))
 
     # -- fragments --
     def read_A(self, s, j, in_loop=True):
         if in_loop and (DEBUG & 4):
             self.issue(("A", s, j)); self.done = len(self.lgkm); return
-        self.emit(f"ds_read_b128 {vr(V_A[s] + 4 * j)}, v{V_RDA[s]} offset:{j * 2048}")
+        self.emit(f"ds_read_b128 {vr(self.A[s] + 4 * j)}, {self.RDA[s]} offset:{j * 2048}")
         self.issue(("A", s, j))
 
     def read_W(self, s, i, in_loop=True):
         if in_loop and (DEBUG & 4):
             self.issue(("W", s, i)); self.done = len(self.lgkm); return
-        self.emit(f"ds_read_b128 {vr(V_W[s] + 4 * i)}, v{V_RDW[s]} offset:{i * 2048}")
+        self.emit(f"ds_read_b128 {vr(self.W[s] + 4 * i)}, {self.RDW[s]} offset:{i * 2048}")
         self.issue(("W", s, i))
 
     def mfma(self, s, i, j, it):
         self.need([("A", s, j), ("W", s, i)], it)
-        a = (i * 8 + j) * 4
-        self.emit(f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], {vr(V_W[s] + 4 * i)}, {vr(V_A[s] + 4 * j)}, a[{a}:{a + 3}]")
+        if i < 8:
+            a = (i * 8 + j) * 4
+            acc = f"a[{a}:{a + 3}]"
+        else:
+            acc = vr(self.ACC8 + 4 * j)          # sub-tile column 8 of the 288-wide tile accumulates in VGPRs
+        self.emit(f"v_mfma_f32_16x16x32_bf16 {acc}, {vr(self.W[s] + 4 * i)}, {vr(self.A[s] + 4 * j)}, {acc}")
 
     def kstep(self, s, pieces, it):
         """NI steps of 8 MFMAs on fragment set s; meanwhile: the reads of set s ^ 1, the given staging pieces, and the
@@ -180,8 +218,7 @@ class Gen:
             if i == NI - 1:
                 # address toggles (VALU, no memory operation): the read addresses of the set just requested from
                 def tog():
-                    self.emit(f"v_xor_b32 v{V_RDA[o]}, 0x{BUF_XOR:x}, v{V_RDA[o]}")
-                    self.emit(f"v_xor_b32 v{V_RDW[o]}, 0x{BUF_XOR:x}, v{V_RDW[o]}")
+                    self.toggle((self.RDA[o], self.RDW[o]), o)
                 side.append((1, tog))
             for j in range(8):
                 self.mfma(s, i, j, it)
@@ -212,8 +249,7 @@ class Gen:
             self.emit("s_waitcnt lgkmcnt(0)")
             self.emit("s_sub_u32 s62, s62, s60")
             self.emit("s_add_u32 s64, s64, s62")
-        self.emit(f"v_xor_b32 v{V_WRA}, 0x{BUF_XOR:x}, v{V_WRA}")
-        self.emit(f"v_xor_b32 v{V_WRW}, 0x{BUF_XOR:x}, v{V_WRW}")
+        self.toggle((self.WRA, self.WRW), 2)
         self.emit(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
         self.emit(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
         self.emit(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
@@ -225,16 +261,23 @@ class Gen:
         e = self.emit
         lab = f"%="
         # ---- prologue ----
-        e(f"v_mov_b32 v{V_RDA[0]}, %[rdA]")
-        e(f"v_xor_b32 v{V_RDA[1]}, 64, %[rdA]")
-        e(f"v_mov_b32 v{V_RDW[0]}, %[rdW]")
-        e(f"v_xor_b32 v{V_RDW[1]}, 64, %[rdW]")
-        e(f"v_mov_b32 v{V_WRA}, %[wrA]")
-        e(f"v_mov_b32 v{V_WRW}, %[wrW]")
-        for p in range(PA):
-            e(f"v_mov_b32 v{V_OA + p}, %[oa{p}]")
-        for p in range(PW):
-            e(f"v_mov_b32 v{V_OW + p}, %[ow{p}]")
+        if not self.sgpr_pieces:
+            e(f"v_mov_b32 v{V_RDA[0]}, %[rdA]")
+            e(f"v_xor_b32 v{V_RDA[1]}, 64, %[rdA]")
+            e(f"v_mov_b32 v{V_RDW[0]}, %[rdW]")
+            e(f"v_xor_b32 v{V_RDW[1]}, 64, %[rdW]")
+            e(f"v_mov_b32 v{V_WRA}, %[wrA]")
+            e(f"v_mov_b32 v{V_WRW}, %[wrW]")
+            for p in range(PA):
+                e(f"v_mov_b32 v{V_OA + p}, %[oa{p}]")
+            for p in range(PW):
+                e(f"v_mov_b32 v{V_OW + p}, %[ow{p}]")
+        else:
+            for p in range(P):                             # lane p of %[tab]: byte offset of piece p (A: 0..7, W: 8..16)
+                e(f"v_readlane_b32 s{S_PIECE + p}, %[tab], {p}")
+            for g_ in range(3):                            # +D: the step from staging buffer 0 to buffer 1
+                e(f"s_mov_b32 s{S_DELTA + g_}, %[bufd]")
+            e("s_nop 4")
         e(f"s_mov_b32 s{S_KLOAD}, 0")
         e(f"s_sub_u32 s{S_KLAST}, %[nk], 1")
         e(f"s_lshl_b32 s{S_KLAST}, s{S_KLAST}, 7")
@@ -243,8 +286,11 @@ class Gen:
         order = first + second
         for p in order:                                    # tile 0
             self.load_piece(p, False)
-        for a in range(0, NI * 32, 1):                     # accumulators = 0 while the fetches fly
+        for a in range(0, min(NI, 8) * 32, 1):             # accumulators = 0 while the fetches fly
             e(f"v_accvgpr_write_b32 a{a}, 0")
+        if NI > 8:
+            for a in range(32):
+                e(f"v_mov_b32 v{self.ACC8 + a}, 0")
         e("s_waitcnt vmcnt(0)")
         for p in order:
             self.write_piece(p, False)
@@ -252,8 +298,7 @@ class Gen:
         e(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
         for p in order:                                    # tile 1 (fetch order = the loop's consumption order)
             self.load_piece(p, False)
-        e(f"v_xor_b32 v{V_WRA}, 0x{BUF_XOR:x}, v{V_WRA}")
-        e(f"v_xor_b32 v{V_WRW}, 0x{BUF_XOR:x}, v{V_WRW}")
+        self.toggle((self.WRA, self.WRW), 2)
         e(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
         e(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
         for p in first:                                    # "k-step 1 of tile -1": first half of tile 1 -> buffer 1, refetch for tile 2
@@ -269,8 +314,7 @@ class Gen:
             self.read_W(0, i, False)
             self.read_W(1, i, False)
         # the read addresses of set 0 now point at the buffer of tile 1 (they are toggled at the end of every k-step 1 ... see kstep)
-        e(f"v_xor_b32 v{V_RDA[0]}, 0x{BUF_XOR:x}, v{V_RDA[0]}")
-        e(f"v_xor_b32 v{V_RDW[0]}, 0x{BUF_XOR:x}, v{V_RDW[0]}")
+        self.toggle((self.RDA[0], self.RDW[0]), 0)
         self.drain()
         if DEBUG & 16:
             e("s_mov_b32 s64, 0")
@@ -300,6 +344,13 @@ class Gen:
             e("s_mov_b32 %[bar], s64")
         e("s_nop 15")
         e("s_nop 15")
+        if NI > 8:
+            # the VGPR accumulators (sub-tile column 8) leave through LDS: every wave's LDS traffic is over behind the barrier,
+            # each lane writes and later reads back its own 8 x 16 bytes (%[dump] = its address)
+            e("s_barrier")
+            for j in range(8):
+                e(f"ds_write_b128 %[dump], {vr(self.ACC8 + 4 * j)} offset:{j * 1024}")
+            e("s_waitcnt lgkmcnt(0)")
         return self.lines
 
 
@@ -321,7 +372,7 @@ def main():
            "// GENERATED by gen/gemm_w4_gen.py -- do not edit; `make gemm_w4_loop.inc` regenerates it.",
            "// The hand-scheduled main loop of gemm_w4_kernel (gemm_bf16.hip): see the generator for the schedule.",
            ""]
-    for NI in (8, 6):
+    for NI in (8, 6, 9):
         g = Gen(NI)
         lines = g.generate()
         n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
@@ -329,12 +380,13 @@ def main():
         out.append(f"#define VGPT_W4_ASM_NI{NI} \\")
         out.append(" \\\n".join('    "' + l + '\\n\\t"' for l in lines))
         out.append("")
-    cl = [f'"v{i}"' for i in range(V_R, V_LAST + 1)] + [f'"a{i}"' for i in range(256)] + \
-         [f'"s{i}"' for i in range(S_FIRST, S_LAST + 1)] + ['"scc"', '"memory"']
-    out.append("#define VGPT_W4_CLOBBERS \\")
-    rows = [", ".join(cl[k:k + 16]) for k in range(0, len(cl), 16)]
-    out.append(", \\\n".join("    " + r for r in rows))
-    out.append("")
+    for name, v0 in (("VGPT_W4_CLOBBERS", V_R), ("VGPT_W4_CLOBBERS_NI9", 20)):
+        cl = [f'"v{i}"' for i in range(v0, V_LAST + 1)] + [f'"a{i}"' for i in range(256)] + \
+             [f'"s{i}"' for i in range(S_FIRST, S_LAST + 1)] + ['"scc"', '"memory"']
+        out.append(f"#define {name} \\")
+        rows = [", ".join(cl[k:k + 16]) for k in range(0, len(cl), 16)]
+        out.append(", \\\n".join("    " + r for r in rows))
+        out.append("")
     sys.stdout.write("\n".join(out))
 
 
