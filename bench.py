@@ -105,7 +105,7 @@ def pmc_records(kind):
     """Counter evidence of one kernel kind from the committed rocprofv3 --pmc passes of THIS command (separate runs, as
     MI355X_MICROARCH.md prescribes; scripts/pmc_traffic.py / pmc_mfma.py): beyond-L2 bytes per launch and matrix-pipe busy
     fraction, each with the file it came from.  Not measured in this run -- `source` says so."""
-    pat = {"gate_up": ("gemm_w4_kernel<1", ""), "qkv_rope": ("gemm_bf16_kernel<2", "<256"),
+    pat = {"gate_up": ("gemm_w4_kernel<1", ""), "qkv_rope": ("gemm_w4_kernel<2", ""),
            "o_proj": ("gemm_w4_kernel<0", ""), "down_proj": ("gemm_w4_kernel<0", ""),
            "attn_fwd": ("attn_fwd_kernel<96", "")}[kind]
     out = {}
@@ -618,7 +618,7 @@ def main():
             tag = " + folded RMSNorm" if fz is not None else ""
             kinds = (("gate_up", "gemm_w4_kernel<MODE_GATED, 8> (four-wave hand-scheduled loop, 256 x 256 tiles; gate_up_proj + act(gate) * up epilogue" + tag + ")",
                       2 * rows * H * 2 * I, f_gate),
-                     ("qkv_rope", "gemm_bf16_kernel<MODE_ROPE, 256 x 288> (eight-wave LDS-DMA loop; qkv_proj + RoPE epilogue" + tag + ")",
+                     ("qkv_rope", "gemm_w4_kernel<MODE_ROPE, 9> (four-wave hand-scheduled loop, 256 x 288 tiles; qkv_proj + RoPE epilogue" + tag + ")",
                       2 * rows * H * 3 * H, f_qkv),
                      ("down_proj", "gemm_w4_kernel<MODE_PLAIN, 6> (four-wave hand-scheduled loop, 256 x 192 tiles; down_proj + residual"
                       + (" + 1 / rms of the output rows for the next norm" if fz is not None else "") + ")", 2 * rows * I * H, f_down),

@@ -32,14 +32,17 @@ if stamps:
     lib.vgpt_gemm_w4_debug_buffer.argtypes = [__import__("ctypes").c_void_p]
     lib.vgpt_gemm_w4_debug_buffer(dbg.data_ptr())
 for name, M, N, K, kind in (("gate_up", 4096, 8192, 3072, "gated"), ("o_proj", 4096, 3072, 3072, "resid"), ("down_proj", 4096, 3072, 8192, "resid"),
-                            ("square", 8192, 8192, 8192, "plain")):
+                            ("qkv_rope", 4096, 9216, 3072, "rope"), ("qkv_plain", 4096, 9216, 3072, "plain"), ("square", 8192, 8192, 8192, "plain")):
     x = torch.randn(M, K, device=dev).to(BF)
     ws = [(torch.randn((2 * N if kind == "gated" else N), K, device=dev) * 0.05).to(BF) for _ in range(4)]
     res = torch.randn(M, N, device=dev).to(BF)
     y = torch.empty(M, N, dtype=BF, device=dev)
+    if kind == "rope":
+        cos, sin = ops.rope_table(torch.arange(M, dtype=torch.int64, device=dev), ops.rope_inv_freq(96, 10000.0, dev))
     def call(w):
         if kind == "plain": ops.linear(x, w, out=y)
         elif kind == "resid": ops.linear(x, w, residual=res, out=y)
+        elif kind == "rope": ops.linear_qkv_rope(x, w, cos, sin, 32, 32, 96, out=y)
         else: ops.gated_mlp_act(x, w, ops.ACT_SILU, out=y)
     for i in range(6): call(ws[i % 4])
     torch.cuda.synchronize()

@@ -185,7 +185,7 @@ def test_gemm_families_agree_bit_for_bit(ops):
             finally:
                 lib.vgpt_gemm_set_family(prev)
         return out
-    for (M, N, K) in ((4096, 3072, 3072), (4096, 3072, 8192), (4100, 3076, 320)):
+    for (M, N, K) in ((4096, 3072, 3072), (4096, 3072, 8192), (4100, 3076, 320), (4096, 9216, 384)):   # the last: 256 x 288 tiles
         a = bf(torch.randn(M, K, generator=g(71))).to(DEV, BF)
         w = bf(torch.randn(N, K, generator=g(72)) * 0.05).to(DEV, BF)
         r = bf(torch.randn(M, N, generator=g(73))).to(DEV, BF)

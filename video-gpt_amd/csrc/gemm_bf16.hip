@@ -819,9 +819,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
 // barriers, k-tiles}
 #ifdef VGPT_W4_STAMPS
 #define VGPT_W4_OUTS [cyc] "=s"(st_cyc), [rt] "=s"(st_rt), [bar] "=s"(st_bar)
+#define VGPT_W4_OUTS_ VGPT_W4_OUTS,
 uint32_t* g_w4_dbg = nullptr;
 #else
 #define VGPT_W4_OUTS
+#define VGPT_W4_OUTS_
 #endif
 
 template <int I0, int N0, typename F>
@@ -849,6 +851,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     constexpr bool ROPE = MODE == MODE_ROPE;
     constexpr int BM = 256, BN = NI * 32, MI = 8;
     constexpr int A_BYTES = BM * BK * 2;
+    // LDS: NI <= 8: A buffers at 0 / 32 KiB, W buffers at 64 / 96 KiB (toggled by XOR 0x8000); NI == 9 (36-KiB W images):
+    // [A0 | W0 | A1 | W1], the two halves W4_BUFD bytes apart; behind the staging area the 256 rstd values of the folded RMSNorm
+    constexpr int W4_BUFD = A_BYTES + BN * BK * 2;
+    constexpr int STAGE_BYTES = NI == 9 ? 2 * W4_BUFD : 4 * A_BYTES;
+    constexpr int DUMP_OFF = 3 * A_BYTES;              // NI == 9: the VGPR accumulators (sub-tile column 8) leave through here
+    static_assert(MODE != MODE_GATED || NI != 9, "256 x 288 tiles: no gated mode (a wave's 144 slots are 4.5 gate / up pairs)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -882,14 +890,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     // per piece and lane: byte offset of the 16 bytes this lane fetches, relative to the tile's first A row (oa) / to the W
     // origin below (ow); rows clamped per lane into the matrix (rows past M / columns past N are computed and never stored)
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-    uint32_t oa[8], ow[8];
+    uint32_t oa[8] = {}, ow[8] = {};
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < (NI == 9 ? 0 : 8); ++p) {
         const int r = min((wave * 8 + p) * 8 + srow, g.M - 1 - m0);
         oa[p] = (uint32_t)(r * (int)g.lda + schunk * 8) * 2u;
     }
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < (NI == 9 ? 0 : 8); ++p) {
         const int sl = (wave * NI + min(p, NI - 1)) * 8 + srow;   // n-slot inside the tile
         int wr;
         if constexpr (ROPE) wr = min(rope_col_of_slot(n0 + sl, g.rope_cols, g.head_dim), n_rows_w - 1);
@@ -910,15 +918,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     const v4i32 srdA = srd(a_org), srdW = srd(w_org);
     const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 15, fk = lane >> 4, sw = frow & 7;
-    const uint32_t rdA = (uint32_t)((wm * 128 + frow) * 128 + ((fk ^ sw) * 16));
-    const uint32_t rdW = (uint32_t)(2 * A_BYTES + (wn * NI * 16 + frow) * 128 + ((fk ^ sw) * 16));
-    const uint32_t wrA = (uint32_t)(wave * 8192 + lane * 16);
-    const uint32_t wrW = (uint32_t)(2 * A_BYTES + wave * NI * 1024 + lane * 16);
+    constexpr int W_BASE = NI == 9 ? A_BYTES : 2 * A_BYTES;
+    uint32_t rdA = (uint32_t)((wm * 128 + frow) * 128 + ((fk ^ sw) * 16));
+    uint32_t rdW = (uint32_t)(W_BASE + (wn * NI * 16 + frow) * 128 + ((fk ^ sw) * 16));
+    uint32_t wrA = (uint32_t)(wave * 8192 + lane * 16);
+    uint32_t wrW = (uint32_t)(W_BASE + wave * NI * 1024 + lane * 16);
     const int nk = __builtin_amdgcn_readfirstlane(g.K / BK);
 
     // folded RMSNorm, consumer side: 1 / rms of this tile's 256 rows into LDS behind the staging buffers (thread t: row t);
     // the loop's barriers order it before the epilogue's reads
-    float* rs_lds = reinterpret_cast<float*>(smem + 4 * A_BYTES);
+    float* rs_lds = reinterpret_cast<float*>(smem + STAGE_BYTES);
     if constexpr (MODE != MODE_PLAIN) {
         if (g.nrm_rstd != nullptr) rs_lds[tid] = m0 + tid < g.M ? g.nrm_rstd[m0 + tid] : 0.f;
     }
@@ -926,7 +935,26 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
 #ifdef VGPT_W4_STAMPS
     const uint32_t st_t1 = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
-    if constexpr (NI == 8) {
+    if constexpr (NI == 9) {
+        // whole tiles only (launch_w4 checks): no per-lane row clamp, one SGPR offset per piece (lane p of `tab`: p < 8 the A
+        // pieces, 8 + p the W pieces) on top of one per-lane offset per operand
+        uint32_t tab;
+        {
+            const int pw = min(max(lane - 8, 0), NI - 1);
+            const int sl8 = (wave * NI + pw) * 8;
+            const int wrow = ROPE ? rope_col_of_slot(n0 + sl8, g.rope_cols, g.head_dim) : sl8;
+            tab = lane < 8 ? (uint32_t)((wave * 8 + lane) * 8 * (int)g.lda) * 2u : (uint32_t)(wrow * (int)g.ldw) * 2u;
+        }
+        const uint32_t va = (uint32_t)(srow * (int)g.lda + schunk * 8) * 2u, vw = (uint32_t)(srow * (int)g.ldw + schunk * 8) * 2u;
+        uint32_t rdA1 = rdA ^ 64u, rdW1 = rdW ^ 64u;
+        const uint32_t dump = (uint32_t)(DUMP_OFF + wave * 8192 + lane * 16);
+        const int bufd = W4_BUFD;
+        asm volatile(VGPT_W4_ASM_NI9
+                     : VGPT_W4_OUTS_ [rdA0] "+v"(rdA), [rdA1] "+v"(rdA1), [rdW0] "+v"(rdW), [rdW1] "+v"(rdW1), [wrA] "+v"(wrA), [wrW] "+v"(wrW)
+                     : [srdA] "s"(srdA), [srdW] "s"(srdW), [nk] "s"(nk), [wv] "s"(wave), [tab] "v"(tab), [va] "v"(va), [vw] "v"(vw),
+                       [dump] "v"(dump), [bufd] "s"(bufd)
+                     : VGPT_W4_CLOBBERS_NI9);
+    } else if constexpr (NI == 8) {
         asm volatile(VGPT_W4_ASM_NI8
                      : VGPT_W4_OUTS
                      : [srdA] "s"(srdA), [srdW] "s"(srdW), [rdA] "v"(rdA), [rdW] "v"(rdW), [wrA] "v"(wrA), [wrW] "v"(wrW), [nk] "s"(nk), [wv] "s"(wave),
@@ -957,6 +985,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     //      column lies outside the matrix gets an offset past the descriptor's range -- its loads return zeros, its stores are
     //      dropped -- so every row is one basic block (the residual quads of row j + 1 are requested before row j is stored) ----
     const int em = lane & 15, en = (lane >> 4) * 4;
+    // accumulator quad of sub-tile (i, j): AGPRs of the asm loop; column 8 of a 288-wide tile comes back from LDS
+    auto acc_of = [&](auto ic_, auto jc_) -> f32x4 {
+        constexpr int i_ = decltype(ic_)::value, j_ = decltype(jc_)::value;
+        if constexpr (i_ < 8) return w4_acc<i_ * 8 + j_>();
+        else return *reinterpret_cast<const f32x4*>(smem + DUMP_OFF + wave * 8192 + j_ * 1024 + lane * 16);
+    };
     constexpr uint32_t OOB = 0x80000000u;
     auto make_rs = [](const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); };
     auto pack4 = [](const f32x4& v) {
@@ -971,8 +1005,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
         // rows of the tile staged through the (now free) LDS
         const int half = g.head_dim >> 1;
         const int tab_bytes = (BM * half * 4 + 1023) & ~1023;
-        const bool staged = 2 * tab_bytes <= 4 * A_BYTES;
-        if (staged) {
+        // (launch_w4 only takes head dims whose two tables fit: w4_ok)
+        {
             __syncthreads();
             const int64_t row0_bytes = (int64_t)m0 * half * 4;
             const uint32_t last = (uint32_t)min((int64_t)g.M * half * 4 - row0_bytes - 16, (int64_t)tab_bytes);
@@ -986,45 +1020,53 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        // Branch-free over the sub-tiles (one basic block per row: the LDS reads, lane swaps and stores of consecutive sub-tiles
+        // overlap; with a branch per sub-tile the compiler drained every store before the next sub-tile's reads -- 72 round
+        // trips per lane).  Slot u = gs >> 4 is wave-uniform, the lane part of a slot is en = 4 (lane >> 4): inside the
+        // rotated region column n = (u / per) hd + (u % per) 8 + (en & 7) + (en & 8 ? hd / 2 : 0), the partner sits in lane ^ 32
+        // (en & 8 <=> upper half-wave), and both read cos / sin at d = (u % per) 8 + (en & 7) -- a valid table index for the
+        // plain (V) columns too, whose rotation is computed and discarded.
         const auto rsC = make_rs(g.C + (int64_t)m0 * g.ldc);
         const bool upper = (lane & 32) != 0;
-        static_for<0, MI>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const int ml = wm * 128 + j * 16 + em;
-            const bool m_ok = m0 + ml < g.M;
-            const int mr = m_ok ? ml : 0;
-            static_for<0, NI>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const int gs = n0 + nl0 + i * 16;
-                const int n = rope_col_of_slot(gs, g.rope_cols, g.head_dim);
-                f32x4 v = w4_acc<i * 8 + j>();
-                if (g.nrm_rstd != nullptr) {
-                    const float rs = rs_lds[ml];
+        const int per = g.head_dim >> 4;
+        auto rope_store = [&](auto normc) {
+            constexpr bool NORM = decltype(normc)::value;
+            static_for<0, MI>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int ml = wm * 128 + j * 16 + em;
+                const bool m_ok = m0 + ml < g.M;
+                const int mr = m_ok ? ml : 0;
+                [[maybe_unused]] const float rs = NORM ? rs_lds[ml] : 1.0f;
+                static_for<0, NI>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const int gs0 = n0 + wn * (NI * 16) + i * 16;         // wave-uniform first slot of the sub-tile
+                    const int u = gs0 >> 4;
+                    const bool rot = gs0 < g.rope_cols;                    // rope_cols is a multiple of 16
+                    const int dcol = (u % per) * 8 + (en & 7);
+                    const int n = rot ? (u / per) * g.head_dim + dcol + ((en & 8) ? half : 0) : gs0 + en;
+                    f32x4 v = acc_of(ic, jc);
+                    if constexpr (NORM) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] *= rs;
-                }
-                if (gs < g.rope_cols) {                       // wave-uniform: rope_cols is a multiple of 16
-                    const int d = (n % g.head_dim) - (upper ? half : 0);
-                    f32x4 cs, sn;
-                    if (staged) {
-                        cs = *reinterpret_cast<const f32x4*>(smem + (mr * half + d) * 4);
-                        sn = *reinterpret_cast<const f32x4*>(smem + tab_bytes + (mr * half + d) * 4);
-                    } else {
-                        cs = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)(m0 + mr) * half + d);
-                        sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)(m0 + mr) * half + d);
+                        for (int t = 0; t < 4; ++t) v[t] *= rs;
                     }
+                    const f32x4 cs = *reinterpret_cast<const f32x4*>(smem + (mr * half + dcol) * 4);
+                    const f32x4 sn = *reinterpret_cast<const f32x4*>(smem + tab_bytes + (mr * half + dcol) * 4);
+                    f32x4 o;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const float own = bf2f(f2bf(v[t]));
                         auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
                         const float other = __uint_as_float(upper ? sw2[0] : sw2[1]);
-                        v[t] = upper ? own * cs[t] + other * sn[t] : own * cs[t] - other * sn[t];
+                        const float r_ = upper ? own * cs[t] + other * sn[t] : own * cs[t] - other * sn[t];
+                        o[t] = rot ? r_ : v[t];
                     }
-                }
-                const uint32_t off = (m_ok && gs < g.N) ? (uint32_t)(ml * (int)g.ldc + n) * 2u : OOB;
-                __builtin_amdgcn_raw_buffer_store_b64(pack4(v), rsC, off, 0, 0);
+                    const uint32_t off = (m_ok && gs0 + en < g.N) ? (uint32_t)(ml * (int)g.ldc + n) * 2u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b64(pack4(o), rsC, off, 0, 0);
+                });
             });
-        });
+        };
+        if (g.nrm_rstd != nullptr) rope_store(std::true_type{});
+        else rope_store(std::false_type{});
     } else if constexpr (MODE == MODE_PLAIN) {
         auto plain_store = [&](auto epic) {
             constexpr int EPI = decltype(epic)::value;
@@ -1058,7 +1100,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                     constexpr int i = decltype(ic)::value;
                     const int nl = nl0 + i * 16;
                     const bool ok = row_ok && n0 + nl < g.N;
-                    f32x4 v = w4_acc<i * 8 + j>();
+                    f32x4 v = acc_of(ic, jc);
                     if constexpr (EPI != VGPT_EPI_NONE) {
                         const bf16x4 rb = __builtin_bit_cast(bf16x4, r[j][i]);
 #pragma unroll
@@ -1093,7 +1135,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                     // arrival -- in a fixed order and writes the rows' 1 / rms: the consumers read one float per row.
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    int* flag = reinterpret_cast<int*>(smem + 4 * A_BYTES);
+                    int* flag = reinterpret_cast<int*>(smem + STAGE_BYTES);
                     if (tid == 0) {
                         const int old = __hip_atomic_fetch_add(g.ssq_cnt + tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         *flag = old == g.tiles_n - 1;
@@ -1124,9 +1166,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
         else if (g.epi == VGPT_EPI_BIAS) plain_store(std::integral_constant<int, VGPT_EPI_BIAS>{});
         else plain_store(std::integral_constant<int, VGPT_EPI_NONE>{});
     } else {
-        auto gated_store = [&](auto actc, auto keepc) {
+        auto gated_store = [&](auto actc, auto keepc, auto normc) {
             constexpr int ACT = decltype(actc)::value;
             constexpr bool KEEP = decltype(keepc)::value;
+            constexpr bool NORM = decltype(normc)::value;
             const auto rsC = make_rs(g.C + (int64_t)m0 * g.ldc + n0);
             const auto rsG = make_rs(KEEP ? g.gu_out + (int64_t)m0 * g.ld_gu + n0 : g.C);
             const int ol0 = wn * (NI / 2) * 16 + en;          // this lane's first OUTPUT column inside the tile
@@ -1134,13 +1177,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                 constexpr int j = decltype(jc)::value;
                 const int ml = wm * 128 + j * 16 + em;
                 const bool row_ok = m0 + ml < g.M;
-                const float rs = g.nrm_rstd != nullptr ? rs_lds[ml] : 1.0f;
+                [[maybe_unused]] const float rs = NORM ? rs_lds[ml] : 1.0f;
                 static_for<0, NI / 2>([&](auto pc) {
                     constexpr int p = decltype(pc)::value;
                     const int nl = ol0 + p * 16;
                     const bool ok = row_ok && n0 + nl < g.I;
-                    f32x4 gate = w4_acc<(2 * p) * 8 + j>(), up = w4_acc<(2 * p + 1) * 8 + j>();
-                    if (g.nrm_rstd != nullptr) {
+                    f32x4 gate = acc_of(std::integral_constant<int, 2 * p>{}, jc), up = acc_of(std::integral_constant<int, 2 * p + 1>{}, jc);
+                    if constexpr (NORM) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) { gate[t] *= rs; up[t] *= rs; }
                     }
@@ -1166,16 +1209,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
         };
         using KT = std::true_type;
         using KF = std::false_type;
-        if (g.act == VGPT_ACT_SILU) {
-            if (g.gu_out) gated_store(std::integral_constant<int, VGPT_ACT_SILU>{}, KT{});
-            else gated_store(std::integral_constant<int, VGPT_ACT_SILU>{}, KF{});
-        } else if (g.act == VGPT_ACT_GELU) {
-            if (g.gu_out) gated_store(std::integral_constant<int, VGPT_ACT_GELU>{}, KT{});
-            else gated_store(std::integral_constant<int, VGPT_ACT_GELU>{}, KF{});
-        } else {
-            if (g.gu_out) gated_store(std::integral_constant<int, VGPT_ACT_GELU_TANH>{}, KT{});
-            else gated_store(std::integral_constant<int, VGPT_ACT_GELU_TANH>{}, KF{});
-        }
+        // one instantiation per (activation, keeps [gate | up], folded norm) in use: the inference step (SiLU, no keep) with and
+        // without the norm, the training forward (keep, no norm); other activations without the norm
+        auto by_act = [&](auto keepc, auto normc) {
+            if (g.act == VGPT_ACT_SILU) gated_store(std::integral_constant<int, VGPT_ACT_SILU>{}, keepc, normc);
+            else if (g.act == VGPT_ACT_GELU) gated_store(std::integral_constant<int, VGPT_ACT_GELU>{}, keepc, normc);
+            else gated_store(std::integral_constant<int, VGPT_ACT_GELU_TANH>{}, keepc, normc);
+        };
+        if (g.gu_out) by_act(KT{}, KF{});
+        else if (g.nrm_rstd != nullptr) by_act(KF{}, KT{});
+        else by_act(KF{}, KF{});
     }
 #ifdef VGPT_W4_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the epilogue's stores have left the CU
@@ -1289,7 +1332,7 @@ bool w4_enabled() { return g_family == 0; }
 
 template <int MODE, int NI>
 int launch_w4_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
-    constexpr int LDS = 128 * 1024 + 1024;   // staging buffers + the 256 rstd values of the folded RMSNorm
+    constexpr int LDS = (NI == 9 ? 2 * (256 + 288) * BK * 2 : 128 * 1024) + 1024;   // staging buffers + the 256 rstd values of the folded RMSNorm
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_kernel<MODE, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1320,6 +1363,10 @@ bool w4_ok(const GemmArgs& g, int64_t n_out) {
     if ((256 + 8) * g.lda * 2 + (int64_t)g.K * 2 >= (1ll << 31)) return false;
     if ((rows_w + 8) * g.ldw * 2 + (int64_t)g.K * 2 >= (1ll << 31)) return false;
     if (g.ldc >= (1 << 21) || g.ldr >= (1 << 21) || g.ld_gu >= (1 << 21)) return false;   // 256 rows x ld x 2 bytes below the descriptors' range
+    if (MODE == MODE_ROPE) {   // the epilogue stages the tile's cos / sin rows through LDS (two tables of 256 x head_dim / 2 floats)
+        const int tab_bytes = (256 * (g.head_dim >> 1) * 4 + 1023) & ~1023;
+        if (2 * tab_bytes > 3 * 256 * BK * 2 || g.rope_cols % 16 != 0) return false;
+    }
     return true;
 }
 
@@ -1344,14 +1391,27 @@ double w4_cost_rounds(const GemmArgs& g, int64_t n_out) {
     return (c192 < c256 ? c192 : c256) / ((double)(g.K / BK) + 13.5);
 }
 
+// 256 x 288 tiles (NI = 9: whole tiles only, no gated mode): a k-tile is 144 instead of 128 MFMAs per wave
+template <int MODE>
+double w4_cost288(const GemmArgs& g, int64_t n_out) {
+    if (MODE == MODE_GATED || g.M % 256 != 0 || n_out % 288 != 0) return 1e30;
+    const int64_t t288 = (g.M / 256) * (n_out / 288);
+    return (double)cdiv(t288, cu_count()) * (1.125 * (double)(g.K / BK) + 13.5);
+}
+
 template <int MODE>
 int launch_w4(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     double c256, c192;
     w4_costs<MODE>(g, n_out, c256, c192);
+    const double c288 = w4_cost288<MODE>(g, n_out);
     static int forced = -1;
     if (forced < 0) {
-        const char* e = getenv("VGPT_GEMM_W4_NI");   // probes: force the tile width (8 = 256, 6 = 192)
+        const char* e = getenv("VGPT_GEMM_W4_NI");   // probes: force the tile width (8 = 256, 6 = 192, 9 = 288 where it applies)
         forced = e ? atoi(e) : 0;
+    }
+    if constexpr (MODE != MODE_GATED) {
+        if (c288 < 1e29 && g.ssq_out == nullptr && (forced == 9 || (forced == 0 && c288 < c256 && c288 < c192)))
+            return launch_w4_cfg<MODE, 9>(g, n_out, s, name);
     }
     const bool use192 = forced == 6 || (forced != 8 && c192 < c256);
     if (use192) return launch_w4_cfg<MODE, 6>(g, n_out, s, name);
@@ -1369,18 +1429,7 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     if (!use256) return launch_cfg<MODE, Cfg128, 0, ATR, WTR>(g, n_out, s, name);
     if constexpr (!ATR && !WTR) {
         if (f == 0 && w4_enabled() && w4_ok<MODE>(g, n_out)) {
-            // one exception, measured inside the sampler step on the same box (profiles/r04_*): qkv_proj of a 4096-row step
-            // (N = 9216 = 32 x 288) is two exact rounds of the eight-wave kernel's 256 x 288 tiles, 198 us, against three rounds
-            // of 256 x 192 four-wave tiles, 214 us (a 192-wide round costs 0.89 of a 256-wide one, not 0.75: see launch_w4)
-            bool keep288 = false;
-            if constexpr (MODE == MODE_PLAIN || MODE == MODE_ROPE) {
-                if (n_out % 288 == 0) {
-                    const int64_t t288 = tiles_m * (n_out / 288), cus = cu_count();
-                    const double r288 = (double)cdiv(t288, cus) * 1.30;
-                    keep288 = t288 % cus == 0 && r288 < w4_cost_rounds<MODE>(g, n_out);
-                }
-            }
-            if (!keep288) return launch_w4<MODE>(g, n_out, s, name);
+            return launch_w4<MODE>(g, n_out, s, name);
         }
     }
     if (f == 257) return launch_cfg<MODE, Cfg256, 0, ATR, WTR>(g, n_out, s, name);
