@@ -115,19 +115,56 @@ def fullwidth_layer(seeds):
     return res
 
 
+def fullwidth_stage1():
+    """The cfg-3 stage-1 batch of tests/test_fullwidth_parity_gpu.py::test_cfg3_stage1_step_full_width (2 x 3870 tokens, one
+    full-width decoder layer): per-frame loss and the gradients of the parameters that test compares, stock bf16 ops against
+    fp32 (several minutes on 8 host cores: bf16 matmuls of K = 3072 / 8192 over 7740 rows, forward and backward)."""
+    cfg = R.Phi3Cfg(hidden_size=3072, intermediate_size=8192, num_hidden_layers=1, num_attention_heads=32,
+                    num_key_value_heads=32, vocab_size=64, pos_embed_max_size=24)
+    p = {k: v.to(BF).float() for k, v in R.make_params(cfg, seed=11).items()}
+    batch = R.collate_stage1([8, 8], 256)
+    gen = torch.Generator("cpu").manual_seed(3)
+    nd, nc = 16, 14
+    mk = lambda n: torch.randn(n, 4, 32, 32, generator=gen)
+    x1, x0, clean, x0i = mk(nd), mk(nd), mk(nc), mk(nc)
+    t = torch.rand(nd, generator=gen)
+    ti = 0.9 + 0.1 * torch.rand(nc, generator=gen)
+    names = ["llm.layers.0.self_attn.qkv_proj.weight", "llm.layers.0.self_attn.o_proj.weight",
+             "llm.layers.0.mlp.gate_up_proj.weight", "llm.layers.0.mlp.down_proj.weight",
+             "llm.layers.0.input_layernorm.weight", "llm.layers.0.post_attention_layernorm.weight", "llm.norm.weight",
+             "final_layer.linear.weight", "x_embedder.proj.weight", "input_x_embedder.proj.weight",
+             "time_token.mlp.2.weight", "final_layer.adaLN_modulation.1.weight"]
+    runs = {}
+    for name, dt in (("f32", torch.float32), ("bf16", BF)):
+        pr = {k: v.to(dt).clone().requires_grad_(k in names) for k, v in p.items()}
+        c = lambda a: list(a.to(dt).split(1))
+        loss, _ = R.stage1_loss(pr, cfg, c(x1), c(x0), t, c(clean), c(x0i), ti, batch)
+        loss.float().mean().backward()
+        runs[name] = (loss.detach().float(), {k: pr[k].grad.detach().float() for k in names})
+        print(f"fullwidth stage-1: {name} run done", flush=True)
+    g32, g16 = runs["f32"][1], runs["bf16"][1]
+    per = {k: rel(g16[k], g32[k]) for k in names}
+    print("fullwidth stage-1 per-parameter:", {k: round(v, 5) for k, v in per.items()}, flush=True)
+    return {"fullwidth_stage1_loss": [rel(runs["bf16"][0], runs["f32"][0])], "fullwidth_stage1_param_grads": [max(per.values())]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fullwidth", action="store_true")
+    ap.add_argument("--fullwidth-stage1", action="store_true", help="only the cfg-3 full-width stage-1 quantities (slow)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "tolerance_calibration.json"))
     args = ap.parse_args()
     torch.manual_seed(0)
     cfg = R.TINY
     seeds = (0, 1, 2)
     meas = {}
-    with torch.no_grad():
-        meas.update(forward_and_sampler(cfg, seeds, ((8, 8), (16, 16))))
-        meas.update(single_forward(cfg, seeds))
-    meas.update(loss_and_grads(cfg, (3, 4, 5)))
+    if args.fullwidth_stage1:
+        meas.update(fullwidth_stage1())
+    else:
+        with torch.no_grad():
+            meas.update(forward_and_sampler(cfg, seeds, ((8, 8), (16, 16))))
+            meas.update(single_forward(cfg, seeds))
+        meas.update(loss_and_grads(cfg, (3, 4, 5)))
     path = args.out
     prev = json.load(open(path)) if os.path.exists(path) else {"quantities": {}}
     if args.fullwidth:

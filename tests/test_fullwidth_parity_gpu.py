@@ -11,7 +11,8 @@ per layer at this width on the host cores).  A wrong stride at 32 x 96 or at K =
          evaluated on bands of query rows (block seams, first / last rows) -- the dense problem does not fit a CPU test.
 
 Tolerances (bf16 HIP vs fp32 CPU oracle, identical bf16-representable weights): rel-L2 <= 2e-2 for one layer's hidden
-states and for one-step latents, <= 2e-2 loss, <= 6e-2 gradients, <= 1e-2 / 2e-2 attention forward / backward vs fp64."""
+states and for one-step latents; stage-1 loss and gradients: 2 x the measured error of stock bf16 ops on the same batch
+(tests/golden/tolerance_calibration.json: 3.9e-3 / 1.1e-2); <= 1e-2 / 2e-2 attention forward / backward vs fp64."""
 import importlib
 import math
 
@@ -144,8 +145,15 @@ def test_cfg3_stage1_step_full_width(full_params, gemm_family):
     dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
     loss = tr.step(dbatch, x1, x0, t, clean, x0i, ti, update=False)
     assert SC.rel_l2(tr.last["xt"], torch.cat(xt_ref)) < 4e-3
-    assert SC.rel_l2(loss, loss_ref.detach()) < 2e-2
-    bad = {n: SC.rel_l2(tr.grads[n], pr[n].grad) for n in names if not SC.rel_l2(tr.grads[n], pr[n].grad) < 6e-2}
+    # tolerances measured, not guessed: 2 x the error of torch's stock bf16 ops on this very batch against the fp32 oracle
+    # (scripts/calibrate_tolerances.py --fullwidth-stage1 -> tests/golden/tolerance_calibration.json: loss 1.9e-3, worst
+    # parameter gradient 5.6e-3)
+    e_loss = SC.rel_l2(loss, loss_ref.detach())
+    errs = {n: SC.rel_l2(tr.grads[n], pr[n].grad) for n in names}
+    print(f"cfg-3 full width: loss rel-L2 {e_loss:.3e} (tolerance {SC.tol('fullwidth_stage1_loss'):.3e}); worst gradient "
+          f"{max(errs.values()):.3e} at {max(errs, key=errs.get)} (tolerance {SC.tol('fullwidth_stage1_param_grads'):.3e})")
+    assert e_loss < SC.tol("fullwidth_stage1_loss")
+    bad = {n: e for n, e in errs.items() if not e < SC.tol("fullwidth_stage1_param_grads")}
     assert not bad, bad
 
 
