@@ -846,8 +846,12 @@ __device__ __forceinline__ f32x4 w4_acc() {
     return f32x4{x0, x1, x2, x3};
 }
 
-template <int MODE, int NI>
+template <int MODE, int NI, bool WTR = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
+    // WTR: W is stored with the reduction index as its ROW index ([K][N]: dX = dY W of the backward): staged as a
+    // [64 reduction rows][256 columns] image (512-byte rows, 32-byte units XOR-swizzled as in gemm_bf16_kernel), fragments by
+    // ds_read_b64_tr_b16; a 192-wide tile (NI 6) uses the same image and ignores its last 64 columns
+    static_assert(!WTR || (MODE == MODE_PLAIN && NI <= 8), "transposed W: plain kernel, 256- / 192-wide tiles");
     constexpr bool ROPE = MODE == MODE_ROPE;
     constexpr int BM = 256, BN = NI * 32, MI = 8;
     constexpr int A_BYTES = BM * BK * 2;
@@ -896,8 +900,18 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
         const int r = min((wave * 8 + p) * 8 + srow, g.M - 1 - m0);
         oa[p] = (uint32_t)(r * (int)g.lda + schunk * 8) * 2u;
     }
+    if constexpr (WTR) {
 #pragma unroll
-    for (int p = 0; p < (NI == 9 ? 0 : 8); ++p) {
+        for (int p = 0; p < 8; ++p) {      // piece = two 512-byte rows of the image: lane -> (row, 16-byte chunk)
+            const int row = (wave * 8 + p) * 2 + (lane >> 5), t_c = lane & 31;
+            const int key = (((row >> 3) & 1) << 2) | (row & 3);
+            const int lchunk = ((((t_c >> 1) ^ key) << 1) | (t_c & 1));
+            const int col = min(n0 + lchunk * 8, g.N - 8) - n0;
+            ow[p] = (uint32_t)(row * (int)g.ldw + col) * 2u;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < (NI == 9 || WTR ? 0 : 8); ++p) {
         const int sl = (wave * NI + min(p, NI - 1)) * 8 + srow;   // n-slot inside the tile
         int wr;
         if constexpr (ROPE) wr = min(rope_col_of_slot(n0 + sl, g.rope_cols, g.head_dim), n_rows_w - 1);
@@ -905,7 +919,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
         ow[p] = (uint32_t)(wr * (int)g.ldw + schunk * 8) * 2u;
     }
     const bf16* a_org = g.A + (int64_t)m0 * g.lda;
-    const bf16* w_org = (MODE == MODE_GATED || ROPE) ? g.W : g.W + (int64_t)n0 * g.ldw;
+    const bf16* w_org = WTR ? g.W + n0 : ((MODE == MODE_GATED || ROPE) ? g.W : g.W + (int64_t)n0 * g.ldw);
     auto srd = [](const void* base) {
         const uint64_t b = (uint64_t)(uintptr_t)base;
         v4i32 r;
@@ -922,7 +936,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     uint32_t rdA = (uint32_t)((wm * 128 + frow) * 128 + ((fk ^ sw) * 16));
     uint32_t rdW = (uint32_t)(W_BASE + (wn * NI * 16 + frow) * 128 + ((fk ^ sw) * 16));
     uint32_t wrA = (uint32_t)(wave * 8192 + lane * 16);
-    uint32_t wrW = (uint32_t)(W_BASE + wave * NI * 1024 + lane * 16);
+    uint32_t wrW = (uint32_t)(W_BASE + wave * (WTR ? 8 : NI) * 1024 + lane * 16);
     const int nk = __builtin_amdgcn_readfirstlane(g.K / BK);
 
     // folded RMSNorm, consumer side: 1 / rms of this tile's 256 rows into LDS behind the staging buffers (thread t: row t);
@@ -935,7 +949,44 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
 #ifdef VGPT_W4_STAMPS
     const uint32_t st_t1 = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
-    if constexpr (NI == 9) {
+    if constexpr (WTR) {
+        // fragment addresses of the transposed image: lane (g4 = lane >> 4, li = lane & 15) of sub-tile `unit` reads rows
+        // 32 ks + 8 g4 + (li >> 2) (+ 4) at columns 4 (li & 3) .. + 4 of the unit's (swizzled) 32-byte column group
+        const int tr_li = lane & 15, tr_g = lane >> 4;
+        const int tr_key = ((tr_g & 1) << 2) | (tr_li >> 2);
+        uint32_t rw0[8], rw1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int unit = wn * NI + min(i, NI - 1);
+            rw0[i] = rw1[i] = (uint32_t)(W_BASE + (8 * tr_g + (tr_li >> 2)) * 512 + 8 * (tr_li & 3) + ((unit ^ tr_key) << 5));
+        }
+        uint32_t rdA1 = rdA ^ 64u;
+        const int wstep = __builtin_amdgcn_readfirstlane((int)(64 * g.ldw * 2));
+        if constexpr (NI == 8) {
+            asm volatile(VGPT_W4_ASM_NI8_WTR
+                         : VGPT_W4_OUTS_ [rdA0] "+v"(rdA), [rdA1] "+v"(rdA1), [wrA] "+v"(wrA), [wrW] "+v"(wrW),
+                           [rw0_0] "+v"(rw0[0]), [rw0_1] "+v"(rw0[1]), [rw0_2] "+v"(rw0[2]), [rw0_3] "+v"(rw0[3]), [rw0_4] "+v"(rw0[4]),
+                           [rw0_5] "+v"(rw0[5]), [rw0_6] "+v"(rw0[6]), [rw0_7] "+v"(rw0[7]), [rw1_0] "+v"(rw1[0]), [rw1_1] "+v"(rw1[1]),
+                           [rw1_2] "+v"(rw1[2]), [rw1_3] "+v"(rw1[3]), [rw1_4] "+v"(rw1[4]), [rw1_5] "+v"(rw1[5]), [rw1_6] "+v"(rw1[6]),
+                           [rw1_7] "+v"(rw1[7])
+                         : [srdA] "s"(srdA), [srdW] "s"(srdW), [nk] "s"(nk), [wv] "s"(wave), [wstep] "s"(wstep),
+                           [oa0] "v"(oa[0]), [oa1] "v"(oa[1]), [oa2] "v"(oa[2]), [oa3] "v"(oa[3]), [oa4] "v"(oa[4]), [oa5] "v"(oa[5]),
+                           [oa6] "v"(oa[6]), [oa7] "v"(oa[7]), [ow0] "v"(ow[0]), [ow1] "v"(ow[1]), [ow2] "v"(ow[2]), [ow3] "v"(ow[3]),
+                           [ow4] "v"(ow[4]), [ow5] "v"(ow[5]), [ow6] "v"(ow[6]), [ow7] "v"(ow[7])
+                         : VGPT_W4_CLOBBERS_WTR);
+        } else {
+            asm volatile(VGPT_W4_ASM_NI6_WTR
+                         : VGPT_W4_OUTS_ [rdA0] "+v"(rdA), [rdA1] "+v"(rdA1), [wrA] "+v"(wrA), [wrW] "+v"(wrW),
+                           [rw0_0] "+v"(rw0[0]), [rw0_1] "+v"(rw0[1]), [rw0_2] "+v"(rw0[2]), [rw0_3] "+v"(rw0[3]), [rw0_4] "+v"(rw0[4]),
+                           [rw0_5] "+v"(rw0[5]), [rw1_0] "+v"(rw1[0]), [rw1_1] "+v"(rw1[1]), [rw1_2] "+v"(rw1[2]), [rw1_3] "+v"(rw1[3]),
+                           [rw1_4] "+v"(rw1[4]), [rw1_5] "+v"(rw1[5])
+                         : [srdA] "s"(srdA), [srdW] "s"(srdW), [nk] "s"(nk), [wv] "s"(wave), [wstep] "s"(wstep),
+                           [oa0] "v"(oa[0]), [oa1] "v"(oa[1]), [oa2] "v"(oa[2]), [oa3] "v"(oa[3]), [oa4] "v"(oa[4]), [oa5] "v"(oa[5]),
+                           [oa6] "v"(oa[6]), [oa7] "v"(oa[7]), [ow0] "v"(ow[0]), [ow1] "v"(ow[1]), [ow2] "v"(ow[2]), [ow3] "v"(ow[3]),
+                           [ow4] "v"(ow[4]), [ow5] "v"(ow[5]), [ow6] "v"(ow[6]), [ow7] "v"(ow[7])
+                         : VGPT_W4_CLOBBERS_WTR);
+        }
+    } else if constexpr (NI == 9) {
         // whole tiles only (launch_w4 checks): no per-lane row clamp, one SGPR offset per piece (lane p of `tab`: p < 8 the A
         // pieces, 8 + p the W pieces) on top of one per-lane offset per operand
         uint32_t tab;
@@ -1330,12 +1381,12 @@ BigPlan plan_big(int64_t M, int64_t n_out, int bn_out, int64_t nk) {
 int g_family = 0;
 bool w4_enabled() { return g_family == 0; }
 
-template <int MODE, int NI>
+template <int MODE, int NI, bool WTR = false>
 int launch_w4_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     constexpr int LDS = (NI == 9 ? 2 * (256 + 288) * BK * 2 : 128 * 1024) + 1024;   // staging buffers + the 256 rstd values of the folded RMSNorm
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_kernel<MODE, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_kernel<MODE, NI, WTR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             vgpt_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return VGPT_ERR_HIP;
@@ -1348,7 +1399,7 @@ int launch_w4_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
 #endif
     g.tiles_m = (int)cdiv(g.M, 256);
     g.tiles_n = (int)cdiv(n_out, MODE == MODE_GATED ? BN / 2 : BN);
-    hipLaunchKernelGGL((gemm_w4_kernel<MODE, NI>), dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, s, g);
+    hipLaunchKernelGGL((gemm_w4_kernel<MODE, NI, WTR>), dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, s, g);
     VGPT_CHECK_LAUNCH(name);
     return VGPT_OK;
 }
@@ -1430,6 +1481,18 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
     if constexpr (!ATR && !WTR) {
         if (f == 0 && w4_enabled() && w4_ok<MODE>(g, n_out)) {
             return launch_w4<MODE>(g, n_out, s, name);
+        }
+    }
+    if constexpr (!ATR && WTR && MODE == MODE_PLAIN) {
+        // dX = dY W of the backward on the four-wave kernel (fragments of W by ds_read_b64_tr_b16): one launch for all rows --
+        // the eight-wave plan splits a 7740-row product at a round boundary and re-streams W for the remainder
+        if (f == 0 && w4_enabled() && g.K % BK == 0 && g.K >= 2 * BK && g.M >= 8 && n_out >= 8 &&
+            (256 + 8) * g.lda * 2 + (int64_t)g.K * 2 < (1ll << 31) && ((int64_t)g.K + 64) * g.ldw * 2 < (1ll << 31) &&
+            g.ldc < (1 << 21) && g.ldr < (1 << 21)) {
+            double c256, c192;
+            w4_costs<MODE>(g, n_out, c256, c192);
+            if (c192 < c256) return launch_w4_cfg<MODE, 6, true>(g, n_out, s, name);
+            return launch_w4_cfg<MODE, 8, true>(g, n_out, s, name);
         }
     }
     if (f == 257) return launch_cfg<MODE, Cfg256, 0, ATR, WTR>(g, n_out, s, name);

@@ -31,6 +31,7 @@ V_LAST = 255
 S_KLOAD, S_KLAST, S_CNT = 56, 57, 58
 S_FIRST, S_LAST = 36, 71
 S_PIECE, S_TMP, S_DELTA = 36, 59, 53   # NI = 9: s36..s52 piece offsets, s53..s55 buffer deltas
+S_KLOADW, S_KLASTW = 70, 71            # transposed W: its own k offset (64 rows per k-tile)
 # diagnostics (python gemm_w4_gen.py --debug N; results are garbage unless N == 16): 1 = no global fetches in the loop,
 # 2 = no LDS writes, 4 = no fragment reads, 8 = no barrier, 16 = s_memtime / s_memrealtime stamps around the loop and around
 # every barrier (outputs %[cyc], %[rt], %[bar]: loop cycles, loop time in 10-ns ticks, cycles spent at the barriers)
@@ -50,11 +51,24 @@ def vr(base, n=4):
 
 
 class Gen:
-    def __init__(self, NI):
+    def __init__(self, NI, wtr=False):
         self.NI = NI
-        self.PA, self.PW = 8, NI          # pieces per wave and k-tile
+        self.wtr = wtr                    # W stored [K][N] (dX = dY W): fragments by ds_read_b64_tr_b16
+        self.PA, self.PW = 8, (8 if wtr else NI)   # pieces per wave and k-tile (a transposed W tile is a 256-column image)
         self.P = self.PA + self.PW
-        if NI <= 8:
+        if wtr:
+            # transposed W: 64 reduction rows x 256 columns (512-byte rows, 32-byte units XOR-swizzled as in the eight-wave
+            # kernel), a fragment = two ds_read_b64_tr_b16 at a per-lane address that is lane-dependent in the sub-tile index,
+            # so one address VGPR per (fragment set, sub-tile) -- 2 NI of them -- and no room for register copies: every
+            # address / offset is an asm operand used in place
+            assert NI <= 8
+            self.R = 64
+            self.A = (128, 160)
+            self.W = (192, 224)
+            self.RDA, self.RDW = ("%[rdA0]", "%[rdA1]"), (None, None)
+            self.WRA, self.WRW = "%[wrA]", "%[wrW]"
+            self.sgpr_pieces = False
+        elif NI <= 8:
             # physical registers; the operands are copied in by the prologue
             self.R, self.A, self.W = V_R, V_A, V_W
             self.RDA, self.RDW = tuple(f"v{x}" for x in V_RDA), tuple(f"v{x}" for x in V_RDW)
@@ -123,6 +137,12 @@ class Gen:
             self.emit(f"s_add_u32 s{S_TMP}, s{S_PIECE + p}, s{S_KLOAD}")
             self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, {vo}, {srd}, s{S_TMP} offen")
             return
+        if self.wtr:
+            if p < self.PA:
+                self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, %[oa{p}], %[srdA], s{S_KLOAD} offen")
+            else:
+                self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, %[ow{p - self.PA}], %[srdW], s{S_KLOADW} offen")
+            return
         srd, vo = ("%[srdA]", V_OA + p) if p < self.PA else ("%[srdW]", V_OW + p - self.PA)
         self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, v{vo}, {srd}, s{S_KLOAD} offen")
 
@@ -161,6 +181,14 @@ class Gen:
     def read_W(self, s, i, in_loop=True):
         if in_loop and (DEBUG & 4):
             self.issue(("W", s, i)); self.done = len(self.lgkm); return
+        if self.wtr:
+            # set s = k-step s of the tile: rows 32 s .. of the [64][256] image (512-byte rows); the upper half 4 rows on
+            w = self.W[s] + 4 * i
+            self.emit(f"ds_read_b64_tr_b16 {vr(w, 2)}, %[rw{s}_{i}] offset:{s * 32 * 512}")
+            self.issue(("Wlo", s, i))
+            self.emit(f"ds_read_b64_tr_b16 {vr(w + 2, 2)}, %[rw{s}_{i}] offset:{s * 32 * 512 + 4 * 512}")
+            self.issue(("W", s, i))
+            return
         self.emit(f"ds_read_b128 {vr(self.W[s] + 4 * i)}, {self.RDW[s]} offset:{i * 2048}")
         self.issue(("W", s, i))
 
@@ -218,7 +246,10 @@ class Gen:
             if i == NI - 1:
                 # address toggles (VALU, no memory operation): the read addresses of the set just requested from
                 def tog():
-                    self.toggle((self.RDA[o], self.RDW[o]), o)
+                    if self.wtr:
+                        self.toggle((self.RDA[o],) + tuple(f"%[rw{o}_{i_}]" for i_ in range(NI)), o)
+                    else:
+                        self.toggle((self.RDA[o], self.RDW[o]), o)
                 side.append((1, tog))
             for j in range(8):
                 self.mfma(s, i, j, it)
@@ -226,6 +257,14 @@ class Gen:
                     if slot == j:
                         fn()
         assert ri == len(reads) and pi == len(pieces)
+
+    def advance_k(self):
+        """The fetches issued from here on belong to the next k-tile (clamped to the last one)."""
+        self.emit(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
+        self.emit(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
+        if self.wtr:      # a transposed W advances by 64 ROWS per k-tile
+            self.emit(f"s_add_u32 s{S_KLOADW}, s{S_KLOADW}, %[wstep]")
+            self.emit(f"s_min_u32 s{S_KLOADW}, s{S_KLOADW}, s{S_KLASTW}")
 
     def body(self, it):
         P, PA, PW = self.P, self.PA, self.PW
@@ -250,8 +289,7 @@ class Gen:
             self.emit("s_sub_u32 s62, s62, s60")
             self.emit("s_add_u32 s64, s64, s62")
         self.toggle((self.WRA, self.WRW), 2)
-        self.emit(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
-        self.emit(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
+        self.advance_k()
         self.emit(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
         # k-step 1: set 1; reads set 0 of tile t + 1; writes the first half of tile t + 2, refetches it for tile t + 3
         self.kstep(1, first, it)
@@ -261,7 +299,9 @@ class Gen:
         e = self.emit
         lab = f"%="
         # ---- prologue ----
-        if not self.sgpr_pieces:
+        if self.wtr:
+            pass                                           # every address / offset is an operand used in place
+        elif not self.sgpr_pieces:
             e(f"v_mov_b32 v{V_RDA[0]}, %[rdA]")
             e(f"v_xor_b32 v{V_RDA[1]}, 64, %[rdA]")
             e(f"v_mov_b32 v{V_RDW[0]}, %[rdW]")
@@ -280,6 +320,9 @@ class Gen:
             e("s_nop 4")
         e(f"s_mov_b32 s{S_KLOAD}, 0")
         e(f"s_sub_u32 s{S_KLAST}, %[nk], 1")
+        if self.wtr:
+            e(f"s_mov_b32 s{S_KLOADW}, 0")
+            e(f"s_mul_i32 s{S_KLASTW}, s{S_KLAST}, %[wstep]")
         e(f"s_lshl_b32 s{S_KLAST}, s{S_KLAST}, 7")
         e(f"s_mov_b32 s{S_CNT}, %[nk]")
         first, second = self.first, self.second
@@ -294,13 +337,11 @@ class Gen:
         e("s_waitcnt vmcnt(0)")
         for p in order:
             self.write_piece(p, False)
-        e(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
-        e(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
+        self.advance_k()
         for p in order:                                    # tile 1 (fetch order = the loop's consumption order)
             self.load_piece(p, False)
         self.toggle((self.WRA, self.WRW), 2)
-        e(f"s_add_u32 s{S_KLOAD}, s{S_KLOAD}, 128")
-        e(f"s_min_u32 s{S_KLOAD}, s{S_KLOAD}, s{S_KLAST}")
+        self.advance_k()
         for p in first:                                    # "k-step 1 of tile -1": first half of tile 1 -> buffer 1, refetch for tile 2
             e(f"s_waitcnt vmcnt({P - 1})")
             self.write_piece(p, False)
@@ -314,7 +355,10 @@ class Gen:
             self.read_W(0, i, False)
             self.read_W(1, i, False)
         # the read addresses of set 0 now point at the buffer of tile 1 (they are toggled at the end of every k-step 1 ... see kstep)
-        self.toggle((self.RDA[0], self.RDW[0]), 0)
+        if self.wtr:
+            self.toggle((self.RDA[0],) + tuple(f"%[rw0_{i_}]" for i_ in range(NI)), 0)
+        else:
+            self.toggle((self.RDA[0], self.RDW[0]), 0)
         self.drain()
         if DEBUG & 16:
             e("s_mov_b32 s64, 0")
@@ -372,15 +416,15 @@ def main():
            "// GENERATED by gen/gemm_w4_gen.py -- do not edit; `make gemm_w4_loop.inc` regenerates it.",
            "// The hand-scheduled main loop of gemm_w4_kernel (gemm_bf16.hip): see the generator for the schedule.",
            ""]
-    for NI in (8, 6, 9):
-        g = Gen(NI)
+    for NI, wtr in ((8, False), (6, False), (9, False), (8, True), (6, True)):
+        g = Gen(NI, wtr)
         lines = g.generate()
         n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
-        out.append(f"// NI = {NI}: {len(lines)} lines, {n_mfma} MFMAs in the text (loop body {NI * 16})")
-        out.append(f"#define VGPT_W4_ASM_NI{NI} \\")
+        out.append(f"// NI = {NI}{', W transposed' if wtr else ''}: {len(lines)} lines, {n_mfma} MFMAs in the text (loop body {NI * 16})")
+        out.append(f"#define VGPT_W4_ASM_NI{NI}{'_WTR' if wtr else ''} \\")
         out.append(" \\\n".join('    "' + l + '\\n\\t"' for l in lines))
         out.append("")
-    for name, v0 in (("VGPT_W4_CLOBBERS", V_R), ("VGPT_W4_CLOBBERS_NI9", 20)):
+    for name, v0 in (("VGPT_W4_CLOBBERS", V_R), ("VGPT_W4_CLOBBERS_NI9", 20), ("VGPT_W4_CLOBBERS_WTR", 64)):
         cl = [f'"v{i}"' for i in range(v0, V_LAST + 1)] + [f'"a{i}"' for i in range(256)] + \
              [f'"s{i}"' for i in range(S_FIRST, S_LAST + 1)] + ['"scc"', '"memory"']
         out.append(f"#define {name} \\")
