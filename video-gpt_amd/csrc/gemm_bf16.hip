@@ -1119,26 +1119,43 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
         if (g.nrm_rstd != nullptr) rope_store(std::true_type{});
         else rope_store(std::false_type{});
     } else if constexpr (MODE == MODE_PLAIN) {
-        auto plain_store = [&](auto epic) {
+        auto plain_store = [&](auto epic, auto widec) {
             constexpr int EPI = decltype(epic)::value;
+            // WIDE (N % 8 == 0): 16-byte residual loads and output stores.  v_permlane16_swap on the fp32 accumulators of TWO
+            // sub-tiles trades the first one's odd lane rows for the second one's even ones (see the gated epilogue): a lane
+            // then holds 8 consecutive columns of one sub-tile row -- half the load and store instructions of the epilogue's
+            // burst, whole 16-byte segments.  An odd last sub-tile (NI = 9) and ragged widths keep the 8-byte form.
+            constexpr bool WIDE = decltype(widec)::value;
+            constexpr int NP = WIDE ? NI / 2 : 0;
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
             const auto rsC = make_rs(g.C + (int64_t)m0 * g.ldc + n0);
             const bf16* rbase = EPI == VGPT_EPI_RESID ? g.extra + (int64_t)m0 * g.ldr + n0 : (EPI == VGPT_EPI_BIAS ? g.extra + n0 : g.C);
             const auto rsR = make_rs(rbase);
-            // every residual quad of the wave tile is requested up front (MI * NI * 2 registers: the loop's registers are
+            const int grp = lane >> 4;
+            auto wide_col = [&](int q) { return wn * (NI * 16) + (2 * q + (grp & 1)) * 16 + 4 * (grp & 2); };
+            // every residual value of the wave tile is requested up front (MI * NI * 2 registers: the loop's registers are
             // dead by now): with the quads of one row in flight at a time the epilogue was bound by the round trip of a
             // load -- 13.4 us for the 96 KiB of a 256 x 192 tile (in-kernel stamps, profiles/r04_w4_stamps_v2.log)
-            u32x2_t r[MI][NI];
+            u32x4_t rw[MI][NP > 0 ? NP : 1];
+            u32x2_t r[MI][NI - 2 * NP > 0 ? NI - 2 * NP : 1];
             if constexpr (EPI != VGPT_EPI_NONE) {
                 static_for<0, MI>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     const int ml = wm * 128 + j * 16 + em;
                     const bool row_ok = m0 + ml < g.M;
-                    static_for<0, NI>([&](auto ic) {
+                    static_for<0, NP>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        const int nl = wide_col(q);
+                        const bool ok = row_ok && n0 + nl < g.N;
+                        const uint32_t off = EPI == VGPT_EPI_RESID ? (uint32_t)(ml * (int)g.ldr + nl) * 2u : (uint32_t)nl * 2u;
+                        rw[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rsR, ok ? off : OOB, 0, 0);
+                    });
+                    static_for<2 * NP, NI>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
                         const int nl = nl0 + i * 16;
                         const bool ok = row_ok && n0 + nl < g.N;
                         const uint32_t off = EPI == VGPT_EPI_RESID ? (uint32_t)(ml * (int)g.ldr + nl) * 2u : (uint32_t)nl * 2u;
-                        r[j][i] = __builtin_amdgcn_raw_buffer_load_b64(rsR, ok ? off : OOB, 0, 0);
+                        r[j][i - 2 * NP] = __builtin_amdgcn_raw_buffer_load_b64(rsR, ok ? off : OOB, 0, 0);
                     });
                 });
             }
@@ -1147,13 +1164,42 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                 const int ml = wm * 128 + j * 16 + em;
                 const bool row_ok = m0 + ml < g.M;
                 float ssq = 0.f;
-                static_for<0, NI>([&](auto ic) {
+                static_for<0, NP>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    const f32x4 v0 = acc_of(std::integral_constant<int, 2 * q>{}, jc), v1 = acc_of(std::integral_constant<int, 2 * q + 1>{}, jc);
+                    float w8[8];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const auto sw_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0[t]), __float_as_uint(v1[t]), false, false);
+                        w8[t] = __uint_as_float(sw_[0]);
+                        w8[4 + t] = __uint_as_float(sw_[1]);
+                    }
+                    const int nl = wide_col(q);
+                    const bool ok = row_ok && n0 + nl < g.N;
+                    if constexpr (EPI != VGPT_EPI_NONE) {
+                        const bf16x8 rb = __builtin_bit_cast(bf16x8, rw[j][q]);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) w8[t] += bf2f(rb[t]);
+                    }
+                    bf16x8 o8;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) o8[t] = f2bf(w8[t]);
+                    if constexpr (EPI == VGPT_EPI_RESID) {
+                        float qs = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) qs += bf2f(o8[t]) * bf2f(o8[t]);
+                        ssq += (n0 + nl < g.N) ? qs : 0.f;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o8), rsC,
+                                                           ok ? (uint32_t)(ml * (int)g.ldc + nl) * 2u : OOB, 0, 0);
+                });
+                static_for<2 * NP, NI>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     const int nl = nl0 + i * 16;
                     const bool ok = row_ok && n0 + nl < g.N;
                     f32x4 v = acc_of(ic, jc);
                     if constexpr (EPI != VGPT_EPI_NONE) {
-                        const bf16x4 rb = __builtin_bit_cast(bf16x4, r[j][i]);
+                        const bf16x4 rb = __builtin_bit_cast(bf16x4, r[j][i - 2 * NP]);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) v[t] += bf2f(rb[t]);
                     }
@@ -1213,9 +1259,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                 }
             }
         };
-        if (g.epi == VGPT_EPI_RESID) plain_store(std::integral_constant<int, VGPT_EPI_RESID>{});
-        else if (g.epi == VGPT_EPI_BIAS) plain_store(std::integral_constant<int, VGPT_EPI_BIAS>{});
-        else plain_store(std::integral_constant<int, VGPT_EPI_NONE>{});
+        const bool wide = (g.N & 7) == 0;
+        auto by_width = [&](auto epic) {
+            if (wide) plain_store(epic, std::true_type{});
+            else plain_store(epic, std::false_type{});
+        };
+        if (g.epi == VGPT_EPI_RESID) by_width(std::integral_constant<int, VGPT_EPI_RESID>{});
+        else if (g.epi == VGPT_EPI_BIAS) by_width(std::integral_constant<int, VGPT_EPI_BIAS>{});
+        else by_width(std::integral_constant<int, VGPT_EPI_NONE>{});
     } else {
         auto gated_store = [&](auto actc, auto keepc, auto normc) {
             constexpr int ACT = decltype(actc)::value;
@@ -1229,7 +1280,36 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                 const int ml = wm * 128 + j * 16 + em;
                 const bool row_ok = m0 + ml < g.M;
                 [[maybe_unused]] const float rs = NORM ? rs_lds[ml] : 1.0f;
-                static_for<0, NI / 2>([&](auto pc) {
+                // Inference form: 16-byte stores.  A lane holds 4 consecutive columns of a sub-tile (8 bytes of bf16); lane
+                // groups g = lane >> 4 hold columns 4 g.  v_permlane16_swap on the packed outputs X, Y of TWO sub-tiles trades
+                // X's odd lane rows for Y's even ones: an even group then holds columns 4 g .. 4 g + 7 of the first sub-tile,
+                // an odd group 4 (g - 1) .. 4 g + 3 of the second -- half the store instructions, whole 16-byte segments
+                // (the epilogue's burst of stores is issue-bound: MI355X_MICROARCH.md, T21).
+                constexpr int NPAIR = KEEP ? 0 : (NI / 2) / 2;
+                static_for<0, NPAIR>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    u32x2_t ob[2];
+                    static_for<0, 2>([&](auto hc) {
+                        constexpr int p = 2 * q + decltype(hc)::value;
+                        f32x4 gate = acc_of(std::integral_constant<int, 2 * p>{}, jc), up = acc_of(std::integral_constant<int, 2 * p + 1>{}, jc);
+                        f32x4 o;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if constexpr (NORM) { gate[t] *= rs; up[t] *= rs; }
+                            o[t] = act_apply(gate[t], ACT) * up[t];
+                        }
+                        ob[decltype(hc)::value] = pack4(o);
+                    });
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(ob[0][0], ob[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(ob[0][1], ob[1][1], false, false);
+                    const int grp = lane >> 4;
+                    const int nl = wn * (NI / 2) * 16 + (2 * q + (grp & 1)) * 16 + 4 * (grp & 2);
+                    const bool ok = row_ok && n0 + nl < g.I;        // I % 16 == 0: the 8 columns are in or out together
+                    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                    const u32x4_t data = {s0[0], s1[0], s0[1], s1[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(data, rsC, ok ? (uint32_t)(ml * (int)g.ldc + nl) * 2u : OOB, 0, 0);
+                });
+                static_for<2 * NPAIR, NI / 2>([&](auto pc) {
                     constexpr int p = decltype(pc)::value;
                     const int nl = ol0 + p * 16;
                     const bool ok = row_ok && n0 + nl < g.I;
