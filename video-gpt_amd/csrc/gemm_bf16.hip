@@ -1077,6 +1077,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
         // rotated region column n = (u / per) hd + (u % per) 8 + (en & 7) + (en & 8 ? hd / 2 : 0), the partner sits in lane ^ 32
         // (en & 8 <=> upper half-wave), and both read cos / sin at d = (u % per) 8 + (en & 7) -- a valid table index for the
         // plain (V) columns too, whose rotation is computed and discarded.
+        // (16-byte stores through v_permlane16_swap of sub-tile pairs, as the gated and plain epilogues have, were measured here
+        // and lost: the per-lane head / slot arithmetic and 37-57 spilled SGPRs cost more than the halved store count returned --
+        // w4 / eight-wave 0.986 against 0.965 with the 8-byte stores, profiles/r04_w4_check_v7_rope_wide_stores.log)
         const auto rsC = make_rs(g.C + (int64_t)m0 * g.ldc);
         const bool upper = (lane & 32) != 0;
         const int per = g.head_dim >> 4;
