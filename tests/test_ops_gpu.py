@@ -7,7 +7,9 @@ Tolerances (bf16 kernels vs the fp32 oracle evaluated on the SAME bf16-rounded i
   bf16 as the reference's bf16 path also does (attention probabilities, RoPE tables).
 Integer / bit work (mask packing, tile summary, gathers) is compared bit-exactly.
 """
+import importlib
 import math
+import os
 
 import numpy as np
 import pytest
@@ -513,6 +515,70 @@ def test_attention_planned_kernel(ops, B, L, nh, nkv, segs, hd):
         ops.attention_qkv_range(dq, pm, nh, nkv, hd, 0, out8, segments=segs, item_rows=256)
         assert torch.equal(out8, out)
         assert (pm.plan(segs, 256).item_rows == 256) and pm.plan(segs, 256).n_items < pm.plan(segs).n_items
+
+
+@pytest.mark.parametrize("kind", ["dense", "packed", "frame_causal", "causal", "holes", "gqa_segments"])
+def test_attention_hand_scheduled_bodies_agree_bit_for_bit(ops, kind):
+    """Head dim 96 runs its tiles through the hand-scheduled, software-pipelined bodies of csrc/gen/attn_p2_gen.py (the
+    default); VGPT_ATTN_P2=0 selects the compiler-scheduled tile body.  Same instructions per element and the same summation
+    order: outputs AND log-sum-exp must agree bit for bit on dense, packed, block-causal, causal and holed masks (tiles a
+    wave sees in full, in part, or not at all; wholly masked rows; a last tile running past L), with grouped KV heads, on
+    row segments, and where a row's running maximum moves late (the rescale branch)."""
+    ops_train = importlib.import_module("video-gpt_amd.ops_train")
+    nh, nkv, hd = 4, 4, 96
+
+    def frame_causal(L, f):
+        i = np.arange(L) // f
+        return (i[:, None] >= i[None, :]).astype(np.uint8)
+    segs = None
+    if kind == "dense":
+        m = np.ones((1, 1100, 1100), dtype=np.uint8)
+    elif kind == "packed":
+        m = np.zeros((1, 1300, 1300), dtype=np.uint8); m[0, :780, :780] = 1; m[0, 780:, 780:] = 1
+    elif kind == "frame_causal":
+        m = np.stack([frame_causal(900, 300), frame_causal(900, 180)])
+    elif kind == "causal":
+        m = np.tril(np.ones((1, 700, 700), dtype=np.uint8))
+    elif kind == "holes":
+        m = frame_causal(1000, 100)[None].copy(); m[0, 400:440] = 0; m[0, :, 64:128] = 0; m[0, 5, 64] = 1
+    else:
+        nh, nkv = 8, 2
+        m = _random_block_mask(1, 1300, 32)
+        np.fill_diagonal(m[0], 1)
+        segs = ((0, 256, 790), (0, 790, 1300))
+    B, L = m.shape[:2]
+    qkv = bf(torch.randn(B, L, (nh + 2 * nkv) * hd, generator=g(71)) * 1.5)
+    kq = qkv[..., nh * hd:(nh + nkv) * hd].view(B, L, nkv, hd)
+    kq[:, (2 * L) // 3] = bf(qkv[..., : nh * hd].view(B, L, nh, hd)[:, L - 7, :nkv] * 6.0)   # a late key far above the others
+    pm = ops.pack_mask(torch.from_numpy(m).to(DEV))
+    dq = qkv.to(DEV, BF)
+    res = {}
+    old = os.environ.get("VGPT_ATTN_P2")
+    try:
+        for p2 in ("0", "1"):
+            os.environ["VGPT_ATTN_P2"] = p2
+            if segs is None:
+                out = torch.empty(B, L, nh * hd, dtype=BF, device=DEV)
+                lse = torch.empty(B, nh, L, dtype=torch.float32, device=DEV)
+                ops_train.attention_qkv_train(dq, pm, nh, nkv, hd, out, lse)
+                res[p2] = (out, lse)
+            else:
+                out = torch.full((B, L, nh * hd), 7.0, dtype=BF, device=DEV)
+                ops.attention_qkv_range(dq, pm, nh, nkv, hd, 0, out, segments=segs)
+                res[p2] = (out, torch.zeros(1, device=DEV))
+    finally:
+        if old is None:
+            os.environ.pop("VGPT_ATTN_P2", None)
+        else:
+            os.environ["VGPT_ATTN_P2"] = old
+    assert torch.equal(res["0"][0], res["1"][0])
+    assert torch.equal(res["0"][1], res["1"][1])
+    q = qkv[..., : nh * hd].view(B, L, nh, hd).transpose(1, 2)
+    k = qkv[..., nh * hd:(nh + nkv) * hd].view(B, L, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
+    v = qkv[..., (nh + nkv) * hd:].view(B, L, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
+    ref = _ref_attention(q, k, v, torch.from_numpy(m), 1 / math.sqrt(hd)).transpose(1, 2).reshape(B, L, -1)
+    rows = slice(256, 1300) if segs is not None else slice(0, L)
+    assert rel_l2(res["1"][0][:, rows], ref[:, rows]) < 1e-2
 
 
 @pytest.mark.parametrize("spike_at,boost", [(200, 8.0), (40, 30.0), (700, 3.0)])

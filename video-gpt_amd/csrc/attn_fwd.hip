@@ -57,6 +57,10 @@
 // waves per SIMD already fill the issue port between them (active_inst_any 0.39 per wave, profiles/r02_pmc_mfma.json);
 // kept out of the product as csrc/experiments/attn_fwd_pipelined_loop.inc.
 
+#include "attn_p2_loop.inc"
+#define VGPT_P2_DRAIN_0_M VGPT_P2_DRAIN_0
+#define VGPT_P2_DRAIN_1_M VGPT_P2_DRAIN_1
+
 namespace {
 
 struct AttnArgs {
@@ -142,9 +146,14 @@ constexpr int vbytes() { return TR ? 64 * Cfg<D>::VROW_TR : D * Cfg<D>::VROW_T; 
 // NW = waves per workgroup: 4 (128 query rows, two workgroups per CU) or 8 (256 rows, one workgroup per CU, planned launches
 // with 256-row items, head dim 96 on the LDS-DMA path): the same K / V tile then serves twice the query rows, so every wave
 // issues half the LDS-DMA pieces per tile (3 instead of 6) and the CU takes in half the bytes per FLOP.
-template <int D, bool TR, int NW = 4>
+// P2: runs of tiles every wave sees in full go through the hand-scheduled, software-pipelined tile bodies of
+// gen/attn_p2_gen.py (QK^T of tile t+1 beside the exponentials of tile t, P.V of tile t beside the maxima of tile t+1, packed
+// fp32 instructions only where no MFMA is in flight); mixed tiles and everything around the tiles stay in C++.  Same
+// arithmetic per element: bit-identical to the C++ body.
+template <int D, bool TR, int NW = 4, bool P2 = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void attn_fwd_kernel(AttnArgs a) {
     static_assert(NW == 4 || (NW == 8 && D == 96 && TR), "8 waves: head dim 96, LDS-DMA path");
+    static_assert(!P2 || (D == 96 && TR && NW == 4), "hand-scheduled bodies: head dim 96, four waves");
     constexpr int CODE_BITS = 2 * NW;                       // summary bits of one tile in an active-list entry
     constexpr uint32_t CODE_MASK = (1u << CODE_BITS) - 1u;
     using C = Cfg<D>;
@@ -217,7 +226,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q][16s + 8h .. +8) ----
     const int q_row = row0 + wave * 32 + r;
-    const bool q_valid = q_row <= row_last;
     const int q_ld = min(q_row, row_last);
     const bf16* qp = a.q + (int64_t)b * a.q_sb + (int64_t)head * a.q_sh + (int64_t)q_ld * a.q_ss;
     bf16x8 Qf[KS];
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
     }
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-    auto glds_tile = [&](int buf, int kt) {
+    auto glds_tile = [&](int buf, int kt, bool want_k = true, bool want_v = true) {
         if constexpr (GLDS) {
             const char* kt_base = reinterpret_cast<const char*>(kbase + (int64_t)kt * 64 * a.k_ss);
             const char* vt_base = reinterpret_cast<const char*>(vbase + (int64_t)kt * 64 * a.v_ss);
@@ -285,8 +293,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
                     vo = key * (uint32_t)a.v_ss * 2u + g_vc[j];
                 }
                 const uint32_t dst = lds_base + (uint32_t)(buf * STAGE + (swave * PIECES + j) * 1024);
-                if (do_k) glds16(kt_base, ko, dst);
-                if (do_v) glds16(vt_base, vo, dst + C::KBYTES);
+                if (do_k && want_k) glds16(kt_base, ko, dst);
+                if (do_v && want_v) glds16(vt_base, vo, dst + C::KBYTES);
             }
         }
     };
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
     // inside the tile loop and the vmcnt(0) emitted for it would also drain the (asm-issued) LDS-DMA in flight.
 #pragma unroll
     for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(Qf[s]));
+    if constexpr (P2) asm volatile(VGPT_P2_INIT ::: VGPT_P2_CLOBBERS);
     for (int chunk0 = 0; chunk0 < a.nkt; chunk0 += ACT_MAX) {
     __syncthreads();  // every wave is done with the previous list and the staging buffers
     if (wave == 0) {
@@ -366,7 +375,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
     int buf = 0;
     mask_dma(0, e_cur);
     stage(0, (int)(e_cur >> CODE_BITS));
-    for (int it = 0; it < n_act; ++it) {
+    int it = 0;
+    auto classic = [&]() {
         STAMP(sA);
         if constexpr (GLDS) {
             // this wave's share of the current tile has landed; the raw barrier then (a) publishes every wave's
@@ -558,9 +568,134 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
         e_cur = e_nxt;
         e_nxt = __builtin_amdgcn_readfirstlane(e_n2);
         buf ^= 1;
+        ++it;
+    };
+    if constexpr (!P2) {
+        while (it < n_act) classic();
+    } else {
+        // per-lane LDS addresses of the fragment reads; buffer, key half, k-step and d block are immediates of the bodies
+        const uint32_t sw = (uint32_t)(r >> 2) & 3u;
+        const uint32_t ka0 = lds_base + (uint32_t)r * C::KROW + (((uint32_t)h) ^ sw) * 16u;
+        const uint32_t ka1 = lds_base + (uint32_t)r * C::KROW + ((2u + (uint32_t)h) ^ sw) * 16u;
+        const int li = lane & 15;
+        const uint32_t va = lds_base + (uint32_t)(4 * h + (li >> 2)) * C::VROW_TR + (uint32_t)((((lane >> 4) & 1) * 16 + 4 * (li & 3)) * 2);
+        static_assert(STAGE == 24576 && C::KBYTES == 12288 && C::KROW == 192 && C::VROW_TR == 192, "layout constants of gen/attn_p2_gen.py");
+        const float scale = a.scale_log2e;
+        const uint32_t ninf = 0xff800000u;
+        [[maybe_unused]] uint32_t m0_keep;
+        // (no outputs: O, m, l, alpha and S stay in v[72:191] from body to body -- VGPT_P2_INIT / VGPT_P2_EXPORT around the item)
+#define VGPT_P2_OPERANDS                                                                                                        \
+        : [m0keep] "=&s"(m0_keep)                                                                                                 \
+        : [q0] "v"(Qf[0]), [q1] "v"(Qf[1]), [q2] "v"(Qf[2]), [q3] "v"(Qf[3]), [q4] "v"(Qf[4]), [q5] "v"(Qf[5]), [ka0] "v"(ka0),   \
+          [ka1] "v"(ka1), [va] "v"(va), [scale] "s"(scale), [ninf] "s"(ninf), [mw0] "v"(mw0), [mw1] "v"(mw1),                     \
+          [kbase] "s"(k_src), [vbase] "s"(v_src), [kdst] "s"(k_dst), [vdst] "s"(v_dst), [ko0] "v"(ko[0]), [ko1] "v"(ko[1]),       \
+          [ko2] "v"(ko[2]), [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2])                                                  \
+        : VGPT_P2_CLOBBERS
+#define VGPT_P2_BODY(KIND, masked)                                                                     \
+        do {                                                                                           \
+            if (buf == 0) {                                                                            \
+                if (masked) asm volatile(VGPT_P2_##KIND##_0_M VGPT_P2_OPERANDS);                       \
+                else asm volatile(VGPT_P2_##KIND##_0 VGPT_P2_OPERANDS);                                \
+            } else {                                                                                   \
+                if (masked) asm volatile(VGPT_P2_##KIND##_1_M VGPT_P2_OPERANDS);                       \
+                else asm volatile(VGPT_P2_##KIND##_1 VGPT_P2_OPERANDS);                                \
+            }                                                                                          \
+        } while (0)
+        auto top_sync = [&]() {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        // mask words of this wave's rows in tile entry E (slot of staging buffer BUFM): a wave that sees nothing of the tile
+        // masks every key (its scores become -inf, P = 0: state unchanged)
+#define VGPT_P2_MASK_WORDS(BUFM, E)                                                                                              \
+        uint32_t mw0 = 0u, mw1 = 0u;            /* key bits of the lane's query row in the tile, >> 4 h */                       \
+        const int code_ = ((E) >> (2 * wave)) & 3;                                                                               \
+        const bool masked = code_ != 1;                                                                                          \
+        if (code_ == 2) {                                                                                                        \
+            const uint2 mw = *reinterpret_cast<const uint2*>(smem + MASK_OFF + (BUFM) * (NW * 256) + wave * 256 + r * 8);        \
+            mw0 = mw.x >> (4 * h);                                                                                               \
+            mw1 = ((2 * (int)((E) >> CODE_BITS) + 1 < a.W) ? mw.y : 0u) >> (4 * h);                                              \
+        }
+        // ---- first tile: S^T and the maxima ----
+        top_sync();
+        uint32_t e_n2 = __builtin_amdgcn_readfirstlane(n_act > 2 ? alist[3] : 0u);
+        if (n_act > 1) {
+            mask_dma(1, e_nxt);
+            stage(1, (int)(e_nxt >> CODE_BITS));
+        }
+        {
+            const char *k_src = nullptr, *v_src = nullptr;      // (operands of the steady bodies' LDS-DMA: unused here)
+            const uint32_t k_dst = 0u, v_dst = 0u, ko[3] = {0u, 0u, 0u}, vo[3] = {0u, 0u, 0u};
+            VGPT_P2_MASK_WORDS(0, e_cur)
+            VGPT_P2_BODY(PRO, masked);
+        }
+        // ---- pipelined bodies: exponentials and P.V of tile `it`, QK^T and maxima of tile it + 1; the body also issues the
+        //      LDS-DMA of K(it+2) (over K(it)) and V(it+1) (over V(it-1)), spread between its MFMAs.  Where there is no tile
+        //      it + 2 the K image of the current tile is fetched again onto itself, and the first body repeats the V image the
+        //      full stage above already requested: same bytes to the same place, no branch in the body ----
+        uint32_t e_n3v = n_act > 3 ? alist[4] : 0u;       // entry it + 3, read one body ahead of its use
+        for (; it + 1 < n_act; ++it) {
+            STAMP(sA);
+            top_sync();                         // K(it+1), V(it) have landed; every wave is done with K(it) and V(it-1)
+            STAMP(sB);
+            if (it + 2 < n_act) mask_dma(buf, e_n2);                  // mask words of tile it + 2 over those of tile it
+            const int kt_k = (int)((it + 2 < n_act ? e_n2 : e_cur) >> CODE_BITS), kt_v = (int)(e_nxt >> CODE_BITS);
+            const char* k_src = reinterpret_cast<const char*>(kbase + (int64_t)kt_k * 64 * a.k_ss);
+            const char* v_src = reinterpret_cast<const char*>(vbase + (int64_t)kt_v * 64 * a.v_ss);
+            // per-lane source offsets of the six pieces; a tile that runs past the last key clamps its keys onto it -- rare, so
+            // the (key, chunk) of a lane's units are recomputed there instead of being held in nine registers across the bodies
+            uint32_t ko[PIECES], vo[PIECES];
+#pragma unroll
+            for (int j = 0; j < PIECES; ++j) {
+                ko[j] = g_koff[j];
+                vo[j] = g_voff[j];
+            }
+            if (kt_k * 64 + 64 > a.L || kt_v * 64 + 64 > a.L) {
+                int lane_t = threadIdx.x & 63;
+                asm volatile("" : "+v"(lane_t));      // (opaque: keeps hipcc from hoisting these out of the loop and spilling them)
+#pragma unroll
+                for (int j = 0; j < PIECES; ++j) {
+                    const int unit = (wave * PIECES + j) * 64 + lane_t, key = unit / C::CHUNKS, ch = unit % C::CHUNKS;
+                    if (kt_k * 64 + 64 > a.L)
+                        ko[j] = (uint32_t)(min(kt_k * 64 + key, a.L - 1) - kt_k * 64) * (uint32_t)a.k_ss * 2u + (uint32_t)((ch ^ ((key >> 2) & 3)) * 16);
+                    if (kt_v * 64 + 64 > a.L)
+                        vo[j] = (uint32_t)(min(kt_v * 64 + key, a.L - 1) - kt_v * 64) * (uint32_t)a.v_ss * 2u + (uint32_t)(ch * 16);
+                }
+            }
+            const uint32_t k_dst = lds_base + (uint32_t)(buf * STAGE + wave * PIECES * 1024);
+            const uint32_t v_dst = lds_base + (uint32_t)((buf ^ 1) * STAGE + wave * PIECES * 1024) + C::KBYTES;
+            VGPT_P2_MASK_WORDS(buf ^ 1, e_nxt)
+            STAMP(sC);
+            VGPT_P2_BODY(STEADY, masked);
+#if VGPT_ATTN_STAMPS
+            {
+                STAMP(sD);
+                ph[0] += sB - sA; ph[1] += sC - sB; ph[2] += sD - sC;
+            }
+#endif
+            e_cur = e_nxt;
+            e_nxt = e_n2;
+            e_n2 = __builtin_amdgcn_readfirstlane(e_n3v);
+            e_n3v = it + 4 < n_act ? alist[5 + it] : 0u;
+            buf ^= 1;
+        }
+        // ---- the last tile ----
+        top_sync();
+        {
+            const char *k_src = nullptr, *v_src = nullptr;
+            const uint32_t k_dst = 0u, v_dst = 0u, ko[3] = {0u, 0u, 0u}, vo[3] = {0u, 0u, 0u};
+            const uint32_t mw0 = 0u, mw1 = 0u;
+            VGPT_P2_BODY(DRAIN, false);
+        }
+        ++it;
+#undef VGPT_P2_BODY
+#undef VGPT_P2_MASK_WORDS
+#undef VGPT_P2_OPERANDS
     }
     }
 
+    if constexpr (P2) asm volatile(VGPT_P2_EXPORT : "=&v"(O[0][0]), "=&v"(O[0][1]), "=&v"(O[0][2]), "=&v"(O[0][3]), "=&v"(O[0][4]), "=&v"(O[0][5]), "=&v"(O[0][6]), "=&v"(O[0][7]), "=&v"(O[0][8]), "=&v"(O[0][9]), "=&v"(O[0][10]), "=&v"(O[0][11]), "=&v"(O[0][12]), "=&v"(O[0][13]), "=&v"(O[0][14]), "=&v"(O[0][15]), "=&v"(O[1][0]), "=&v"(O[1][1]), "=&v"(O[1][2]), "=&v"(O[1][3]), "=&v"(O[1][4]), "=&v"(O[1][5]), "=&v"(O[1][6]), "=&v"(O[1][7]), "=&v"(O[1][8]), "=&v"(O[1][9]), "=&v"(O[1][10]), "=&v"(O[1][11]), "=&v"(O[1][12]), "=&v"(O[1][13]), "=&v"(O[1][14]), "=&v"(O[1][15]), "=&v"(O[2][0]), "=&v"(O[2][1]), "=&v"(O[2][2]), "=&v"(O[2][3]), "=&v"(O[2][4]), "=&v"(O[2][5]), "=&v"(O[2][6]), "=&v"(O[2][7]), "=&v"(O[2][8]), "=&v"(O[2][9]), "=&v"(O[2][10]), "=&v"(O[2][11]), "=&v"(O[2][12]), "=&v"(O[2][13]), "=&v"(O[2][14]), "=&v"(O[2][15]), "=&v"(m_i), "=&v"(l_i) :: VGPT_P2_CLOBBERS);
     if (a.trace && tid == 0) {
         unsigned hw_id, xcc_id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
@@ -582,11 +717,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
 #if VGPT_ATTN_LAZY
     const float l_i = Ol[0], m_i = m_ref;   // every register of Ol holds the lane's row sum (all 64 keys of a tile: no half-sum)
 #endif
-    if (a.lse && q_valid && h == 0)
-        a.lse[((int64_t)b * a.n_heads + head) * a.L + q_row] = l_i > 0.f ? m_i + __builtin_amdgcn_logf(l_i) : INFINITY;
-    if (q_valid) {
+    int lane_e = threadIdx.x & 63;
+    if constexpr (P2) asm volatile("" : "+v"(lane_e));   // the hand-scheduled kernel leaves hipcc 64 registers in the tile loop: the
+    const int r_e = lane_e & 31, h_e = lane_e >> 5;      // epilogue's lane-derived values are formed here, not carried through it
+    const int q_row_e = row0 + wave * 32 + r_e;
+    const bool q_valid_e = q_row_e <= row_last;
+    if (a.lse && q_valid_e && h_e == 0)
+        a.lse[((int64_t)b * a.n_heads + head) * a.L + q_row_e] = l_i > 0.f ? m_i + __builtin_amdgcn_logf(l_i) : INFINITY;
+    if (q_valid_e) {
         const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
-        bf16* op = a.o + (int64_t)b * a.o_sb + (int64_t)head * a.o_sh + (int64_t)q_row * a.o_ss;
+        bf16* op = a.o + (int64_t)b * a.o_sb + (int64_t)head * a.o_sh + (int64_t)q_row_e * a.o_ss;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -594,17 +734,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
                 bf16x4 o;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[t] = f2bf(O[dt][4 * g4 + t] * inv);
-                *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g4 + 4 * h) = o;
+                *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g4 + 4 * h_e) = o;
             }
     }
 }
 
-template <int D, bool TR, int NW = 4>
+template <int D, bool TR, int NW = 4, bool P2 = false>
 int launch(const AttnArgs& a, hipStream_t s) {
     constexpr int lds = 2 * (Cfg<D>::KBYTES + vbytes<D, TR>()) + 4096 + 2 * NW * 256;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, TR, NW>,
+        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, TR, NW, P2>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             vgpt_set_error("vgpt_attn_blockmask_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -613,7 +753,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int total = a.items ? a.n_items * a.n_heads : (a.nqb - a.qb0) * a.n_heads * a.B;
-    hipLaunchKernelGGL((attn_fwd_kernel<D, TR, NW>), dim3(total), dim3(64 * NW), lds, s, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, TR, NW, P2>), dim3(total), dim3(64 * NW), lds, s, a);
     VGPT_CHECK_LAUNCH("vgpt_attn_blockmask_fwd");
     return VGPT_OK;
 }
@@ -631,6 +771,12 @@ VGPT_EXPORT int vgpt_attn_trace(void* buf, int64_t capacity_workgroups) {
 
 VGPT_EXPORT int vgpt_attn_supported(int head_dim) {
     return head_dim == 64 || head_dim == 96 || head_dim == 128;
+}
+
+// VGPT_ATTN_P2=0 keeps head dim 96 on the compiler-scheduled tile body (A/B runs, the bit-for-bit test)
+static bool attn_p2_enabled() {
+    const char* e = getenv("VGPT_ATTN_P2");
+    return !(e && e[0] == '0');
 }
 
 struct ItemPlan {
@@ -702,6 +848,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
                      "vgpt_attn_fwd_plan: 256-row items need head_dim 96 (got %d)", head_dim);
         return launch<96, true, 8>(a, s);
     }
+    if (head_dim == 96 && variant == 0 && attn_p2_enabled()) return launch<96, true, 4, true>(a, s);
     switch (head_dim) {
         ATTN_CASE(64) ATTN_CASE(96) ATTN_CASE(128)
     }
