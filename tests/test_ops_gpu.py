@@ -577,8 +577,11 @@ def test_attention_hand_scheduled_bodies_agree_bit_for_bit(ops, kind):
     k = qkv[..., nh * hd:(nh + nkv) * hd].view(B, L, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
     v = qkv[..., (nh + nkv) * hd:].view(B, L, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
     ref = _ref_attention(q, k, v, torch.from_numpy(m), 1 / math.sqrt(hd)).transpose(1, 2).reshape(B, L, -1)
-    rows = slice(256, 1300) if segs is not None else slice(0, L)
-    assert rel_l2(res["1"][0][:, rows], ref[:, rows]) < 1e-2
+    live = torch.from_numpy(m.any(axis=2))                    # rows that see no key at all come out as zeros
+    if segs is not None:
+        live[:, :256] = False
+    assert rel_l2(res["1"][0].cpu()[live], ref[live]) < 1e-2
+    assert bool((res["1"][0].cpu()[~torch.from_numpy(m.any(axis=2))].float() == 0).all())
 
 
 @pytest.mark.parametrize("spike_at,boost", [(200, 8.0), (40, 30.0), (700, 3.0)])

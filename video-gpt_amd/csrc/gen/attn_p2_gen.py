@@ -21,6 +21,7 @@ kernels agree bit for bit (tests/test_ops_gpu.py).  Control (tile list, barriers
 Emits attn_p2_loop.inc: VGPT_P2_PRO_<p>, VGPT_P2_STEADY_<p>, VGPT_P2_DRAIN_<p> for p = parity of the staging buffer that
 holds the CURRENT tile (the S registers alternate with it), and the operand / clobber lists.
 """
+import os
 import sys
 
 # ---- physical registers ------------------------------------------------------------------------------------------------
@@ -191,7 +192,8 @@ def fill(sc, queue, budget):
 SLOT = 24      # cycles of one-pass vector issue that fit beside one MFMA (32 - 8 of MFMA issue)
 
 
-K_AHEAD = 6     # K fragments requested before the first MFMA; one more behind every MFMA
+K_AHEAD = int(os.environ.get("P2_KAHEAD", 6))     # K fragments requested before the first MFMA; one more behind every MFMA
+PREFILL = int(os.environ.get("P2_PREFILL", 48))   # cycles of exponentials issued while the first K fragments travel
 
 
 def phase_qk(sc, p_next, buf_next, valu, with_dma=False):
@@ -200,7 +202,7 @@ def phase_qk(sc, p_next, buf_next, valu, with_dma=False):
     workgroup, in lockstep behind the barrier, asked the LDS for ~190 B/clk."""
     for j in range(K_AHEAD):
         k_read(sc, buf_next, j)
-    fill(sc, valu, 48)
+    fill(sc, valu, PREFILL)
     for j in range(12):
         sc.need({("k", j)})
         sc.emit(qk_mfma(p_next, j))
@@ -244,7 +246,8 @@ def body(kind, p, masked=False):
     """p = staging buffer (and S register set) of the CURRENT tile; masked: the tile whose maxima this body forms (the first
     tile in `pro`, the NEXT one in `steady`) is not visible in full to this wave"""
     sc = Sched()
-    sc.emit("s_nop 3")
+    if not int(os.environ.get("P2_NONOP", 0)):
+        sc.emit("s_nop 3")
     if kind == "pro":          # QK^T of the first tile of a run, then its maxima: no tile before it
         phase_qk(sc, p, p, [])
         sc.emit("s_nop 7"); sc.emit("s_nop 3")          # MFMA result -> vector reader
