@@ -624,7 +624,7 @@ def main():
                       + (" + 1 / rms of the output rows for the next norm" if fz is not None else "") + ")", 2 * rows * I * H, f_down),
                      ("o_proj", "gemm_w4_kernel<MODE_PLAIN, 6> (four-wave hand-scheduled loop, 256 x 192 tiles; o_proj + residual"
                       + (" + 1 / rms of the output rows for the next norm" if fz is not None else "") + ")", 2 * rows * H * H, f_o),
-                     ("attn_fwd", "attn_fwd_kernel<96> (block-masked flash attention, planned launch)", flops_attn // nl, attn_call))
+                     ("attn_fwd", "attn_fwd_kernel<96, true, 4, P2> (block-masked flash attention, planned launch, hand-scheduled tile bodies)", flops_attn // nl, attn_call))
             # (1) every kind on its own, back to back over the 32 layers: one event pair per kind
             iso = {}
             for name, kname, alg, fn in kinds:
