@@ -517,7 +517,8 @@ def test_attention_planned_kernel(ops, B, L, nh, nkv, segs, hd):
         assert (pm.plan(segs, 256).item_rows == 256) and pm.plan(segs, 256).n_items < pm.plan(segs).n_items
 
 
-@pytest.mark.parametrize("kind", ["dense", "packed", "frame_causal", "causal", "holes", "gqa_segments"])
+@pytest.mark.parametrize("kind", ["dense", "packed", "frame_causal", "causal", "holes", "gqa_segments", "tiny_40", "tiny_64", "tiny_100",
+                                  "tiny_130", "tiny_200"])
 def test_attention_hand_scheduled_bodies_agree_bit_for_bit(ops, kind):
     """Head dim 96 runs its tiles through the hand-scheduled, software-pipelined bodies of csrc/gen/attn_p2_gen.py (the
     default); VGPT_ATTN_P2=0 selects the compiler-scheduled tile body.  Same instructions per element and the same summation
@@ -541,6 +542,9 @@ def test_attention_hand_scheduled_bodies_agree_bit_for_bit(ops, kind):
         m = np.tril(np.ones((1, 700, 700), dtype=np.uint8))
     elif kind == "holes":
         m = frame_causal(1000, 100)[None].copy(); m[0, 400:440] = 0; m[0, :, 64:128] = 0; m[0, 5, 64] = 1
+    elif kind.startswith("tiny"):        # one, two, three and four key tiles: prologue + drain only, then one / two pipelined bodies
+        Lt = int(kind.split("_")[1])
+        m = np.stack([np.ones((Lt, Lt), dtype=np.uint8), frame_causal(Lt, 16)])
     else:
         nh, nkv = 8, 2
         m = _random_block_mask(1, 1300, 32)
@@ -549,7 +553,7 @@ def test_attention_hand_scheduled_bodies_agree_bit_for_bit(ops, kind):
     B, L = m.shape[:2]
     qkv = bf(torch.randn(B, L, (nh + 2 * nkv) * hd, generator=g(71)) * 1.5)
     kq = qkv[..., nh * hd:(nh + nkv) * hd].view(B, L, nkv, hd)
-    kq[:, (2 * L) // 3] = bf(qkv[..., : nh * hd].view(B, L, nh, hd)[:, L - 7, :nkv] * 6.0)   # a late key far above the others
+    kq[:, (2 * L) // 3] = bf(qkv[..., : nh * hd].view(B, L, nh, hd)[:, L - 7, :nkv] * (6.0 if L > 256 else 2.0))   # a late key far above the others
     pm = ops.pack_mask(torch.from_numpy(m).to(DEV))
     dq = qkv.to(DEV, BF)
     res = {}
