@@ -581,13 +581,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
         const uint32_t va = lds_base + (uint32_t)(4 * h + (li >> 2)) * C::VROW_TR + (uint32_t)((((lane >> 4) & 1) * 16 + 4 * (li & 3)) * 2);
         static_assert(STAGE == 24576 && C::KBYTES == 12288 && C::KROW == 192 && C::VROW_TR == 192, "layout constants of gen/attn_p2_gen.py");
         const float scale = a.scale_log2e;
+        const unsigned long long scale2 = ((unsigned long long)__float_as_uint(scale) << 32) | __float_as_uint(scale);
         const uint32_t ninf = 0xff800000u;
         [[maybe_unused]] uint32_t m0_keep;
         // (no outputs: O, m, l, alpha and S stay in v[72:191] from body to body -- VGPT_P2_INIT / VGPT_P2_EXPORT around the item)
 #define VGPT_P2_OPERANDS                                                                                                        \
         : [m0keep] "=&s"(m0_keep)                                                                                                 \
         : [q0] "v"(Qf[0]), [q1] "v"(Qf[1]), [q2] "v"(Qf[2]), [q3] "v"(Qf[3]), [q4] "v"(Qf[4]), [q5] "v"(Qf[5]), [ka0] "v"(ka0),   \
-          [ka1] "v"(ka1), [va] "v"(va), [scale] "s"(scale), [ninf] "s"(ninf), [mw0] "v"(mw0), [mw1] "v"(mw1),                     \
+          [ka1] "v"(ka1), [va] "v"(va), [scale] "s"(scale), [scale2] "s"(scale2), [ninf] "s"(ninf), [mw0] "v"(mw0), [mw1] "v"(mw1),                     \
           [kbase] "s"(k_src), [vbase] "s"(v_src), [kdst] "s"(k_dst), [vdst] "s"(v_dst), [ko0] "v"(ko[0]), [ko1] "v"(ko[1]),       \
           [ko2] "v"(ko[2]), [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2])                                                  \
         : VGPT_P2_CLOBBERS

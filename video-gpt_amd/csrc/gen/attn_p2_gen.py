@@ -47,9 +47,19 @@ class Sched:
         self.out, self.lds = [], []      # lds: tags of outstanding reads in issue order
 
     def emit(self, s):
+        if (DIAG & 8) and s.startswith("v_exp_f32"):
+            s = s.replace("v_exp_f32", "v_mov_b32")
+        if (DIAG & 16) and s.startswith("v_mfma"):
+            return
+        if (DIAG & 4) and s.startswith("global_load_lds"):
+            return
         self.out.append(s)
 
     def read(self, tag, s):
+        if (DIAG & 1) and tag[0] == "v":
+            return
+        if (DIAG & 2) and tag[0] == "k":
+            return
         self.out.append(s)
         self.lds.append(tag)
 
@@ -163,9 +173,17 @@ def part1_ops(p, masked):
           f"v_cmp_neq_f32 vcc, v{a}, v{V_M}", "s_nop 1", f"v_cndmask_b32 v{V_MOVED}, 0, 1, vcc",
           f"v_cmp_neq_f32 vcc, 0xff800000, v{a}", "s_nop 1", f"v_cndmask_b32 v{V_MUSE}, 0, v{a}, vcc",
           f"v_sub_f32 v{t}, v{V_M}, v{V_MUSE}", f"v_exp_f32 v{V_ALPHA}, v{t}", f"v_mov_b32 v{V_M}, v{a}"]
-    for kb in range(2):
-        for i in range(16):
-            o.append(f"v_fma_f32 v{S(p, kb, i)}, v{S(p, kb, i)}, %[scale], -v{V_MUSE}")
+    if PKFMA:
+        # x = S scale - m_use two at a time: the diagnostics (P2_DIAG) show the kernel bound by the vector issue port the two
+        # waves of a SIMD share, not by the matrix pipe -- a packed instruction stalls the MFMA in flight but halves the slots
+        for kb in range(2):
+            for i in range(0, 16, 2):
+                r = S(p, kb, i)
+                o.append(f"v_pk_fma_f32 v[{r}:{r + 1}], v[{r}:{r + 1}], %[scale2], v[{V_MUSE}:{V_MUSE + 1}] op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]")
+    else:
+        for kb in range(2):
+            for i in range(16):
+                o.append(f"v_fma_f32 v{S(p, kb, i)}, v{S(p, kb, i)}, %[scale], -v{V_MUSE}")
     return [(4, x) for x in pre + o]
 
 
@@ -193,6 +211,9 @@ SLOT = 24      # cycles of one-pass vector issue that fit beside one MFMA (32 - 
 
 
 K_AHEAD = int(os.environ.get("P2_KAHEAD", 6))     # K fragments requested before the first MFMA; one more behind every MFMA
+DIAG = int(os.environ.get("P2_DIAG", 0))   # diagnostics (results are WRONG): 1 no V fragment reads, 2 no K fragment reads, 4 no LDS-DMA, 8 v_exp_f32
+                                           # replaced by v_mov_b32, 16 no MFMAs
+PKFMA = int(os.environ.get("P2_PKFMA", 0))     # x = S scale - m as 16 v_pk_fma_f32 instead of 32 v_fma_f32
 PREFILL = int(os.environ.get("P2_PREFILL", 48))   # cycles of exponentials issued while the first K fragments travel
 
 
