@@ -349,6 +349,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
     // inside the tile loop and the vmcnt(0) emitted for it would also drain the (asm-issued) LDS-DMA in flight.
 #pragma unroll
     for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(Qf[s]));
+#ifdef VGPT_ATTN_PRIO
+    // experiment (make attn-variant-VGPT_ATTN_PRIO VAL=n): a static s_setprio 1 for one of the two workgroups of a CU
+    if constexpr (P2) { if ((blockIdx.x >> VGPT_ATTN_PRIO) & 1) __builtin_amdgcn_s_setprio(1); }
+#endif
     if constexpr (P2) asm volatile(VGPT_P2_INIT ::: VGPT_P2_CLOBBERS);
     for (int chunk0 = 0; chunk0 < a.nkt; chunk0 += ACT_MAX) {
     __syncthreads();  // every wave is done with the previous list and the staging buffers
