@@ -49,7 +49,7 @@ const char* vgpt_last_error(void);
 /* VGPT_ABI_VERSION of the library that was loaded.  Bumped with EVERY change of an exported signature; a binding written
  * for another value must refuse to call (video-gpt_amd/_lib.py does): with shifted arguments a stale library would read a
  * stream pointer as a scale and fault on the device instead of failing cleanly. */
-#define VGPT_ABI_VERSION 4
+#define VGPT_ABI_VERSION 5
 int vgpt_abi_version(void);
 
 /* ---- transformer block -------------------------------------------------- */
@@ -262,6 +262,12 @@ int vgpt_attn_qblock_order(const uint8_t* summary, int64_t B, int64_t L, int64_t
  * `capacity_workgroups` workgroups records {start, end (100 MHz realtime ticks), XCC_ID<<32|HW_ID, work item<<32 |
  * key tiles processed} per workgroup.  buf = NULL switches it off (the default). */
 int vgpt_attn_trace(void* buf, int64_t capacity_workgroups);
+
+/* Tile body of the head-dim-96 attention forward (every vgpt_attn_* forward entry above): 1 (default) = the generated,
+ * hand-scheduled, software-pipelined bodies (csrc/gen/attn_p2_gen.py), 0 = the compiler-scheduled body.  Outputs and log-sum-exp
+ * are bit-identical.  Process-wide, not thread-safe: a test and measurement switch (the environment variable VGPT_ATTN_P2=0
+ * sets the initial value, read once).  Returns the previous value; other values change nothing. */
+int vgpt_attn_set_hand_scheduled(int on);
 
 /* ---- model glue ---------------------------------------------------------- */
 

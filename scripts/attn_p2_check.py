@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 importlib.import_module("video-gpt_amd")
 ops = importlib.import_module("video-gpt_amd.ops")
+_lib = importlib.import_module("video-gpt_amd._lib").load()
 dev = "cuda:0"; BF = torch.bfloat16
 H, D = 32, 96
 
@@ -30,7 +31,7 @@ def masks():
 
 
 def run(qkv, pm, p2):
-    os.environ["VGPT_ATTN_P2"] = "1" if p2 else "0"
+    _lib.vgpt_attn_set_hand_scheduled(1 if p2 else 0)
     return ops.attention_qkv(qkv, pm, H, H, D)
 
 

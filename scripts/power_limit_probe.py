@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 import torch
 importlib.import_module("video-gpt_amd")
 ops = importlib.import_module("video-gpt_amd.ops")
+_lib = importlib.import_module("video-gpt_amd._lib").load()
 dev = "cuda:0"; BF = torch.bfloat16
 H, D = 32, 96
 m = torch.zeros(1, 5160, 5160, dtype=torch.bool); m[0, :3096, :3096] = True; m[0, 3096:, 3096:] = True
@@ -22,7 +23,7 @@ ygu = torch.empty(4096, 8192, dtype=BF, device=dev); yd = torch.empty(4096, 3072
 
 def attn(p2):
     def f():
-        os.environ["VGPT_ATTN_P2"] = p2
+        _lib.vgpt_attn_set_hand_scheduled(int(p2))
         ops.attention_qkv(qkv, pm, H, H, D)
     return f
 

@@ -521,7 +521,7 @@ def test_attention_planned_kernel(ops, B, L, nh, nkv, segs, hd):
                                   "tiny_130", "tiny_200"])
 def test_attention_hand_scheduled_bodies_agree_bit_for_bit(ops, kind):
     """Head dim 96 runs its tiles through the hand-scheduled, software-pipelined bodies of csrc/gen/attn_p2_gen.py (the
-    default); VGPT_ATTN_P2=0 selects the compiler-scheduled tile body.  Same instructions per element and the same summation
+    default); vgpt_attn_set_hand_scheduled(0) selects the compiler-scheduled tile body.  Same instructions per element and the same summation
     order: outputs AND log-sum-exp must agree bit for bit on dense, packed, block-causal, causal and holed masks (tiles a
     wave sees in full, in part, or not at all; wholly masked rows; a last tile running past L), with grouped KV heads, on
     row segments, and where a row's running maximum moves late (the rescale branch)."""
@@ -557,10 +557,11 @@ def test_attention_hand_scheduled_bodies_agree_bit_for_bit(ops, kind):
     pm = ops.pack_mask(torch.from_numpy(m).to(DEV))
     dq = qkv.to(DEV, BF)
     res = {}
-    old = os.environ.get("VGPT_ATTN_P2")
+    lib = importlib.import_module("video-gpt_amd._lib").load()
+    prev = lib.vgpt_attn_set_hand_scheduled(1)
     try:
         for p2 in ("0", "1"):
-            os.environ["VGPT_ATTN_P2"] = p2
+            lib.vgpt_attn_set_hand_scheduled(int(p2))
             if segs is None:
                 out = torch.empty(B, L, nh * hd, dtype=BF, device=DEV)
                 lse = torch.empty(B, nh, L, dtype=torch.float32, device=DEV)
@@ -571,10 +572,7 @@ def test_attention_hand_scheduled_bodies_agree_bit_for_bit(ops, kind):
                 ops.attention_qkv_range(dq, pm, nh, nkv, hd, 0, out, segments=segs)
                 res[p2] = (out, torch.zeros(1, device=DEV))
     finally:
-        if old is None:
-            os.environ.pop("VGPT_ATTN_P2", None)
-        else:
-            os.environ["VGPT_ATTN_P2"] = old
+        lib.vgpt_attn_set_hand_scheduled(prev)
     assert torch.equal(res["0"][0], res["1"][0])
     assert torch.equal(res["0"][1], res["1"][1])
     q = qkv[..., : nh * hd].view(B, L, nh, hd).transpose(1, 2)

@@ -151,8 +151,8 @@ def test_cfg5_chained_rounds_with_fp8_attention(pipe_case, monkeypatch):
     steps.  gen_nums [2, 2, 2], max_frame_window 6 from 2 input frames: the condition window GROWS 2 -> 4 and then SLIDES
     (round 2 drops the two oldest frames); every noise draw is replayed from fixed CPU tensors.
       * every round's sampled latents against the oracle composition run on that round's own recorded inputs:
-        bf16 engine within the calibrated latent tolerance, fp8 within 6e-2 (the fp8 option's own bound,
-        tests/test_attn_fp8_gpu.py: measured ~2e-2 against bf16 attention on the same operands);
+        bf16 AND fp8 engine within the calibrated latent tolerance (the fp8 kernel's own bound against bf16
+        attention on the same operands is in tests/test_attn_fp8_gpu.py);
       * fp8 rollout against the bf16 rollout on the returned uint8 frames;
       * round 2 presents the same sequence as round 1 (full window), so the scheduler RE-BINDS round 1's engine (buffers,
         per-layer fp8 workspaces, attention plan, captured graph kept; per-clip pass redone): the last round re-run ALONE on
@@ -200,7 +200,7 @@ def test_cfg5_chained_rounds_with_fp8_attention(pipe_case, monkeypatch):
             ref = SC.oracle_sample(cfg, p, batch, [t.float().cpu() for t in z], cond, steps, "x1")
             err = SC.rel_l2(torch.cat(out), torch.cat(ref))
             print(f"cfg-5 rollout, {prec} attention, round {k} (C = {C}): sampled latents rel-L2 vs oracle = {err:.3e}")
-            assert err < (6e-2 if prec == "fp8" else SC.tol("sampler_latents"))
+            assert err < SC.tol("sampler_latents")      # fp8 attention is held to the bf16 path's calibrated tolerance (measured 9.0e-3 vs 8.9e-3)
     diffs = [float((a.int() - b.int()).abs().float().mean()) for a, b in zip(outs["fp8"], outs["bf16"])]
     print("cfg-5 rollout: fp8 vs bf16 attention, mean grey-level difference per returned frame", [round(x, 2) for x in diffs])
     assert max(diffs) <= 4.0

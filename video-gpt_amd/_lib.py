@@ -22,7 +22,7 @@ PRED_V, PRED_X1 = 0, 1
 _P = c_void_p
 _I64 = c_int64
 # VGPT_ABI_VERSION (include/vgpt.h) the SIGNATURES table below was written for; load() refuses any other library
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> (restype, argtypes); every symbol declared in include/vgpt.h
 SIGNATURES = {
@@ -57,6 +57,7 @@ SIGNATURES = {
         c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, c_int, c_int, c_int] + [_I64] * 12 + [c_float, _P]),
     "vgpt_attn_qblock_order": (c_int, [_P, _I64, _I64, _I64, _P, _P]),
     "vgpt_attn_trace": (c_int, [_P, _I64]),
+    "vgpt_attn_set_hand_scheduled": (c_int, [c_int]),
     "vgpt_attn_plan_build": (c_int, [_P, _I64, _I64, _P, _I64, _P, _P, _P]),
     "vgpt_attn_plan_workspace_bytes": (_I64, [_I64, _I64]),
     "vgpt_attn_fwd_plan": (

@@ -778,10 +778,21 @@ VGPT_EXPORT int vgpt_attn_supported(int head_dim) {
     return head_dim == 64 || head_dim == 96 || head_dim == 128;
 }
 
-// VGPT_ATTN_P2=0 keeps head dim 96 on the compiler-scheduled tile body (A/B runs, the bit-for-bit test)
+// Tile body of the head-dim-96 forward: 1 (default) = the hand-scheduled bodies of gen/attn_p2_gen.py, 0 = the compiler-scheduled
+// body (bit-identical results).  vgpt_attn_set_hand_scheduled (include/vgpt.h): a test and measurement switch; the environment
+// variable VGPT_ATTN_P2=0 sets the initial value, read once.
+static int g_attn_p2 = -1;
 static bool attn_p2_enabled() {
-    const char* e = getenv("VGPT_ATTN_P2");
-    return !(e && e[0] == '0');
+    if (g_attn_p2 < 0) {
+        const char* e = getenv("VGPT_ATTN_P2");
+        g_attn_p2 = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_attn_p2 != 0;
+}
+VGPT_EXPORT int vgpt_attn_set_hand_scheduled(int on) {
+    const int prev = attn_p2_enabled() ? 1 : 0;
+    if (on == 0 || on == 1) g_attn_p2 = on;
+    return prev;
 }
 
 struct ItemPlan {
