@@ -21,8 +21,8 @@ def audit(verbose=True):
         meta[m.group(1)] = {k: int(re.search(k + r":\s+(\d+)", body).group(1))
                             for k in (".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size", ".vgpr_count")}
     names = sorted(meta)
-    if len(names) != 10:   # PLAIN / GATED / ROPE x 256- and 192-wide tiles, PLAIN / ROPE x 288-wide, PLAIN with a transposed W x 256 / 192
-        findings.append(f"expected 10 gemm_w4_kernel instantiations, found {len(names)}")
+    if len(names) != 12:   # PLAIN / GATED / ROPE x 256- and 192-wide tiles, PLAIN / ROPE x 288-wide, PLAIN with a transposed W, and with both operands transposed, x 256 / 192
+        findings.append(f"expected 12 gemm_w4_kernel instantiations, found {len(names)}")
     for name in names:
         i = s.index("\n" + name + ":")
         j = s.index(".Lfunc_end", i)

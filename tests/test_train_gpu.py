@@ -72,6 +72,30 @@ def test_transposed_operand_gemms(ops, T, M, N, K):
         assert torch.equal(dw2, dw)
 
 
+@pytest.mark.parametrize("M,N,K", [(777, 4096, 2048), (7740, 3072, 3072), (1000, 2056, 4104), (130, 8192, 1024)])
+def test_weight_gradient_product_on_the_four_wave_kernel(ops, T, M, N, K):
+    """dW (N, K) = dY (M, N)^T X (M, K) at sizes the four-wave kernel takes (128 or more 256 x 256 tiles): both operands staged
+    in their natural [token][channel] layout and read with ds_read_b64_tr_b16, token counts that are no multiple of 64 (the
+    partial last k-tile is zero-filled by the buffer descriptors), ragged output widths -- against fp64 and against the
+    eight-wave kernel (vgpt_gemm_set_family(1))."""
+    import importlib
+    lib = importlib.import_module("video-gpt_amd._lib").load()
+    dy = bf(torch.randn(M, N, generator=g(91)))
+    x = bf(torch.randn(M, K, generator=g(92)))
+    ref = (dy.to(DEV).double().t() @ x.to(DEV).double())
+    out = {}
+    for family in (0, 1):
+        prev = lib.vgpt_gemm_set_family(family)
+        try:
+            dw = torch.full((N, K), 3.0, dtype=BF, device=DEV)
+            T.linear_dw(dy.to(DEV, BF), x.to(DEV, BF), out=dw)
+        finally:
+            lib.vgpt_gemm_set_family(prev)
+        assert rel_l2(dw, ref) < 4e-3, family
+        out[family] = dw
+    assert rel_l2(out[0], out[1]) < 2e-3      # one bf16 rounding of sums formed in a different order
+
+
 @pytest.mark.parametrize("M,I,K", [(300, 256, 192), (37, 64, 64), (4096, 2048, 512), (7740, 1536, 128)])
 def test_gated_forward_that_keeps_gate_up_is_the_unfused_pair_bit_for_bit(ops, T, M, I, K):
     """The training forward's gate_up_proj + activation in one kernel (vgpt_gated_mlp_act_fwd_keep) against what it

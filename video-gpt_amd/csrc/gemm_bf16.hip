@@ -846,8 +846,11 @@ __device__ __forceinline__ f32x4 w4_acc() {
     return f32x4{x0, x1, x2, x3};
 }
 
-template <int MODE, int NI, bool WTR = false>
+template <int MODE, int NI, bool WTR = false, bool ATR = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
+    // ATR (with WTR: dW = dY^T X, the reduction runs over the ROWS of both operands): A is staged and read like the transposed W
+    // below, a partial last k-tile is zero-filled by the buffer descriptors' range check
+    static_assert(!ATR || WTR, "a transposed A comes with a transposed W");
     // WTR: W is stored with the reduction index as its ROW index ([K][N]: dX = dY W of the backward): staged as a
     // [64 reduction rows][256 columns] image (512-byte rows, 32-byte units XOR-swizzled as in gemm_bf16_kernel), fragments by
     // ds_read_b64_tr_b16; a 192-wide tile (NI 6) uses the same image and ignores its last 64 columns
@@ -896,7 +899,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
     uint32_t oa[8] = {}, ow[8] = {};
 #pragma unroll
-    for (int p = 0; p < (NI == 9 ? 0 : 8); ++p) {
+    for (int p = 0; p < (NI == 9 || ATR ? 0 : 8); ++p) {
         const int r = min((wave * 8 + p) * 8 + srow, g.M - 1 - m0);
         oa[p] = (uint32_t)(r * (int)g.lda + schunk * 8) * 2u;
     }
@@ -908,6 +911,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
             const int lchunk = ((((t_c >> 1) ^ key) << 1) | (t_c & 1));
             const int col = min(n0 + lchunk * 8, g.N - 8) - n0;
             ow[p] = (uint32_t)(row * (int)g.ldw + col) * 2u;
+            if constexpr (ATR) {
+                const int cola = min(m0 + lchunk * 8, g.M - 8) - m0;
+                oa[p] = (uint32_t)(row * (int)g.lda + cola) * 2u;
+            }
         }
     }
 #pragma unroll
@@ -918,7 +925,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
         else wr = min(w_row_of_slot<MODE>(n0, sl, g.I), n_rows_w - 1) - (MODE == MODE_GATED ? 0 : n0);
         ow[p] = (uint32_t)(wr * (int)g.ldw + schunk * 8) * 2u;
     }
-    const bf16* a_org = g.A + (int64_t)m0 * g.lda;
+    const bf16* a_org = ATR ? g.A + m0 : g.A + (int64_t)m0 * g.lda;
     const bf16* w_org = WTR ? g.W + n0 : ((MODE == MODE_GATED || ROPE) ? g.W : g.W + (int64_t)n0 * g.ldw);
     auto srd = [](const void* base) {
         const uint64_t b = (uint64_t)(uintptr_t)base;
@@ -929,7 +936,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
         r[3] = 0x00020000;
         return r;
     };
-    const v4i32 srdA = srd(a_org), srdW = srd(w_org);
+    v4i32 srdA = srd(a_org), srdW = srd(w_org);
+    if constexpr (ATR) {      // reduction rows past K read as zeros (the last k-tile of a token count that is no multiple of 64)
+        srdA[2] = __builtin_amdgcn_readfirstlane((int)(((int64_t)g.K * g.lda - m0) * 2));
+        srdW[2] = __builtin_amdgcn_readfirstlane((int)(((int64_t)g.K * g.ldw - n0) * 2));
+    }
     const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 15, fk = lane >> 4, sw = frow & 7;
     constexpr int W_BASE = NI == 9 ? A_BYTES : 2 * A_BYTES;
@@ -937,7 +948,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
     uint32_t rdW = (uint32_t)(W_BASE + (wn * NI * 16 + frow) * 128 + ((fk ^ sw) * 16));
     uint32_t wrA = (uint32_t)(wave * 8192 + lane * 16);
     uint32_t wrW = (uint32_t)(W_BASE + wave * (WTR ? 8 : NI) * 1024 + lane * 16);
-    const int nk = __builtin_amdgcn_readfirstlane(g.K / BK);
+    const int nk = __builtin_amdgcn_readfirstlane(ATR ? (g.K + BK - 1) / BK : g.K / BK);
 
     // folded RMSNorm, consumer side: 1 / rms of this tile's 256 rows into LDS behind the staging buffers (thread t: row t);
     // the loop's barriers order it before the epilogue's reads
@@ -962,7 +973,33 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
         }
         uint32_t rdA1 = rdA ^ 64u;
         const int wstep = __builtin_amdgcn_readfirstlane((int)(64 * g.ldw * 2));
-        if constexpr (NI == 8) {
+        if constexpr (ATR) {
+            uint32_t ra0[8], ra1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int unit = wm * 8 + j;
+                ra0[j] = ra1[j] = (uint32_t)((8 * tr_g + (tr_li >> 2)) * 512 + 8 * (tr_li & 3) + ((unit ^ tr_key) << 5));
+            }
+            const int astep = __builtin_amdgcn_readfirstlane((int)(64 * g.lda * 2));
+#define VGPT_W4_ATR_OPERANDS(NIW)                                                                                                 \
+            : VGPT_W4_OUTS_ [wrA] "+v"(wrA), [wrW] "+v"(wrW),                                                                      \
+              [ra0_0] "+v"(ra0[0]), [ra0_1] "+v"(ra0[1]), [ra0_2] "+v"(ra0[2]), [ra0_3] "+v"(ra0[3]), [ra0_4] "+v"(ra0[4]),          \
+              [ra0_5] "+v"(ra0[5]), [ra0_6] "+v"(ra0[6]), [ra0_7] "+v"(ra0[7]), [ra1_0] "+v"(ra1[0]), [ra1_1] "+v"(ra1[1]),          \
+              [ra1_2] "+v"(ra1[2]), [ra1_3] "+v"(ra1[3]), [ra1_4] "+v"(ra1[4]), [ra1_5] "+v"(ra1[5]), [ra1_6] "+v"(ra1[6]),          \
+              [ra1_7] "+v"(ra1[7]),                                                                                               \
+              [rw0_0] "+v"(rw0[0]), [rw0_1] "+v"(rw0[1]), [rw0_2] "+v"(rw0[2]), [rw0_3] "+v"(rw0[3]), [rw0_4] "+v"(rw0[4]),          \
+              [rw0_5] "+v"(rw0[5]), [rw0_6] "+v"(rw0[6]), [rw0_7] "+v"(rw0[7]), [rw1_0] "+v"(rw1[0]), [rw1_1] "+v"(rw1[1]),          \
+              [rw1_2] "+v"(rw1[2]), [rw1_3] "+v"(rw1[3]), [rw1_4] "+v"(rw1[4]), [rw1_5] "+v"(rw1[5]), [rw1_6] "+v"(rw1[6]),          \
+              [rw1_7] "+v"(rw1[7])                                                                                                \
+            : [srdA] "s"(srdA), [srdW] "s"(srdW), [nk] "s"(nk), [wv] "s"(wave), [wstep] "s"(wstep), [astep] "s"(astep),              \
+              [oa0] "v"(oa[0]), [oa1] "v"(oa[1]), [oa2] "v"(oa[2]), [oa3] "v"(oa[3]), [oa4] "v"(oa[4]), [oa5] "v"(oa[5]),            \
+              [oa6] "v"(oa[6]), [oa7] "v"(oa[7]), [ow0] "v"(ow[0]), [ow1] "v"(ow[1]), [ow2] "v"(ow[2]), [ow3] "v"(ow[3]),            \
+              [ow4] "v"(ow[4]), [ow5] "v"(ow[5]), [ow6] "v"(ow[6]), [ow7] "v"(ow[7])                                                \
+            : VGPT_W4_CLOBBERS_WTR
+            if constexpr (NI == 8) asm volatile(VGPT_W4_ASM_NI8_ATR VGPT_W4_ATR_OPERANDS(8));
+            else asm volatile(VGPT_W4_ASM_NI6_ATR VGPT_W4_ATR_OPERANDS(6));
+#undef VGPT_W4_ATR_OPERANDS
+        } else if constexpr (NI == 8) {
             asm volatile(VGPT_W4_ASM_NI8_WTR
                          : VGPT_W4_OUTS_ [rdA0] "+v"(rdA), [rdA1] "+v"(rdA1), [wrA] "+v"(wrA), [wrW] "+v"(wrW),
                            [rw0_0] "+v"(rw0[0]), [rw0_1] "+v"(rw0[1]), [rw0_2] "+v"(rw0[2]), [rw0_3] "+v"(rw0[3]), [rw0_4] "+v"(rw0[4]),
@@ -1464,12 +1501,12 @@ BigPlan plan_big(int64_t M, int64_t n_out, int bn_out, int64_t nk) {
 int g_family = 0;
 bool w4_enabled() { return g_family == 0; }
 
-template <int MODE, int NI, bool WTR = false>
+template <int MODE, int NI, bool WTR = false, bool ATR = false>
 int launch_w4_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
     constexpr int LDS = (NI == 9 ? 2 * (256 + 288) * BK * 2 : 128 * 1024) + 1024;   // staging buffers + the 256 rstd values of the folded RMSNorm
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_kernel<MODE, NI, WTR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_kernel<MODE, NI, WTR, ATR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             vgpt_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return VGPT_ERR_HIP;
@@ -1482,7 +1519,7 @@ int launch_w4_cfg(GemmArgs g, int64_t n_out, hipStream_t s, const char* name) {
 #endif
     g.tiles_m = (int)cdiv(g.M, 256);
     g.tiles_n = (int)cdiv(n_out, MODE == MODE_GATED ? BN / 2 : BN);
-    hipLaunchKernelGGL((gemm_w4_kernel<MODE, NI, WTR>), dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, s, g);
+    hipLaunchKernelGGL((gemm_w4_kernel<MODE, NI, WTR, ATR>), dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, s, g);
     VGPT_CHECK_LAUNCH(name);
     return VGPT_OK;
 }
@@ -1576,6 +1613,18 @@ int launch(const GemmArgs& g, int64_t n_out, hipStream_t s, const char* name) {
             w4_costs<MODE>(g, n_out, c256, c192);
             if (c192 < c256) return launch_w4_cfg<MODE, 6, true>(g, n_out, s, name);
             return launch_w4_cfg<MODE, 8, true>(g, n_out, s, name);
+        }
+    }
+    if constexpr (ATR && WTR && MODE == MODE_PLAIN) {
+        // dW = dY^T X of the backward on the four-wave kernel: both images natural [64 reduction rows][256 columns], fragments
+        // of both operands by ds_read_b64_tr_b16
+        if (f == 0 && w4_enabled() && g.K >= 2 * BK && g.M >= 8 && n_out >= 8 && big_tiles >= 128 &&
+            ((int64_t)g.K + 64) * g.lda * 2 < (1ll << 31) && ((int64_t)g.K + 64) * g.ldw * 2 < (1ll << 31) &&
+            g.ldc < (1 << 21) && g.ldr < (1 << 21)) {
+            double c256, c192;
+            w4_costs<MODE>(g, n_out, c256, c192);
+            if (c192 < c256) return launch_w4_cfg<MODE, 6, true, true>(g, n_out, s, name);
+            return launch_w4_cfg<MODE, 8, true, true>(g, n_out, s, name);
         }
     }
     if (f == 257) return launch_cfg<MODE, Cfg256, 0, ATR, WTR>(g, n_out, s, name);

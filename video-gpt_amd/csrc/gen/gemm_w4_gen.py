@@ -29,9 +29,10 @@ V_WRA, V_WRW = 236, 237
 V_OA, V_OW = 240, 248   # per-piece, per-lane source byte offsets (A: 8, W: up to 8): row clamped per lane, chunk swizzled
 V_LAST = 255
 S_KLOAD, S_KLAST, S_CNT = 56, 57, 58
-S_FIRST, S_LAST = 36, 71
+S_FIRST, S_LAST = 36, 73
 S_PIECE, S_TMP, S_DELTA = 36, 59, 53   # NI = 9: s36..s52 piece offsets, s53..s55 buffer deltas
 S_KLOADW, S_KLASTW = 70, 71            # transposed W: its own k offset (64 rows per k-tile)
+S_KLOADA, S_KLASTA = 72, 73            # transposed A (dW = dY^T X: both operands [K][..]): likewise
 # diagnostics (python gemm_w4_gen.py --debug N; results are garbage unless N == 16): 1 = no global fetches in the loop,
 # 2 = no LDS writes, 4 = no fragment reads, 8 = no barrier, 16 = s_memtime / s_memrealtime stamps around the loop and around
 # every barrier (outputs %[cyc], %[rt], %[bar]: loop cycles, loop time in 10-ns ticks, cycles spent at the barriers)
@@ -51,9 +52,11 @@ def vr(base, n=4):
 
 
 class Gen:
-    def __init__(self, NI, wtr=False):
+    def __init__(self, NI, wtr=False, atr=False):
         self.NI = NI
         self.wtr = wtr                    # W stored [K][N] (dX = dY W): fragments by ds_read_b64_tr_b16
+        self.atr = atr                    # A stored [K][M] too (dW = dY^T X): its image and fragments as W's
+        assert wtr or not atr
         self.PA, self.PW = 8, (8 if wtr else NI)   # pieces per wave and k-tile (a transposed W tile is a 256-column image)
         self.P = self.PA + self.PW
         if wtr:
@@ -139,7 +142,7 @@ class Gen:
             return
         if self.wtr:
             if p < self.PA:
-                self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, %[oa{p}], %[srdA], s{S_KLOAD} offen")
+                self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, %[oa{p}], %[srdA], s{S_KLOADA if self.atr else S_KLOAD} offen")
             else:
                 self.emit(f"buffer_load_dwordx4 {vr(self.piece_regs(p))}, %[ow{p - self.PA}], %[srdW], s{S_KLOADW} offen")
             return
@@ -175,6 +178,13 @@ class Gen:
     def read_A(self, s, j, in_loop=True):
         if in_loop and (DEBUG & 4):
             self.issue(("A", s, j)); self.done = len(self.lgkm); return
+        if self.atr:
+            a = self.A[s] + 4 * j
+            self.emit(f"ds_read_b64_tr_b16 {vr(a, 2)}, %[ra{s}_{j}] offset:{s * 32 * 512}")
+            self.issue(("Alo", s, j))
+            self.emit(f"ds_read_b64_tr_b16 {vr(a + 2, 2)}, %[ra{s}_{j}] offset:{s * 32 * 512 + 4 * 512}")
+            self.issue(("A", s, j))
+            return
         self.emit(f"ds_read_b128 {vr(self.A[s] + 4 * j)}, {self.RDA[s]} offset:{j * 2048}")
         self.issue(("A", s, j))
 
@@ -246,7 +256,9 @@ class Gen:
             if i == NI - 1:
                 # address toggles (VALU, no memory operation): the read addresses of the set just requested from
                 def tog():
-                    if self.wtr:
+                    if self.atr:
+                        self.toggle(tuple(f"%[ra{o}_{j_}]" for j_ in range(8)) + tuple(f"%[rw{o}_{i_}]" for i_ in range(NI)), o)
+                    elif self.wtr:
                         self.toggle((self.RDA[o],) + tuple(f"%[rw{o}_{i_}]" for i_ in range(NI)), o)
                     else:
                         self.toggle((self.RDA[o], self.RDW[o]), o)
@@ -265,6 +277,9 @@ class Gen:
         if self.wtr:      # a transposed W advances by 64 ROWS per k-tile
             self.emit(f"s_add_u32 s{S_KLOADW}, s{S_KLOADW}, %[wstep]")
             self.emit(f"s_min_u32 s{S_KLOADW}, s{S_KLOADW}, s{S_KLASTW}")
+        if self.atr:
+            self.emit(f"s_add_u32 s{S_KLOADA}, s{S_KLOADA}, %[astep]")
+            self.emit(f"s_min_u32 s{S_KLOADA}, s{S_KLOADA}, s{S_KLASTA}")
 
     def body(self, it):
         P, PA, PW = self.P, self.PA, self.PW
@@ -323,6 +338,9 @@ class Gen:
         if self.wtr:
             e(f"s_mov_b32 s{S_KLOADW}, 0")
             e(f"s_mul_i32 s{S_KLASTW}, s{S_KLAST}, %[wstep]")
+        if self.atr:
+            e(f"s_mov_b32 s{S_KLOADA}, 0")
+            e(f"s_mul_i32 s{S_KLASTA}, s{S_KLAST}, %[astep]")
         e(f"s_lshl_b32 s{S_KLAST}, s{S_KLAST}, 7")
         e(f"s_mov_b32 s{S_CNT}, %[nk]")
         first, second = self.first, self.second
@@ -355,7 +373,9 @@ class Gen:
             self.read_W(0, i, False)
             self.read_W(1, i, False)
         # the read addresses of set 0 now point at the buffer of tile 1 (they are toggled at the end of every k-step 1 ... see kstep)
-        if self.wtr:
+        if self.atr:
+            self.toggle(tuple(f"%[ra0_{j_}]" for j_ in range(8)) + tuple(f"%[rw0_{i_}]" for i_ in range(NI)), 0)
+        elif self.wtr:
             self.toggle((self.RDA[0],) + tuple(f"%[rw0_{i_}]" for i_ in range(NI)), 0)
         else:
             self.toggle((self.RDA[0], self.RDW[0]), 0)
@@ -416,12 +436,13 @@ def main():
            "// GENERATED by gen/gemm_w4_gen.py -- do not edit; `make gemm_w4_loop.inc` regenerates it.",
            "// The hand-scheduled main loop of gemm_w4_kernel (gemm_bf16.hip): see the generator for the schedule.",
            ""]
-    for NI, wtr in ((8, False), (6, False), (9, False), (8, True), (6, True)):
-        g = Gen(NI, wtr)
+    for NI, wtr, atr in ((8, False, False), (6, False, False), (9, False, False), (8, True, False), (6, True, False), (8, True, True),
+                         (6, True, True)):
+        g = Gen(NI, wtr, atr)
         lines = g.generate()
         n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
-        out.append(f"// NI = {NI}{', W transposed' if wtr else ''}: {len(lines)} lines, {n_mfma} MFMAs in the text (loop body {NI * 16})")
-        out.append(f"#define VGPT_W4_ASM_NI{NI}{'_WTR' if wtr else ''} \\")
+        out.append(f"// NI = {NI}{', A and W transposed' if atr else (', W transposed' if wtr else '')}: {len(lines)} lines, {n_mfma} MFMAs in the text (loop body {NI * 16})")
+        out.append(f"#define VGPT_W4_ASM_NI{NI}{'_ATR' if atr else ('_WTR' if wtr else '')} \\")
         out.append(" \\\n".join('    "' + l + '\\n\\t"' for l in lines))
         out.append("")
     for name, v0 in (("VGPT_W4_CLOBBERS", V_R), ("VGPT_W4_CLOBBERS_NI9", 20), ("VGPT_W4_CLOBBERS_WTR", 64)):
