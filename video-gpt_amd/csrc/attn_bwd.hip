@@ -494,6 +494,10 @@ __global__ __launch_bounds__(256, (WANT_DK && WANT_DV) ? 1 : 2) void attn_bwd_dk
 #pragma unroll
                     for (int i = 0; i < 16; ++i) dP[i] = S[i] * dP[i];   // the softmax scale multiplies dK once, in the epilogue
                 }
+                // no MFMA of the products below starts while the packed fp32 instructions above are in flight
+                // (scripts/attn_issue_probe.py: a v_pk_* beside an MFMA costs 53 cycles a group instead of 32; hipcc interleaved
+                // them): whole backward 866 / 875 against 880 / 881 us at the cfg-3 mask, scripts/attn_bwd_probe.py
+                __builtin_amdgcn_sched_barrier(0);
                 if constexpr (WANT_DV) {
                     bf16x8 Pf[2];
 #pragma unroll
