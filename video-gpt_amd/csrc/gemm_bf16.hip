@@ -1325,29 +1325,48 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs g) {
                 // X's odd lane rows for Y's even ones: an even group then holds columns 4 g .. 4 g + 7 of the first sub-tile,
                 // an odd group 4 (g - 1) .. 4 g + 3 of the second -- half the store instructions, whole 16-byte segments
                 // (the epilogue's burst of stores is issue-bound: MI355X_MICROARCH.md, T21).
-                constexpr int NPAIR = KEEP ? 0 : (NI / 2) / 2;
+                constexpr int NPAIR = (NI / 2) / 2;
                 static_for<0, NPAIR>([&](auto qc) {
                     constexpr int q = decltype(qc)::value;
-                    u32x2_t ob[2];
+                    u32x2_t ob[2], gb2[2], ub2[2];
                     static_for<0, 2>([&](auto hc) {
                         constexpr int p = 2 * q + decltype(hc)::value;
                         f32x4 gate = acc_of(std::integral_constant<int, 2 * p>{}, jc), up = acc_of(std::integral_constant<int, 2 * p + 1>{}, jc);
                         f32x4 o;
+                        if constexpr (KEEP) {      // training forward: [gate | up] rounded to bf16 leave too, the activation is formed
+                            bf16x4 gb, ub;         // from the rounded values (the un-fused pair's arithmetic)
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            if constexpr (NORM) { gate[t] *= rs; up[t] *= rs; }
-                            o[t] = act_apply(gate[t], ACT) * up[t];
+                            for (int t = 0; t < 4; ++t) {
+                                gb[t] = f2bf(gate[t]);
+                                ub[t] = f2bf(up[t]);
+                                o[t] = act_apply(bf2f(gb[t]), ACT) * bf2f(ub[t]);
+                            }
+                            gb2[decltype(hc)::value] = __builtin_bit_cast(u32x2_t, gb);
+                            ub2[decltype(hc)::value] = __builtin_bit_cast(u32x2_t, ub);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                if constexpr (NORM) { gate[t] *= rs; up[t] *= rs; }
+                                o[t] = act_apply(gate[t], ACT) * up[t];
+                            }
                         }
                         ob[decltype(hc)::value] = pack4(o);
                     });
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(ob[0][0], ob[1][0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(ob[0][1], ob[1][1], false, false);
+                    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                    auto widen = [&](const u32x2_t (&x)[2]) {
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(x[0][0], x[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(x[0][1], x[1][1], false, false);
+                        return u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+                    };
                     const int grp = lane >> 4;
                     const int nl = wn * (NI / 2) * 16 + (2 * q + (grp & 1)) * 16 + 4 * (grp & 2);
                     const bool ok = row_ok && n0 + nl < g.I;        // I % 16 == 0: the 8 columns are in or out together
-                    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-                    const u32x4_t data = {s0[0], s1[0], s0[1], s1[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(data, rsC, ok ? (uint32_t)(ml * (int)g.ldc + nl) * 2u : OOB, 0, 0);
+                    if constexpr (KEEP) {
+                        const uint32_t og = ok ? (uint32_t)(ml * (int)g.ld_gu + nl) * 2u : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(widen(gb2), rsG, og, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(widen(ub2), rsG, og, g.I * 2, 0);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(widen(ob), rsC, ok ? (uint32_t)(ml * (int)g.ldc + nl) * 2u : OOB, 0, 0);
                 });
                 static_for<2 * NPAIR, NI / 2>([&](auto pc) {
                     constexpr int p = decltype(pc)::value;
