@@ -187,6 +187,9 @@ def part1_ops(p, masked):
     return [(4, x) for x in pre + o]
 
 
+DMA_V_EARLY = int(os.environ.get("P2_DMA_V_EARLY", 1))
+
+
 def dma(op, j):
     """LDS-DMA piece j (of 3) of the K image of tile t+2 / the V image of tile t+1: 1 KiB, lane i's 16 bytes at base + offset
     land at M0 + 16 i.  Spread through the body: issued in one burst behind the barrier the four waves of a workgroup (and
@@ -194,8 +197,8 @@ def dma(op, j):
     o = []
     if j == 0:
         o.append(f"s_mov_b32 m0, %[{op}dst]")
-    else:
-        o.append("s_add_u32 m0, m0, 0x400")
+    else:       # (K and V pieces interleave: M0 is formed from the operand's base every time)
+        o.append(f"s_add_u32 m0, %[{op}dst], {j * 1024}")
     o += ["s_nop 0", f"global_load_lds_dwordx4 %[{op}o{j}], %[{op}base]"]
     return o
 
@@ -235,6 +238,12 @@ def phase_qk(sc, p_next, buf_next, valu, with_dma=False):
             for t in dma("k", (j - 1) // 4):
                 sc.emit(t)
             budget -= 8
+        if with_dma and DMA_V_EARLY and j in (3, 7, 11):
+            # V(t+1) goes out in THIS phase too: issued beside P.V its pieces had ~400 cycles before the next body's
+            # s_waitcnt vmcnt(0) -- a tile's worth of L2 latency was exposed at the top of every body
+            for t in dma("v", (j - 3) // 4):
+                sc.emit(t)
+            budget -= 8
         fill(sc, valu, budget)
     while valu:
         sc.emit(valu.pop(0)[1])
@@ -254,7 +263,7 @@ def phase_pv(sc, buf_cur, valu, with_dma=False, first_requested=True):
             sc.need({("v", j)})
             sc.emit(pv_mfma(j))
             budget = SLOT - (8 if (t < 3 and j == 3 * t) else 0)
-            if with_dma and j in (1, 5, 9):
+            if with_dma and not DMA_V_EARLY and j in (1, 5, 9):
                 for x in dma("v", (j - 1) // 4):
                     sc.emit(x)
                 budget -= 8
