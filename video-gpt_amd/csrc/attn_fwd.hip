@@ -641,10 +641,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
         //      full stage above already requested: same bytes to the same place, no branch in the body ----
         uint32_t e_n3v = n_act > 3 ? alist[4] : 0u;       // entry it + 3, read one body ahead of its use
         for (; it + 1 < n_act; ++it) {
-            STAMP(sA);
-            top_sync();                         // K(it+1), V(it) have landed; every wave is done with K(it) and V(it-1)
-            STAMP(sB);
-            if (it + 2 < n_act) mask_dma(buf, e_n2);                  // mask words of tile it + 2 over those of tile it
+            // (the operands of the body's LDS-DMA are formed BEFORE the wave parks at the barrier)
             const int kt_k = (int)((it + 2 < n_act ? e_n2 : e_cur) >> CODE_BITS), kt_v = (int)(e_nxt >> CODE_BITS);
             const char* k_src = reinterpret_cast<const char*>(kbase + (int64_t)kt_k * 64 * a.k_ss);
             const char* v_src = reinterpret_cast<const char*>(vbase + (int64_t)kt_v * 64 * a.v_ss);
@@ -670,6 +667,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 96 ? 2 : 1))) void at
             }
             const uint32_t k_dst = lds_base + (uint32_t)(buf * STAGE + wave * PIECES * 1024);
             const uint32_t v_dst = lds_base + (uint32_t)((buf ^ 1) * STAGE + wave * PIECES * 1024) + C::KBYTES;
+            STAMP(sA);
+            top_sync();                         // K(it+1), V(it) have landed; every wave is done with K(it) and V(it-1)
+            STAMP(sB);
+            if (it + 2 < n_act) mask_dma(buf, e_n2);                  // mask words of tile it + 2 over those of tile it
             VGPT_P2_MASK_WORDS(buf ^ 1, e_nxt)
             STAMP(sC);
             VGPT_P2_BODY(STEADY, masked);
