@@ -43,6 +43,7 @@ DEBUG = 0
 #          a half of the LDS store path no longer issue their writes in the same cycle
 SPLIT = False
 STAGGER = 0
+EARLY = True   # prologue: tile 1's first half requested beside tile 0 (--no-early: behind it, the first version)
 TAIL = 1      # trailing steps of a k-step that carry MFMAs only (--tail N): the LDS queue drains under them, in front of the barrier
 BUF_XOR = 0x8000
 
@@ -89,6 +90,7 @@ class Gen:
             self.WRA, self.WRW = "%[wrA]", "%[wrW]"
             self.sgpr_pieces = True
         self.lines = []
+        self.stash = {}                   # prologue only: piece -> registers that stand in for its staging registers
         self.lgkm = []                    # tags of issued LGKM operations, program order
         self.done = 0                     # lgkm[:done] are known complete
         self.waits = []                   # (iteration, position, text) of the counted waits, for the periodicity check
@@ -130,7 +132,7 @@ class Gen:
 
     # -- pieces --
     def piece_regs(self, p):
-        return self.R + 4 * p
+        return self.stash.get(p, self.R + 4 * p)
 
     def load_piece(self, p, in_loop=True):
         if in_loop and (DEBUG & 1):
@@ -347,22 +349,39 @@ class Gen:
         order = first + second
         for p in order:                                    # tile 0
             self.load_piece(p, False)
+        if EARLY:
+            # the first half of tile 1 is requested right behind tile 0, into the fragment registers of set 1 (free until the
+            # fragment reads below): its latency runs beside tile 0's instead of behind it -- one global round trip less in
+            # front of every tile's loop (one workgroup per CU: nothing else covers it)
+            self.advance_k()
+            slots = [self.A[1] + 4 * i for i in range(8)] + [self.W[1] + 4 * i for i in range(min(NI, 8))]
+            for idx, p in enumerate(first):
+                self.stash[p] = slots[idx]
+                self.load_piece(p, False)
+            self.stash = {}
         for a in range(0, min(NI, 8) * 32, 1):             # accumulators = 0 while the fetches fly
             e(f"v_accvgpr_write_b32 a{a}, 0")
         if NI > 8:
             for a in range(32):
                 e(f"v_mov_b32 v{self.ACC8 + a}, 0")
-        e("s_waitcnt vmcnt(0)")
+        e(f"s_waitcnt vmcnt({len(first) if EARLY else 0})")
         for p in order:
             self.write_piece(p, False)
-        self.advance_k()
-        for p in order:                                    # tile 1 (fetch order = the loop's consumption order)
-            self.load_piece(p, False)
+        if EARLY:
+            for p in second:                               # second half of tile 1: in flight in its staging registers, as in the loop
+                self.load_piece(p, False)
+        else:
+            self.advance_k()
+            for p in order:                                # tile 1 (fetch order = the loop's consumption order)
+                self.load_piece(p, False)
         self.toggle((self.WRA, self.WRW), 2)
         self.advance_k()
-        for p in first:                                    # "k-step 1 of tile -1": first half of tile 1 -> buffer 1, refetch for tile 2
+        for idx, p in enumerate(first):                    # "k-step 1 of tile -1": first half of tile 1 -> buffer 1, refetch for tile 2
             e(f"s_waitcnt vmcnt({P - 1})")
+            if EARLY:
+                self.stash[p] = slots[idx]
             self.write_piece(p, False)
+            self.stash = {}
             self.load_piece(p, False)
         self.drain()
         e("s_barrier")
@@ -430,6 +449,9 @@ def main():
     global TAIL
     if "--tail" in sys.argv:
         TAIL = int(sys.argv[sys.argv.index("--tail") + 1])
+    global EARLY
+    if "--no-early" in sys.argv:
+        EARLY = False
     if "--stagger" in sys.argv:
         STAGGER = int(sys.argv[sys.argv.index("--stagger") + 1])
     out = [f"// DIAGNOSTICS BUILD, debug = {DEBUG}" if DEBUG else "",
